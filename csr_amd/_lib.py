@@ -1,0 +1,89 @@
+"""
+ctypes binding of libcsrk.so (include/csrk.h).  This is the ONLY way the package computes:
+there is no CPU fallback.  If the library is missing the import fails loudly; if there is no
+GPU every compute call raises CsrkError carrying the HIP error text.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcsrk.so')
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_OVERFLOW = -1, -2, -3, -4
+VAL_NONE, VAL_F32, VAL_F64 = 0, 1, 2
+SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR = 0, 1, 2, 3
+
+
+class CsrkError(RuntimeError):
+    "A libcsrk call failed (message from csrk_last_error())."
+
+    def __init__(self, code, msg):
+        super().__init__(f'libcsrk error {code}: {msg}')
+        self.code = code
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} is not built: run `python csr_amd/build.py` (needs hipcc). '
+        'csr_amd has no CPU fallback.')
+
+lib = C.CDLL(LIB_PATH)
+
+handle_t = C.c_ssize_t     # intptr_t
+_vp = C.c_void_p
+_i32, _i64, _int = C.c_int32, C.c_int64, C.c_int
+
+# name -> (restype, argtypes); mirrors include/csrk.h one to one
+SIGNATURES = {
+    'csrk_version': (_int, []),
+    'csrk_last_error': (C.c_char_p, []),
+    'csrk_device_count': (_int, [C.POINTER(_int)]),
+    'csrk_set_device': (_int, [_int]),
+    'csrk_synchronize': (_int, [_vp]),
+    'csrk_create': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
+    'csrk_create_device': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
+    'csrk_free': (_int, [handle_t]),
+    'csrk_info': (_int, [handle_t, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64),
+                         C.POINTER(_int), C.POINTER(_int)]),
+    'csrk_export': (_int, [handle_t, _vp, _vp, _vp]),
+    'csrk_device_ptrs': (_int, [handle_t, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    'csrk_spmv': (_int, [handle_t, _vp, _vp]),
+    'csrk_spmv_device': (_int, [handle_t, _vp, _vp, _vp]),
+    'csrk_set_spmv_algo': (_int, [handle_t, _int]),
+    'csrk_spmv_algo_name': (C.c_char_p, [handle_t]),
+    'csrk_spmv_plan_info': (_int, [handle_t, C.POINTER(_i64), C.POINTER(_i32)]),
+    'csrk_spgemm_ab': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
+    'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
+    'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),
+    'csrk_spmm_dense_device': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64, _vp]),
+    'csrk_transpose': (_int, [handle_t, _int, C.POINTER(handle_t)]),
+    'csrk_row_nnzs': (_int, [handle_t, _vp]),
+    'csrk_row_extent': (_int, [handle_t, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    'csrk_unit_rows': (_int, [handle_t, _vp]),
+    'csrk_center_rows': (_int, [handle_t, _vp]),
+    'csrk_order_columns': (_int, [handle_t]),
+    'csrk_filter_zeros': (_int, [handle_t, C.POINTER(handle_t)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)       # AttributeError here = header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.csrk_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != OK:
+        msg = last_error()
+        if rc == ERR_INVALID:
+            raise ValueError(f'libcsrk: {msg}')
+        raise CsrkError(rc, msg)
+
+
+def ptr(a):
+    "data pointer of a numpy array (or None)"
+    return None if a is None else a.ctypes.data_as(_vp)

@@ -1,0 +1,324 @@
+"""
+Host-side CSR container: the struct the reference keeps in csr/csr.py:46-100
+(nrows, ncols, nnz, rowptrs, colinds, values) with the methods that sit on the
+`csr.kernels` hot path.  The arrays live in NumPy on the host exactly as in the
+reference; every arithmetic method hands them to the active kernel (csr_amd.kernels.hip by
+default), which runs hand-written HIP kernels on the MI355X.  Only index bookkeeping that
+the reference itself does in NumPy on the host (subset_rows views, shard split points,
+shard reassembly) is done here.
+
+Layout rules kept verbatim (csr/csr.py:79-100): rowptrs int32 when nnz <= INT32_MAX else
+int64; colinds int32; values any float dtype or None; all C-contiguous.
+"""
+import logging
+
+import numpy as np
+
+from .kernels import get_kernel, releasing
+
+INTC = np.iinfo(np.intc)
+_log = logging.getLogger(__name__)
+
+
+class CSR:
+    """
+    Compressed sparse row matrix (host arrays), drop-in for the reference's `csr.CSR` on the
+    kernel hot path.
+
+    Attributes: nrows, ncols, nnz, rowptrs, colinds, values (None = structure only).
+    """
+
+    def __init__(self, nrows, ncols, nnz, rps, cis, vs, _cast=True):
+        # csr/csr.py:79-100
+        assert nrows >= 0 and nrows <= INTC.max
+        assert ncols >= 0 and ncols <= INTC.max
+        assert nnz >= 0
+        self.nrows = int(nrows)
+        self.ncols = int(ncols)
+        self.nnz = int(nnz)
+        if _cast:
+            cis = np.require(cis, np.intc, 'C')
+            if nnz <= INTC.max:
+                rps = np.require(rps, np.intc, 'C')
+            else:
+                rps = np.require(rps, np.int64, 'C')
+            if vs is not None:
+                vs = np.require(vs, requirements='C')
+        self.rowptrs = rps
+        self.colinds = cis
+        self._values = vs
+
+    # ---- construction ---------------------------------------------------------------------
+    @classmethod
+    def empty(cls, nrows, ncols, row_nnzs=None, values=True):
+        "csr/csr.py:102-136"
+        assert nrows >= 0 and ncols >= 0
+        if row_nnzs is None:
+            return cls(nrows, ncols, 0, np.zeros(nrows + 1, dtype=np.intc), np.zeros(0, dtype=np.intc),
+                       np.zeros(0))
+        assert len(row_nnzs) == nrows
+        nnz = int(np.sum(row_nnzs, dtype=np.int64))
+        rp_dtype = np.intc if nnz <= INTC.max else np.int64
+        rps = np.zeros(nrows + 1, dtype=rp_dtype)
+        np.cumsum(row_nnzs, dtype=rp_dtype, out=rps[1:])
+        cis = np.zeros(nnz, dtype=np.int32)
+        if values is True:
+            vs = np.zeros(nnz)
+        elif values:
+            vs = np.zeros(nnz, dtype=values)
+        else:
+            vs = None
+        return cls(nrows, ncols, nnz, rps, cis, vs)
+
+    @classmethod
+    def from_coo(cls, rows, cols, vals, shape=None):
+        """
+        csr/csr.py:138-169 -> csr/structure.py:11-67: stable counting sort of the COO entries
+        by row (entries of a row keep their input order).  Host-side ingest, not on the hot
+        path (out of scope); done with a stable NumPy argsort.
+        """
+        rows = np.asarray(rows)
+        cols = np.asarray(cols)
+        assert np.min(rows, initial=0) >= 0 and np.min(cols, initial=0) >= 0
+        if shape is not None:
+            nrows, ncols = shape
+            assert np.max(rows, initial=0) < max(nrows, 1)
+            assert np.max(cols, initial=0) < max(ncols, 1)
+        else:
+            nrows = int(np.max(rows)) + 1
+            ncols = int(np.max(cols)) + 1
+        nnz = len(rows)
+        assert len(cols) == nnz and (vals is None or len(vals) == nnz)
+        order = np.argsort(rows, kind='stable')
+        rps = np.zeros(nrows + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=nrows), out=rps[1:])
+        return cls(nrows, ncols, nnz, rps, cols[order], None if vals is None else np.asarray(vals)[order])
+
+    @classmethod
+    def from_scipy(cls, mat, copy=True):
+        "csr/csr.py:171-192"
+        import scipy.sparse as sps
+        if not sps.isspmatrix_csr(mat):
+            mat = mat.tocsr(copy=copy)
+        rp = np.require(mat.indptr, np.intc, 'C')
+        cs = np.require(mat.indices, np.intc, 'C')
+        vs = mat.data
+        if copy:
+            rp, cs, vs = rp.copy(), cs.copy(), vs.copy()
+        return cls(mat.shape[0], mat.shape[1], mat.nnz, rp, cs, vs)
+
+    def to_scipy(self):
+        "csr/csr.py:194-209"
+        import scipy.sparse as sps
+        values = self.values
+        if values is None:
+            values = np.full(self.nnz, 1.0)
+        return sps.csr_matrix((values, self.colinds, self.rowptrs), shape=(self.nrows, self.ncols))
+
+    # ---- fields ---------------------------------------------------------------------------
+    @property
+    def values(self):
+        return self._values
+
+    @values.setter
+    def values(self, vs):
+        "csr/csr.py:224-242"
+        if vs is not None:
+            if len(vs) < self.nnz:
+                raise ValueError('value array too small')
+            elif len(vs) > self.nnz:
+                vs = vs[:self.nnz]
+            vs = np.require(vs, requirements='C')
+        self._values = vs
+
+    def copy(self, include_values=True, *, copy_structure=True):
+        "csr/csr.py:298-321"
+        values = self.values
+        values = np.copy(values) if include_values and values is not None else None
+        rps, cis = self.rowptrs, self.colinds
+        if copy_structure:
+            rps, cis = np.copy(rps), np.copy(cis)
+        return CSR(self.nrows, self.ncols, self.nnz, rps, cis, values)
+
+    # ---- rows -----------------------------------------------------------------------------
+    def row_extent(self, row):
+        "csr/csr.py:406-417 -> csr/_rows.py:9-13 (host field read, as in the reference)"
+        return self.rowptrs[row], self.rowptrs[row + 1]
+
+    def row_nnzs(self):
+        "csr/csr.py:432-441.  Host diff like the reference; the device version is kernel.row_nnzs."
+        return np.diff(self.rowptrs)
+
+    def row_cs(self, row):
+        sp, ep = self.row_extent(row)
+        return self.colinds[sp:ep]
+
+    def row_vs(self, row):
+        sp, ep = self.row_extent(row)
+        if self.values is None:
+            return np.full(ep - sp, 1.0)
+        return self.values[sp:ep]
+
+    def row(self, row):
+        "csr/csr.py:370-386 (single row only): dense copy of one row"
+        sp, ep = self.row_extent(row)
+        if self.values is None:
+            v = np.zeros(self.ncols, dtype=np.float32)
+            v[self.colinds[sp:ep]] = 1
+        else:
+            v = np.zeros(self.ncols, dtype=self.values.dtype)
+            v[self.colinds[sp:ep]] = self.values[sp:ep]
+        return v
+
+    def subset_rows(self, begin, end):
+        "csr/csr.py:331-346 -> csr/structure.py:70-81: views of colinds/values, rebased pointers"
+        st = self.rowptrs[begin]
+        ed = self.rowptrs[end]
+        rps = self.rowptrs[begin:(end + 1)] - st
+        cis = self.colinds[st:ed]
+        vs = self.values[st:ed] if self.values is not None else None
+        return CSR(end - begin, self.ncols, ed - st, rps, cis, vs)
+
+    # ---- device operations beyond the kernel protocol -----------------------------------------
+    def _ext(self, name):
+        K = get_kernel()
+        fn = getattr(K, name, None)
+        if fn is None:
+            raise NotImplementedError(f'kernel {K.__name__} does not provide {name}')
+        return K, fn
+
+    def transpose(self, include_values=True):
+        """
+        csr/csr.py:471-486 -> csr/structure.py:240-247.  Runs on the device; bit-exact with the
+        reference (stable counting sort, float64 output values, input pointer width).
+        """
+        K, tr = self._ext('transpose')
+        with releasing(K.to_handle(self), K) as h:
+            with releasing(tr(h, include_values), K) as th:
+                return K.from_handle(th)
+
+    def transpose_structure(self):
+        return self.transpose(False)
+
+    def normalize_rows(self, normalization):
+        "csr/csr.py:443-469 -> csr/transform.py: in place; returns the per-row norms / means"
+        if normalization not in ('center', 'unit'):
+            raise ValueError('unknown normalization: ' + normalization)
+        K, fn = self._ext('center_rows' if normalization == 'center' else 'unit_rows')
+        with releasing(K.to_handle(self), K) as h:
+            stat = fn(h)
+            self._values[...] = K.values_of(h)
+        return stat
+
+    def sort_rows(self):
+        "csr/csr.py:323-329 -> csr/structure.py:156-169, in place, via the kernel's order_columns"
+        K = get_kernel()
+        with releasing(K.to_handle(self), K) as h:
+            K.order_columns(h)
+            out = K.from_handle(h)
+        self.colinds[...] = out.colinds
+        if self._values is not None:
+            self._values[...] = out.values
+
+    # ---- the kernel protocol's callers --------------------------------------------------------
+    def multiply(self, other, transpose=False):
+        """
+        csr/csr.py:524-567: A @ B (or A @ B^T).  Handle lifetime, row sharding above
+        K.max_nnz and the exact-zero filter on the product follow the reference.
+        """
+        if transpose:
+            assert self.ncols == other.ncols
+        else:
+            assert self.ncols == other.nrows
+        K = get_kernel()
+        dev_filter = getattr(K, 'filter_zeros', None)
+
+        def mul(A, b_h):
+            with releasing(K.to_handle(A), K) as a_h:
+                c_h = K.mult_abt(a_h, b_h) if transpose else K.mult_ab(a_h, b_h)
+                with releasing(c_h, K):
+                    if dev_filter is not None:
+                        with releasing(dev_filter(c_h), K) as f_h:
+                            return K.from_handle(f_h)
+                    crepr = K.from_handle(c_h)
+            crepr._filter_zeros()
+            return crepr
+
+        if self.nnz <= K.max_nnz:
+            with releasing(K.to_handle(other), K) as b_h:
+                return mul(self, b_h)
+        shards = self._shard_rows(K.max_nnz)
+        with releasing(K.to_handle(other), K) as b_h:
+            sparts = [mul(s, b_h) for s in shards]
+        return CSR._assemble_shards(sparts)
+
+    def mult_vec(self, v):
+        "csr/csr.py:569-590"
+        v = np.asarray(v)
+        assert v.shape == (self.ncols,)
+        K = get_kernel()
+        if self.nnz <= K.max_nnz:
+            with releasing(K.to_handle(self), K) as h:
+                return K.mult_vec(h, v)
+        svs = []
+        for s in self._shard_rows(K.max_nnz):
+            with releasing(K.to_handle(s), K) as h:
+                svs.append(K.mult_vec(h, v))
+        return np.concatenate(svs)
+
+    def _filter_zeros(self):
+        """
+        csr/csr.py:592-597 -> csr/_struct.py:61-76, host flavour for kernels without a device
+        filter: drop entries whose value is exactly 0 (NaN stays), in place.
+        """
+        if self.values is None:
+            return
+        keep = self.values != 0
+        cum = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+        self.rowptrs = cum[self.rowptrs].astype(self.rowptrs.dtype)
+        self.colinds = np.ascontiguousarray(self.colinds[keep])
+        self._values = np.ascontiguousarray(self.values[keep])
+        self.nnz = int(cum[-1])
+
+    def _shard_rows(self, tgt_nnz):
+        "csr/csr.py:599-621"
+        assert tgt_nnz > 0
+        rest = self
+        shards = []
+        while rest.nnz > tgt_nnz:
+            split = int(np.searchsorted(rest.rowptrs, tgt_nnz))
+            if rest.rowptrs[split] > tgt_nnz:
+                if split <= 1:
+                    raise ValueError("row too large to fit in target matrix size")
+                split -= 1
+            _log.debug('splitting %s at %d (rp@s: %d)', rest, split, rest.rowptrs[split])
+            shards.append(rest.subset_rows(0, split))
+            rest = rest.subset_rows(split, rest.nrows)
+        shards.append(rest)
+        return shards
+
+    @classmethod
+    def _assemble_shards(cls, shards):
+        "csr/csr.py:623-650"
+        nrows = sum(s.nrows for s in shards)
+        ncols = max(s.ncols for s in shards)
+        nnz = sum(s.nnz for s in shards)
+        rps = np.zeros(nrows + 1, np.int64)
+        rs = 0
+        for s in shards:
+            off = rps[rs]
+            rps[rs:rs + s.nrows + 1] = s.rowptrs + off
+            rs += s.nrows
+        assert rps[nrows] == nnz, f'{rps[nrows]} != {nnz}'
+        cis = np.concatenate([s.colinds for s in shards])
+        vs = np.concatenate([s.values for s in shards]) if shards[0].values is not None else None
+        return cls(nrows, ncols, nnz, rps, cis, vs)
+
+    def __str__(self):
+        return '<CSR {}x{} ({} nnz)>'.format(self.nrows, self.ncols, self.nnz)
+
+    __repr__ = __str__
+
+    def __reduce__(self):
+        "csr/csr.py:690-692"
+        return (CSR, (self.nrows, self.ncols, self.nnz, self.rowptrs, self.colinds, self.values, False))

@@ -1,0 +1,272 @@
+// Handle lifecycle of libcsrk: create / free / export / info, plus the trivial row-pointer
+// queries.  Replaces to_handle / from_handle / release_handle of the reference's kernel
+// protocol (csr/kernels/numba/__init__.py:16-44; csr/kernels/mkl/handle.py:61-148) and
+// row_extent / row_nnzs (csr/_rows.py:9-13, csr/csr.py:432-441).
+#include "common.h"
+
+namespace csrk {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+Matrix::~Matrix()
+{
+    if (spmv_plan) free_spmv_plan(spmv_plan);
+    if (spmm_plan) free_spmm_plan(spmm_plan);
+    if (owns) {
+        if (d_rowptrs) (void)hipFree(d_rowptrs);
+        if (d_colinds) (void)hipFree(d_colinds);
+        if (d_values) (void)hipFree(d_values);
+    }
+    magic = 0;
+}
+
+Matrix *from_handle(csrk_handle_t h)
+{
+    Matrix *m = reinterpret_cast<Matrix *>(h);
+    if (!m || m->magic != 0x4353524b) {
+        set_error("invalid csrk handle %p", (void *)h);
+        return nullptr;
+    }
+    return m;
+}
+
+int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_type, Matrix **out)
+{
+    Matrix *m = new (std::nothrow) Matrix();
+    if (!m) {
+        set_error("out of host memory");
+        return CSRK_ERR_INVALID;
+    }
+    m->nrows = nrows;
+    m->ncols = ncols;
+    m->nnz = nnz;
+    m->ptr64 = ptr64 ? 1 : 0;
+    m->val_type = val_type;
+    m->owns = true;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error("hipGetDevice failed: %s", hipGetErrorString(e));
+        delete m;
+        return CSRK_ERR_HIP;
+    }
+    m->device = dev;
+    size_t rp_bytes = (size_t)(nrows + 1) * m->ptr_bytes();
+    size_t ci_bytes = (size_t)nnz * 4;
+    size_t vs_bytes = (size_t)nnz * m->val_bytes();
+    e = hipMalloc(&m->d_rowptrs, rp_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_colinds, ci_bytes ? ci_bytes : 16);
+    if (e == hipSuccess && val_type != CSRK_VAL_NONE) e = hipMalloc(&m->d_values, vs_bytes ? vs_bytes : 16);
+    if (e != hipSuccess) {
+        set_error("hipMalloc failed for %lld-nnz matrix: %s", (long long)nnz, hipGetErrorString(e));
+        delete m;
+        return CSRK_ERR_HIP;
+    }
+    *out = m;
+    return CSRK_OK;
+}
+
+template <class P>
+__global__ void row_nnzs_kernel(const P *__restrict__ rp, P *__restrict__ out, int32_t nrows)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) out[i] = rp[i + 1] - rp[i];
+}
+
+}  // namespace csrk
+
+using namespace csrk;
+
+extern "C" {
+
+int csrk_version(void) { return 1; }
+
+const char *csrk_last_error(void) { return g_last_error.c_str(); }
+
+int csrk_device_count(int *count)
+{
+    CSRK_REQUIRE(count, "count is NULL");
+    *count = 0;
+    CSRK_HIP(hipGetDeviceCount(count));
+    return CSRK_OK;
+}
+
+int csrk_set_device(int device)
+{
+    CSRK_HIP(hipSetDevice(device));
+    return CSRK_OK;
+}
+
+int csrk_synchronize(void *stream)
+{
+    CSRK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return CSRK_OK;
+}
+
+static int check_dims(int32_t nrows, int32_t ncols, int64_t nnz, const void *rowptrs,
+                      const void *colinds, const void *values, int val_type)
+{
+    CSRK_REQUIRE(nrows >= 0 && ncols >= 0 && nnz >= 0, "negative dimension (%d x %d, nnz %lld)",
+                 nrows, ncols, (long long)nnz);
+    CSRK_REQUIRE(rowptrs, "rowptrs is NULL");
+    CSRK_REQUIRE(nnz == 0 || colinds, "colinds is NULL");
+    CSRK_REQUIRE(val_type == CSRK_VAL_NONE || val_type == CSRK_VAL_F32 || val_type == CSRK_VAL_F64,
+                 "unknown val_type %d", val_type);
+    CSRK_REQUIRE(val_type == CSRK_VAL_NONE || nnz == 0 || values, "values is NULL but val_type=%d", val_type);
+    return CSRK_OK;
+}
+
+int csrk_create(int32_t nrows, int32_t ncols, int64_t nnz, const void *rowptrs, int ptr_is_64,
+                const int32_t *colinds, const void *values, int val_type, csrk_handle_t *out)
+{
+    CSRK_REQUIRE(out, "out is NULL");
+    *out = 0;
+    CSRK_TRY(check_dims(nrows, ncols, nnz, rowptrs, colinds, values, val_type));
+    CSRK_REQUIRE(ptr_is_64 || nnz <= INT32_MAX, "nnz %lld needs 64-bit row pointers", (long long)nnz);
+    // The host arrays are trusted like the reference trusts them, except for the one
+    // invariant every kernel's bounds rely on.
+    int64_t last = ptr_is_64 ? ((const int64_t *)rowptrs)[nrows] : (int64_t)((const int32_t *)rowptrs)[nrows];
+    int64_t first = ptr_is_64 ? ((const int64_t *)rowptrs)[0] : (int64_t)((const int32_t *)rowptrs)[0];
+    CSRK_REQUIRE(first == 0 && last == nnz, "rowptrs[0]=%lld, rowptrs[nrows]=%lld but nnz=%lld",
+                 (long long)first, (long long)last, (long long)nnz);
+    Matrix *m = nullptr;
+    CSRK_TRY(new_matrix(nrows, ncols, nnz, ptr_is_64, val_type, &m));
+    hipError_t e = hipMemcpy(m->d_rowptrs, rowptrs, (size_t)(nrows + 1) * m->ptr_bytes(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(m->d_colinds, colinds, (size_t)nnz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz && val_type != CSRK_VAL_NONE)
+        e = hipMemcpy(m->d_values, values, (size_t)nnz * m->val_bytes(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("host-to-device copy failed: %s", hipGetErrorString(e));
+        delete m;
+        return CSRK_ERR_HIP;
+    }
+    *out = to_handle(m);
+    return CSRK_OK;
+}
+
+int csrk_create_device(int32_t nrows, int32_t ncols, int64_t nnz, const void *d_rowptrs, int ptr_is_64,
+                       const int32_t *d_colinds, const void *d_values, int val_type, csrk_handle_t *out)
+{
+    CSRK_REQUIRE(out, "out is NULL");
+    *out = 0;
+    CSRK_TRY(check_dims(nrows, ncols, nnz, d_rowptrs, d_colinds, d_values, val_type));
+    CSRK_REQUIRE(ptr_is_64 || nnz <= INT32_MAX, "nnz %lld needs 64-bit row pointers", (long long)nnz);
+    Matrix *m = new (std::nothrow) Matrix();
+    CSRK_REQUIRE(m, "out of host memory");
+    m->nrows = nrows;
+    m->ncols = ncols;
+    m->nnz = nnz;
+    m->ptr64 = ptr_is_64 ? 1 : 0;
+    m->val_type = val_type;
+    m->owns = false;
+    m->d_rowptrs = const_cast<void *>(d_rowptrs);
+    m->d_colinds = const_cast<int32_t *>(d_colinds);
+    m->d_values = const_cast<void *>(d_values);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error("hipGetDevice failed: %s", hipGetErrorString(e));
+        delete m;
+        return CSRK_ERR_HIP;
+    }
+    m->device = dev;
+    *out = to_handle(m);
+    return CSRK_OK;
+}
+
+int csrk_free(csrk_handle_t h)
+{
+    if (h == 0) return CSRK_OK;
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    delete m;
+    return CSRK_OK;
+}
+
+int csrk_info(csrk_handle_t h, int32_t *nrows, int32_t *ncols, int64_t *nnz, int *ptr_is_64, int *val_type)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    if (nrows) *nrows = m->nrows;
+    if (ncols) *ncols = m->ncols;
+    if (nnz) *nnz = m->nnz;
+    if (ptr_is_64) *ptr_is_64 = m->ptr64;
+    if (val_type) *val_type = m->val_type;
+    return CSRK_OK;
+}
+
+int csrk_export(csrk_handle_t h, void *rowptrs, int32_t *colinds, void *values)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(m->mu);
+    CSRK_HIP(hipDeviceSynchronize());
+    if (rowptrs)
+        CSRK_HIP(hipMemcpy(rowptrs, m->d_rowptrs, (size_t)(m->nrows + 1) * m->ptr_bytes(), hipMemcpyDeviceToHost));
+    if (colinds && m->nnz)
+        CSRK_HIP(hipMemcpy(colinds, m->d_colinds, (size_t)m->nnz * 4, hipMemcpyDeviceToHost));
+    if (values && m->nnz && m->val_type != CSRK_VAL_NONE)
+        CSRK_HIP(hipMemcpy(values, m->d_values, (size_t)m->nnz * m->val_bytes(), hipMemcpyDeviceToHost));
+    return CSRK_OK;
+}
+
+int csrk_device_ptrs(csrk_handle_t h, void **d_rowptrs, void **d_colinds, void **d_values)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    if (d_rowptrs) *d_rowptrs = m->d_rowptrs;
+    if (d_colinds) *d_colinds = m->d_colinds;
+    if (d_values) *d_values = m->d_values;
+    return CSRK_OK;
+}
+
+int csrk_row_nnzs(csrk_handle_t h, void *out)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(out || m->nrows == 0, "out is NULL");
+    if (m->nrows == 0) return CSRK_OK;
+    std::lock_guard<std::mutex> lk(m->mu);
+    DevBuf d;
+    CSRK_TRY(d.alloc((size_t)m->nrows * m->ptr_bytes()));
+    int grid = (int)ceil_div(m->nrows, 256);
+    if (m->ptr64)
+        row_nnzs_kernel<int64_t><<<grid, 256>>>((const int64_t *)m->d_rowptrs, d.as<int64_t>(), m->nrows);
+    else
+        row_nnzs_kernel<int32_t><<<grid, 256>>>((const int32_t *)m->d_rowptrs, d.as<int32_t>(), m->nrows);
+    CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipMemcpy(out, d.p, (size_t)m->nrows * m->ptr_bytes(), hipMemcpyDeviceToHost));
+    return CSRK_OK;
+}
+
+int csrk_row_extent(csrk_handle_t h, int32_t row, int64_t *start, int64_t *end)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(row >= 0 && row < m->nrows, "row %d out of range [0, %d)", row, m->nrows);
+    CSRK_REQUIRE(start && end, "start/end is NULL");
+    if (m->ptr64) {
+        int64_t se[2];
+        CSRK_HIP(hipMemcpy(se, (const int64_t *)m->d_rowptrs + row, 16, hipMemcpyDeviceToHost));
+        *start = se[0];
+        *end = se[1];
+    } else {
+        int32_t se[2];
+        CSRK_HIP(hipMemcpy(se, (const int32_t *)m->d_rowptrs + row, 8, hipMemcpyDeviceToHost));
+        *start = se[0];
+        *end = se[1];
+    }
+    return CSRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,472 @@
+// SpMV (y = A x) for libcsrk on gfx950.  Replaces the reference's mult_vec
+// (csr/kernels/numba/__init__.py:55-67: one sequential pass over nnz with a moving row
+// cursor) and lk_mkl_spmv (csr/kernels/mkl/mkl_ops.c:116-126).
+//
+// Three kernels, selected per handle (csrk_set_spmv_algo; AUTO = merge):
+//
+//  merge   Merge-path tiles.  The path over (row ends, nnz) is cut into tiles of a fixed
+//          number of ITEMS = rows + nnz, so a tile's work is bounded whatever the row-length
+//          distribution (power-law rows, millions of empty rows, one 10^6-entry row).
+//          One 256-thread workgroup per tile:
+//            phase 1  streams the tile's colinds/values fully coalesced, gathers x[col],
+//                     and stages the products in LDS; loads the tile's row ends to LDS;
+//            phase 2  one lane per row sums its (short) row from LDS in storage order --
+//                     the reference's order, so short rows are bit-identical to it -- and
+//                     rows with >= 64 entries in the tile are summed by a whole wavefront
+//                     (strided partials + __shfl_down tree);
+//          a row cut by a tile boundary leaves one partial per tile in carry[], and a
+//          second tiny kernel adds each row's partials in tile order (no float atomics:
+//          results are bitwise reproducible run to run).
+//          HBM traffic per nnz: 4 B colind + 8 B value, read exactly once, + the x gather;
+//          per row: 4/8 B row pointer + 8 B y.
+//  vector  One wavefront per row segment (rows longer than 4096 entries are split);
+//          coalesced 64-lane strides over colinds/values, __shfl_down reduction, ordered
+//          partial combine.  The classic CSR-vector shape; best when most rows are >= 64.
+//  scalar  One lane per row.  Best for tiny uniform rows; kept mainly as an A/B baseline.
+//
+// All kernels accumulate in float64 whatever the storage dtype, like the reference
+// (float32 values are widened on load; structure-only matrices multiply by 1.0,
+// csr/csr.py:254-262).
+#include "common.h"
+
+namespace csrk {
+
+// ---- value loads ------------------------------------------------------------------------
+template <int VT> struct ValLoad;
+template <> struct ValLoad<CSRK_VAL_F64> {
+    static __device__ __forceinline__ double at(const void *v, int64_t k) { return ((const double *)v)[k]; }
+};
+template <> struct ValLoad<CSRK_VAL_F32> {
+    static __device__ __forceinline__ double at(const void *v, int64_t k) { return (double)((const float *)v)[k]; }
+};
+template <> struct ValLoad<CSRK_VAL_NONE> {
+    static __device__ __forceinline__ double at(const void *, int64_t) { return 1.0; }
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+// ---- plan ---------------------------------------------------------------------------------
+struct SpmvPlan {
+    int algo = CSRK_SPMV_MERGE;
+    // merge
+    int tile_items = 0;
+    int64_t n_tiles = 0;
+    DevBuf tile_row;    // int32[n_tiles + 1]: rows completed before each tile boundary
+    DevBuf carry_row;   // int32[n_tiles]
+    DevBuf carry_val;   // double[n_tiles]
+    // vector
+    int64_t n_segs = 0;
+    DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
+    DevBuf seg_row;     // int32[n_segs]
+    DevBuf seg_part;    // double[n_segs]
+};
+
+void free_spmv_plan(SpmvPlan *p) { delete p; }
+
+constexpr int MERGE_THREADS = 256;
+constexpr int MERGE_IPT = 8;
+constexpr int MERGE_ITEMS = MERGE_THREADS * MERGE_IPT;   // 2048 path items per tile
+constexpr int MERGE_LONG = 64;                           // rows this long get a whole wave
+constexpr int MERGE_MAXLONG = MERGE_ITEMS / MERGE_LONG + 2;
+
+// tile_row[t] = number of row ends consumed before merge-path diagonal d = min(t*ITEMS, nrows+nnz).
+// Row end r (= rp[r+1]) is consumed once all its nnz are: it lies before diagonal d iff
+// rp[r+1] + r + 1 <= d.
+template <class P>
+__global__ void merge_plan_kernel(const P *__restrict__ rp, int32_t nrows, int64_t nnz, int items,
+                                  int64_t n_tiles, int32_t *__restrict__ tile_row)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    int64_t total = (int64_t)nrows + nnz;
+    int64_t d = t * items;
+    if (d > total) d = total;
+    int64_t lo = d - nnz > 0 ? d - nnz : 0;
+    int64_t hi = d < nrows ? d : nrows;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rp[mid + 1] <= d - mid - 1)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    tile_row[t] = (int32_t)lo;
+}
+
+template <class P, int VT>
+__global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
+    const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
+    const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
+    int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
+{
+    __shared__ double s_prod[MERGE_ITEMS];
+    __shared__ int32_t s_rend[MERGE_ITEMS + 1];
+    __shared__ int32_t s_long[MERGE_MAXLONG];
+    __shared__ int32_t s_nlong;
+
+    const int tid = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int32_t i0 = tile_row[t], i1 = tile_row[t + 1];
+    const int64_t total = (int64_t)nrows + nnz;
+    const int64_t d0 = t * MERGE_ITEMS;
+    const int64_t d1 = d0 + MERGE_ITEMS < total ? d0 + MERGE_ITEMS : total;
+    const int64_t j0 = d0 - i0;
+    const int nn = (int)((d1 - i1) - j0);   // nnz in this tile
+    const int nr = i1 - i0;                 // rows completed in this tile
+    if (tid == 0) s_nlong = 0;
+
+    // phase 1a: products, coalesced; issue every colind load before the dependent gathers
+    int32_t col[MERGE_IPT];
+#pragma unroll
+    for (int u = 0; u < MERGE_IPT; u++) {
+        int k = tid + u * MERGE_THREADS;
+        col[u] = k < nn ? __builtin_nontemporal_load(ci + j0 + k) : 0;
+    }
+    double a[MERGE_IPT];
+#pragma unroll
+    for (int u = 0; u < MERGE_IPT; u++) {
+        int k = tid + u * MERGE_THREADS;
+        a[u] = k < nn ? ValLoad<VT>::at(vs, j0 + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < MERGE_IPT; u++) {
+        int k = tid + u * MERGE_THREADS;
+        if (k < nn) s_prod[k] = x[col[u]] * a[u];
+    }
+    // phase 1b: tile-relative row ends; the tail segment (row i1, not completed here) ends at nn
+    for (int r = tid; r < nr; r += MERGE_THREADS) s_rend[r] = (int32_t)((int64_t)rp[i0 + r + 1] - j0);
+    if (tid == 0) s_rend[nr] = nn;
+    __syncthreads();
+
+    // phase 2a: one lane per row, in storage order
+    for (int r = tid; r <= nr; r += MERGE_THREADS) {
+        int s = r ? s_rend[r - 1] : 0;
+        int e = s_rend[r];
+        if (e - s >= MERGE_LONG) {
+            int q = atomicAdd(&s_nlong, 1);
+            s_long[q] = r;
+            continue;
+        }
+        double acc = 0.0;
+        for (int k = s; k < e; k++) acc += s_prod[k];
+        if (r < nr) {
+            y[i0 + r] = acc;
+        } else {
+            carry_row[t] = i1 < nrows ? i1 : -1;
+            carry_val[t] = acc;
+        }
+    }
+    __syncthreads();
+
+    // phase 2b: long rows, one wavefront each
+    const int nlong = s_nlong;
+    const int lane = tid & (WAVE - 1);
+    for (int q = tid / WAVE; q < nlong; q += MERGE_THREADS / WAVE) {
+        int r = s_long[q];
+        int s = r ? s_rend[r - 1] : 0;
+        int e = s_rend[r];
+        double acc = 0.0;
+        for (int k = s + lane; k < e; k += WAVE) acc += s_prod[k];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (r < nr) {
+                y[i0 + r] = acc;
+            } else {
+                carry_row[t] = i1 < nrows ? i1 : -1;
+                carry_val[t] = acc;
+            }
+        }
+    }
+}
+
+// One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
+// in tile order, onto the y entry written by the tile that completed the row.
+__global__ __launch_bounds__(256) void spmv_merge_fixup_kernel(const int32_t *__restrict__ carry_row,
+                                                              const double *__restrict__ carry_val,
+                                                              int64_t n_tiles, double *__restrict__ y)
+{
+    int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    int lane = threadIdx.x & (WAVE - 1);
+    if (t >= n_tiles) return;
+    int32_t row = carry_row[t];
+    if (row < 0) return;
+    if (t > 0 && carry_row[t - 1] == row) return;
+    double acc = 0.0;
+    for (int64_t u0 = t; u0 < n_tiles; u0 += WAVE) {
+        int64_t u = u0 + lane;
+        bool ok = u < n_tiles && carry_row[u] == row;
+        if (ok) acc += carry_val[u];
+        if (__ballot(ok) != ~0ull) break;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc + y[row];
+}
+
+// ---- vector: one wavefront per row segment ------------------------------------------------
+constexpr int VEC_SEG = 4096;
+
+template <class P>
+__global__ void vec_count_kernel(const P *__restrict__ rp, int32_t nrows, int64_t *__restrict__ cnt)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    int64_t len = (int64_t)rp[r + 1] - (int64_t)rp[r];
+    cnt[r] = len <= VEC_SEG ? 1 : (len + VEC_SEG - 1) / VEC_SEG;
+}
+
+__global__ void vec_fill_kernel(const int64_t *__restrict__ seg_off, int32_t nrows, int32_t *__restrict__ seg_row)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    for (int64_t q = seg_off[r]; q < seg_off[r + 1]; q++) seg_row[q] = (int32_t)r;
+}
+
+template <class P, int VT>
+__global__ __launch_bounds__(256) void spmv_vector_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                         const void *__restrict__ vs, const double *__restrict__ x,
+                                                         double *__restrict__ y, const int64_t *__restrict__ seg_off,
+                                                         const int32_t *__restrict__ seg_row, int64_t n_segs,
+                                                         double *__restrict__ seg_part)
+{
+    int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    int lane = threadIdx.x & (WAVE - 1);
+    if (q >= n_segs) return;
+    int32_t r = seg_row[q];
+    int64_t first = seg_off[r], nseg = seg_off[r + 1] - first;
+    int64_t s = (int64_t)rp[r] + (q - first) * VEC_SEG;
+    int64_t e = (int64_t)rp[r + 1];
+    if (e > s + VEC_SEG && nseg > 1) e = s + VEC_SEG;
+    double acc = 0.0;
+    for (int64_t k = s + lane; k < e; k += WAVE) acc += x[ci[k]] * ValLoad<VT>::at(vs, k);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (nseg == 1)
+            y[r] = acc;
+        else
+            seg_part[q] = acc;
+    }
+}
+
+__global__ void spmv_vector_fixup_kernel(const int64_t *__restrict__ seg_off, int32_t nrows,
+                                         const double *__restrict__ seg_part, double *__restrict__ y)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    int64_t a = seg_off[r], b = seg_off[r + 1];
+    if (b - a <= 1) return;
+    double acc = 0.0;
+    for (int64_t q = a; q < b; q++) acc += seg_part[q];
+    y[r] = acc;
+}
+
+// ---- scalar: one lane per row ----------------------------------------------------------------
+template <class P, int VT>
+__global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                         const void *__restrict__ vs, const double *__restrict__ x,
+                                                         double *__restrict__ y, int32_t nrows)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    int64_t s = rp[r], e = rp[r + 1];
+    double acc = 0.0;
+    for (int64_t k = s; k < e; k++) acc += x[ci[k]] * ValLoad<VT>::at(vs, k);
+    y[r] = acc;
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+template <class P>
+static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    const P *rp = (const P *)m->d_rowptrs;
+    if (p->algo == CSRK_SPMV_MERGE) {
+        p->tile_items = MERGE_ITEMS;
+        int64_t total = (int64_t)m->nrows + m->nnz;
+        p->n_tiles = ceil_div(total, MERGE_ITEMS);
+        CSRK_TRY(p->tile_row.alloc((size_t)(p->n_tiles + 1) * 4));
+        CSRK_TRY(p->carry_row.alloc((size_t)p->n_tiles * 4));
+        CSRK_TRY(p->carry_val.alloc((size_t)p->n_tiles * 8));
+        int64_t nthr = p->n_tiles + 1;
+        merge_plan_kernel<P><<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(rp, m->nrows, m->nnz, MERGE_ITEMS,
+                                                                          p->n_tiles, p->tile_row.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+    } else if (p->algo == CSRK_SPMV_VECTOR) {
+        CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
+        if (m->nrows > 0) {
+            vec_count_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->nrows, p->seg_off.as<int64_t>());
+            CSRK_LAUNCH_CHECK();
+        }
+        CSRK_TRY(exclusive_scan_i64(p->seg_off.as<int64_t>(), p->seg_off.as<int64_t>(), m->nrows, s));
+        int64_t n_segs = 0;
+        CSRK_HIP(hipMemcpyAsync(&n_segs, p->seg_off.as<int64_t>() + m->nrows, 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        p->n_segs = n_segs;
+        CSRK_TRY(p->seg_row.alloc((size_t)n_segs * 4));
+        CSRK_TRY(p->seg_part.alloc((size_t)n_segs * 8));
+        if (m->nrows > 0) {
+            vec_fill_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(p->seg_off.as<int64_t>(), m->nrows,
+                                                                             p->seg_row.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+        }
+    }
+    return CSRK_OK;
+}
+
+static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!m->spmv_plan) {
+        SpmvPlan *p = new (std::nothrow) SpmvPlan();
+        CSRK_REQUIRE(p, "out of host memory");
+        p->algo = m->spmv_algo == CSRK_SPMV_AUTO ? CSRK_SPMV_MERGE : m->spmv_algo;
+        int rc = m->ptr64 ? build_plan<int64_t>(m, p, s) : build_plan<int32_t>(m, p, s);
+        if (rc != CSRK_OK) {
+            delete p;
+            return rc;
+        }
+        m->spmv_plan = p;
+    }
+    *out = m->spmv_plan;
+    return CSRK_OK;
+}
+
+template <class P, int VT>
+static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, hipStream_t s)
+{
+    const P *rp = (const P *)m->d_rowptrs;
+    if (m->nrows == 0) return CSRK_OK;
+    switch (p->algo) {
+    case CSRK_SPMV_MERGE: {
+        spmv_merge_kernel<P, VT><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
+            rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
+            p->carry_row.as<int32_t>(), p->carry_val.as<double>());
+        CSRK_LAUNCH_CHECK();
+        spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
+            p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
+        CSRK_LAUNCH_CHECK();
+        break;
+    }
+    case CSRK_SPMV_VECTOR: {
+        if (p->n_segs > 0) {
+            spmv_vector_kernel<P, VT><<<(unsigned)ceil_div(p->n_segs * WAVE, 256), 256, 0, s>>>(
+                rp, m->d_colinds, m->d_values, d_x, d_y, p->seg_off.as<int64_t>(), p->seg_row.as<int32_t>(),
+                p->n_segs, p->seg_part.as<double>());
+            CSRK_LAUNCH_CHECK();
+            spmv_vector_fixup_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(
+                p->seg_off.as<int64_t>(), m->nrows, p->seg_part.as<double>(), d_y);
+            CSRK_LAUNCH_CHECK();
+        }
+        break;
+    }
+    case CSRK_SPMV_SCALAR: {
+        spmv_scalar_kernel<P, VT><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->d_colinds, m->d_values, d_x,
+                                                                                  d_y, m->nrows);
+        CSRK_LAUNCH_CHECK();
+        break;
+    }
+    default:
+        set_error("unknown spmv algo %d", p->algo);
+        return CSRK_ERR_INVALID;
+    }
+    return CSRK_OK;
+}
+
+static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s)
+{
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, s, &p));
+#define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s)
+    if (m->ptr64) {
+        if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
+        if (m->val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
+        GO(int64_t, CSRK_VAL_NONE);
+    } else {
+        if (m->val_type == CSRK_VAL_F64) GO(int32_t, CSRK_VAL_F64);
+        if (m->val_type == CSRK_VAL_F32) GO(int32_t, CSRK_VAL_F32);
+        GO(int32_t, CSRK_VAL_NONE);
+    }
+#undef GO
+    return CSRK_ERR_INVALID;   // not reached
+}
+
+}  // namespace csrk
+
+using namespace csrk;
+
+extern "C" {
+
+int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stream)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE((d_x || m->ncols == 0) && (d_y || m->nrows == 0), "x or y is NULL");
+    return spmv_dispatch(m, d_x, d_y, (hipStream_t)stream);
+}
+
+int csrk_spmv(csrk_handle_t h, const double *x, double *y)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE((x || m->ncols == 0) && (y || m->nrows == 0), "x or y is NULL");
+    if (m->nrows == 0) return CSRK_OK;
+    double *dx, *dy;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        CSRK_TRY(m->scratch_x.ensure((size_t)m->ncols * 8));
+        CSRK_TRY(m->scratch_y.ensure((size_t)m->nrows * 8));
+        dx = m->scratch_x.as<double>();
+        dy = m->scratch_y.as<double>();
+    }
+    // The scratch vectors belong to the handle: concurrent csrk_spmv calls on ONE handle
+    // are serialised by the caller contract (the reference creates a handle per call,
+    // csr/csr.py:582); distinct handles run concurrently.
+    if (m->ncols) CSRK_HIP(hipMemcpy(dx, x, (size_t)m->ncols * 8, hipMemcpyHostToDevice));
+    CSRK_TRY(spmv_dispatch(m, dx, dy, nullptr));
+    CSRK_HIP(hipMemcpy(y, dy, (size_t)m->nrows * 8, hipMemcpyDeviceToHost));
+    return CSRK_OK;
+}
+
+int csrk_set_spmv_algo(csrk_handle_t h, int algo)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(algo >= CSRK_SPMV_AUTO && algo <= CSRK_SPMV_SCALAR, "unknown spmv algo %d", algo);
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (m->spmv_plan) {
+        CSRK_HIP(hipDeviceSynchronize());
+        free_spmv_plan(m->spmv_plan);
+        m->spmv_plan = nullptr;
+    }
+    m->spmv_algo = algo;
+    return CSRK_OK;
+}
+
+const char *csrk_spmv_algo_name(csrk_handle_t h)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return "invalid";
+    int a = m->spmv_plan ? m->spmv_plan->algo : m->spmv_algo;
+    switch (a) {
+    case CSRK_SPMV_MERGE: return "merge";
+    case CSRK_SPMV_VECTOR: return "vector";
+    case CSRK_SPMV_SCALAR: return "scalar";
+    default: return "auto";
+    }
+}
+
+int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));
+    if (n_tiles) *n_tiles = p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs;
+    if (tile_items) *tile_items = p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG;
+    return CSRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// Transpose for libcsrk on gfx950, bit-exact with the reference's stable counting sort
+// (csr/structure.py:172-204 _transpose_values, :207-237 _transpose_structure, :240-247).
+//
+// The reference scatters entries in row-major order through one cursor per column, so
+// inside every output row the entries appear in ascending SOURCE POSITION.  A GPU
+// atomic-cursor scatter would lose that order; instead the entries are sorted by column
+// with a STABLE least-significant-digit radix sort (8-bit digits, ceil(bits(ncols)/8)
+// passes), which yields exactly the reference's arrangement, including for duplicate
+// (row, col) entries and unsorted input rows.
+//
+// One pass = per-chunk digit histogram -> exclusive scan of the (digit, chunk) table ->
+// stable scatter.  A chunk is 4096 consecutive records handled by one 256-thread
+// workgroup in 16 in-order rounds; within a round the rank among equal digits comes from
+// a ballot-based match (8 ballots), across wavefronts/rounds from LDS counters, so no
+// ordering depends on atomics.  The first pass reads the CSR arrays directly (source row
+// ids are recovered from rowptrs inside the kernel, values are widened to float64 as
+// structure.py:177 requires); the last pass writes straight into the output matrix.
+//
+// HBM bytes per nnz, two passes with values: 4 (hist) + 12 (read) + 16 (write)
+//   + 4 (hist) + 16 (read) + 12 (write) = 64; structure only: 32.
+// Output rowptrs = exclusive scan of the column histogram (structure.py:180-188).
+#include "common.h"
+
+namespace csrk {
+
+constexpr int RX_THREADS = 256;
+constexpr int RX_ROUNDS = 16;
+constexpr int RX_CHUNK = RX_THREADS * RX_ROUNDS;
+constexpr int RX_WAVES = RX_THREADS / WAVE;
+
+// ---- column histogram -> output row pointers --------------------------------------------
+template <class C>
+__global__ void col_hist_kernel(const int32_t *__restrict__ ci, int64_t nnz, C *__restrict__ counts)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nnz; i += stride) atomicAdd((C *)&counts[ci[i]], (C)1);
+}
+
+// ---- radix pass: histogram ----------------------------------------------------------------
+__global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const int32_t *__restrict__ keys, int64_t n, int shift,
+                                                            int64_t n_chunks, int64_t *__restrict__ table)
+{
+    __shared__ int32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
+#pragma unroll
+    for (int r = 0; r < RX_ROUNDS; r++) {
+        int64_t i = base + r * RX_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = h[threadIdx.x];
+}
+
+// source row of entry i, searched inside [lo, hi] (rows whose extents meet this chunk)
+template <class P>
+__device__ __forceinline__ int32_t row_of(const P *__restrict__ rp, int64_t i, int32_t lo, int32_t hi)
+{
+    // largest r with rp[r] <= i
+    while (lo < hi) {
+        int32_t mid = lo + (hi - lo + 1) / 2;
+        if ((int64_t)rp[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+// ---- radix pass: stable scatter --------------------------------------------------------------
+// FIRST: records come from the CSR arrays (keys = colinds, row ids from rowptrs, values from
+//        the matrix, any dtype).  LAST: keys are not written.  VT = value type of the INPUT of
+//        this pass (CSRK_VAL_NONE = structure only).
+template <class P, int VT, bool FIRST, bool LAST>
+__global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
+    const int32_t *__restrict__ keys_in, const int32_t *__restrict__ rows_in, const void *__restrict__ vals_in,
+    const P *__restrict__ rp, int32_t nrows, int64_t n, int shift, int64_t n_chunks,
+    const int64_t *__restrict__ table, int32_t *__restrict__ keys_out, int32_t *__restrict__ rows_out,
+    double *__restrict__ vals_out)
+{
+    __shared__ int64_t s_goff[256];               // global offset of this chunk's run per digit
+    __shared__ int32_t s_run[256];                // records of each digit already placed
+    __shared__ int32_t s_wcnt[RX_WAVES][256];     // per-wave digit counts of the current round
+    __shared__ int32_t s_rlo, s_rhi;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
+    s_goff[tid] = table[(int64_t)tid * n_chunks + blockIdx.x];
+    s_run[tid] = 0;
+#pragma unroll
+    for (int k = 0; k < RX_WAVES; k++) s_wcnt[k][tid] = 0;
+    if (FIRST && tid == 0) {
+        int64_t last = base + RX_CHUNK - 1 < n - 1 ? base + RX_CHUNK - 1 : n - 1;
+        s_rlo = row_of(rp, base, 0, nrows - 1);
+        s_rhi = row_of(rp, last, s_rlo, nrows - 1);
+    }
+    __syncthreads();
+
+    for (int r = 0; r < RX_ROUNDS; r++) {
+        const int64_t i = base + r * RX_THREADS + tid;
+        const bool valid = i < n;
+        int32_t key = 0, row = 0;
+        double val = 0.0;
+        if (valid) {
+            key = keys_in[i];
+            if (FIRST) {
+                row = row_of(rp, i, s_rlo, s_rhi);
+                if (VT == CSRK_VAL_F64) val = ((const double *)vals_in)[i];
+                if (VT == CSRK_VAL_F32) val = (double)((const float *)vals_in)[i];
+            } else {
+                row = rows_in[i];
+                if (VT != CSRK_VAL_NONE) val = ((const double *)vals_in)[i];
+            }
+        }
+        const int d = (key >> shift) & 255;
+        // lanes holding the same digit (ballot-based match)
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bm = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bm : ~bm;
+        }
+        const int below = __popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && below == 0) s_wcnt[w][d] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            int pre = s_run[d];
+#pragma unroll
+            for (int k = 0; k < RX_WAVES; k++)
+                if (k < w) pre += s_wcnt[k][d];
+            const int64_t o = s_goff[d] + pre + below;
+            if (!LAST) keys_out[o] = key;
+            rows_out[o] = row;
+            if (VT != CSRK_VAL_NONE) vals_out[o] = val;
+        }
+        __syncthreads();
+        {
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < RX_WAVES; k++) {
+                tot += s_wcnt[k][tid];
+                s_wcnt[k][tid] = 0;
+            }
+            s_run[tid] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+template <class P, int VT>
+static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
+{
+    const P *rp = (const P *)a->d_rowptrs;
+    const int64_t nnz = a->nnz;
+    const int32_t ncols = a->ncols;
+    constexpr bool HAS_V = VT != CSRK_VAL_NONE;
+
+    // output row pointers: histogram of columns, then exclusive scan (structure.py:180-188)
+    CSRK_HIP(hipMemsetAsync(t->d_rowptrs, 0, (size_t)(ncols + 1) * sizeof(P), s));
+    if (nnz > 0) {
+        int grid = (int)(ceil_div(nnz, 256) < 8192 ? ceil_div(nnz, 256) : 8192);
+        if (sizeof(P) == 8)
+            col_hist_kernel<unsigned long long><<<grid, 256, 0, s>>>(a->d_colinds, nnz, (unsigned long long *)t->d_rowptrs);
+        else
+            col_hist_kernel<int32_t><<<grid, 256, 0, s>>>(a->d_colinds, nnz, (int32_t *)t->d_rowptrs);
+        CSRK_LAUNCH_CHECK();
+    }
+    if (sizeof(P) == 8)
+        CSRK_TRY(exclusive_scan_i64((const int64_t *)t->d_rowptrs, (int64_t *)t->d_rowptrs, ncols, s));
+    else
+        CSRK_TRY(exclusive_scan_i32((const int32_t *)t->d_rowptrs, (int32_t *)t->d_rowptrs, ncols, s));
+    if (nnz == 0) return CSRK_OK;
+
+    int bits = 0;
+    while (bits < 31 && (1ll << bits) < (int64_t)ncols) bits++;
+    int passes = bits <= 8 ? 1 : (bits + 7) / 8;
+    const int64_t n_chunks = ceil_div(nnz, RX_CHUNK);
+
+    DevBuf table, keyA, keyB, rowA, rowB, valA, valB;
+    CSRK_TRY(table.alloc((size_t)(256 * n_chunks + 1) * 8));
+    if (passes > 1) {
+        CSRK_TRY(keyA.alloc((size_t)nnz * 4));
+        CSRK_TRY(rowA.alloc((size_t)nnz * 4));
+        if (HAS_V) CSRK_TRY(valA.alloc((size_t)nnz * 8));
+    }
+    if (passes > 2) {
+        CSRK_TRY(keyB.alloc((size_t)nnz * 4));
+        CSRK_TRY(rowB.alloc((size_t)nnz * 4));
+        if (HAS_V) CSRK_TRY(valB.alloc((size_t)nnz * 8));
+    }
+
+    const int32_t *k_in = a->d_colinds;
+    const int32_t *r_in = nullptr;
+    const void *v_in = a->d_values;
+    for (int p = 0; p < passes; p++) {
+        const bool first = p == 0, last = p == passes - 1;
+        const int shift = 8 * p;
+        int32_t *k_out = last ? nullptr : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
+        int32_t *r_out = last ? t->d_colinds : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
+        double *v_out = !HAS_V ? nullptr : (last ? (double *)t->d_values : ((p & 1) ? valB.as<double>() : valA.as<double>()));
+        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, nnz, shift, n_chunks, table.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_TRY(exclusive_scan_i64(table.as<int64_t>(), table.as<int64_t>(), 256 * n_chunks, s));
+        const unsigned grid = (unsigned)n_chunks;
+        constexpr int VMID = HAS_V ? CSRK_VAL_F64 : CSRK_VAL_NONE;   // intermediates are float64
+#define RX_ARGS k_in, r_in, v_in, rp, a->nrows, nnz, shift, n_chunks, table.as<int64_t>(), k_out, r_out, v_out
+        if (first && last)
+            rx_scatter_kernel<P, VT, true, true><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+        else if (first)
+            rx_scatter_kernel<P, VT, true, false><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+        else if (last)
+            rx_scatter_kernel<P, VMID, false, true><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+        else
+            rx_scatter_kernel<P, VMID, false, false><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+#undef RX_ARGS
+        CSRK_LAUNCH_CHECK();
+        k_in = k_out;
+        r_in = r_out;
+        v_in = v_out;
+    }
+    CSRK_HIP(hipStreamSynchronize(s));   // temporaries are released on return
+    return CSRK_OK;
+}
+
+// Transpose `a` into a new matrix.  Exposed to the other translation units (spgemm_abt,
+// order_columns).
+int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s)
+{
+    int vt = (with_values && a->val_type != CSRK_VAL_NONE) ? CSRK_VAL_F64 : CSRK_VAL_NONE;
+    Matrix *t = nullptr;
+    CSRK_TRY(new_matrix(a->ncols, a->nrows, a->nnz, a->ptr64, vt, &t));
+    int rc;
+    int in_vt = vt == CSRK_VAL_NONE ? CSRK_VAL_NONE : a->val_type;
+    if (a->ptr64) {
+        if (in_vt == CSRK_VAL_F64) rc = transpose_impl<int64_t, CSRK_VAL_F64>(a, t, s);
+        else if (in_vt == CSRK_VAL_F32) rc = transpose_impl<int64_t, CSRK_VAL_F32>(a, t, s);
+        else rc = transpose_impl<int64_t, CSRK_VAL_NONE>(a, t, s);
+    } else {
+        if (in_vt == CSRK_VAL_F64) rc = transpose_impl<int32_t, CSRK_VAL_F64>(a, t, s);
+        else if (in_vt == CSRK_VAL_F32) rc = transpose_impl<int32_t, CSRK_VAL_F32>(a, t, s);
+        else rc = transpose_impl<int32_t, CSRK_VAL_NONE>(a, t, s);
+    }
+    if (rc != CSRK_OK) {
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return CSRK_OK;
+}
+
+}  // namespace csrk
+
+using namespace csrk;
+
+extern "C" int csrk_transpose(csrk_handle_t h, int with_values, csrk_handle_t *out)
+{
+    CSRK_REQUIRE(out, "out is NULL");
+    *out = 0;
+    Matrix *a = from_handle(h);
+    if (!a) return CSRK_ERR_INVALID;
+    Matrix *t = nullptr;
+    CSRK_TRY(transpose_matrix(a, with_values, &t, nullptr));
+    *out = to_handle(t);
+    return CSRK_OK;
+}

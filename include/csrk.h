@@ -1,0 +1,167 @@
+/*
+ * csrk.h -- C ABI of libcsrk, the MI355X (gfx950) kernel backend for the lenskit/csr
+ * `csr.kernels` hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque integer handles, raw pointers and
+ * sizes, `int` status returns (0 = CSRK_OK; on failure csrk_last_error() describes the
+ * error and nothing aborts the process).  Its shape follows the reference's one native
+ * interface, the MKL helper (csr/kernels/mkl/mkl_ops.h:1-31: lk_mkl_spcreate / spfree /
+ * spexport / sporder / spmv / spmab / spmabt), extended by the operations the reference
+ * runs outside its kernel protocol but which belong to the same hot path
+ * (transpose, row extents, row normalisation).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference checkout).  The Python kernel module csr_amd/kernels/hip.py binds these
+ * with ctypes and implements the reference's kernel-module protocol
+ * (csr/kernel.py:9-16, docs/kernels.rst:61-104) on top of them; INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Memory model.  A handle owns a device-resident (HBM) copy of one CSR matrix:
+ *   rowptrs[nrows+1]  int32, or int64 when ptr_is_64  (csr/csr.py:88-93)
+ *   colinds[nnz]      int32                           (csr/csr.py:89)
+ *   values[nnz]       float64 / float32 / absent      (csr/csr.py:94-95)
+ * "host" entry points take host pointers and copy across PCIe; "_device" entry points
+ * take device pointers (e.g. torch tensors' data_ptr()) and a hipStream_t passed as
+ * void* (NULL = the default stream) and never synchronise the host.
+ *
+ * Threading: handles are immutable after creation except for the in-place operations
+ * that say so; all entry points may be called concurrently from several host threads
+ * (calls on the SAME handle serialise on a per-handle lock).  ctypes releases the GIL
+ * around every call, matching the reference's `nogil=True` kernels.
+ */
+#ifndef CSRK_H
+#define CSRK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSRK_API __attribute__((visibility("default")))
+
+typedef intptr_t csrk_handle_t;      /* 0 is never a valid handle (cf. lk_mh_t, mkl_ops.h:1) */
+
+enum {
+    CSRK_OK = 0,
+    CSRK_ERR_INVALID = -1,           /* bad argument / shape mismatch */
+    CSRK_ERR_HIP = -2,               /* a HIP runtime call failed (no device, OOM, ...) */
+    CSRK_ERR_UNSUPPORTED = -3,
+    CSRK_ERR_OVERFLOW = -4           /* result does not fit the reference's int32 fields */
+};
+
+enum { CSRK_VAL_NONE = 0, CSRK_VAL_F32 = 1, CSRK_VAL_F64 = 2 };
+
+/* SpMV algorithm selector (csrk_set_spmv_algo).  AUTO picks per matrix. */
+enum {
+    CSRK_SPMV_AUTO = 0,
+    CSRK_SPMV_MERGE = 1,             /* merge-path tiles, LDS-staged products            */
+    CSRK_SPMV_VECTOR = 2,            /* one wavefront per row segment, shfl reduction    */
+    CSRK_SPMV_SCALAR = 3             /* one lane per row                                 */
+};
+
+/* ---- library / device ------------------------------------------------------------ */
+CSRK_API int csrk_version(void);
+/* Thread-local description of the calling thread's most recent failure. */
+CSRK_API const char *csrk_last_error(void);
+CSRK_API int csrk_device_count(int *count);
+/* Select the HIP device used by subsequent calls from this thread (one process per
+ * GPU normally passes LOCAL_RANK). */
+CSRK_API int csrk_set_device(int device);
+CSRK_API int csrk_synchronize(void *stream);
+
+/* ---- handles: replaces to_handle / from_handle / release_handle ---------------------
+ * csr/kernels/numba/__init__.py:16-44; csr/kernels/mkl/handle.py:61-70, 95-148;
+ * lk_mkl_spcreate / lk_mkl_spexport / lk_mkl_spfree (mkl_ops.h:11-14).               */
+
+/* Copy a host CSR to the device.  `values` may be NULL iff val_type == CSRK_VAL_NONE.
+ * nnz must equal rowptrs[nrows]; nnz == 0 and nrows == 0 are valid (the reference's
+ * kernel fixture creates a 1x1 empty matrix, conftest.py:33-35). */
+CSRK_API int csrk_create(int32_t nrows, int32_t ncols, int64_t nnz,
+                         const void *rowptrs, int ptr_is_64,
+                         const int32_t *colinds,
+                         const void *values, int val_type,
+                         csrk_handle_t *out);
+/* Wrap arrays that already live in HBM.  Nothing is copied or owned: the caller keeps
+ * them alive for the handle's lifetime (same contract as to_handle, docs/kernels.rst). */
+CSRK_API int csrk_create_device(int32_t nrows, int32_t ncols, int64_t nnz,
+                                const void *d_rowptrs, int ptr_is_64,
+                                const int32_t *d_colinds,
+                                const void *d_values, int val_type,
+                                csrk_handle_t *out);
+/* Idempotent on 0. */
+CSRK_API int csrk_free(csrk_handle_t h);
+CSRK_API int csrk_info(csrk_handle_t h, int32_t *nrows, int32_t *ncols, int64_t *nnz,
+                       int *ptr_is_64, int *val_type);
+/* Copy the matrix back to caller-allocated host arrays sized from csrk_info
+ * (any of the three may be NULL to skip it). */
+CSRK_API int csrk_export(csrk_handle_t h, void *rowptrs, int32_t *colinds, void *values);
+/* Device pointers of the handle's arrays (for zero-copy torch interop). */
+CSRK_API int csrk_device_ptrs(csrk_handle_t h, void **d_rowptrs, void **d_colinds,
+                              void **d_values);
+
+/* ---- mult_vec: y = A x ---------------------------------------------------------------
+ * csr/kernels/numba/__init__.py:55-67; lk_mkl_spmv (mkl_ops.h:29).  x has ncols float64
+ * entries, y receives nrows float64 entries (every entry is written; empty rows get 0).
+ * Structure-only matrices multiply with implicit 1.0 (csr/csr.py:254-262).            */
+CSRK_API int csrk_spmv(csrk_handle_t h, const double *x, double *y);
+CSRK_API int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stream);
+CSRK_API int csrk_set_spmv_algo(csrk_handle_t h, int algo);
+/* Name of the kernel the handle's plan resolved to, e.g. "merge" (after first use). */
+CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);
+/* Launch geometry of the dominant SpMV kernel (for roofline accounting in bench.py). */
+CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items);
+
+/* ---- mult_ab / mult_abt: sparse x sparse -> sparse ------------------------------------
+ * csr/kernels/numba/multiply.py:13-57; lk_mkl_spmab / lk_mkl_spmabt (mkl_ops.h:30-31).
+ * The product is a NEW handle owned by the caller (rowptrs int32 as in multiply.py:28,
+ * values float64).  Structural zeros produced by cancellation are KEPT (the caller
+ * filters them, csr/csr.py:555).  Columns inside a product row are ascending (the
+ * reference's order is an artefact of its linked list and pinned by no test).
+ * Both operands need values (multiply.py:115,120).  CSRK_ERR_OVERFLOW if the product
+ * has more than INT32_MAX entries.                                                     */
+CSRK_API int csrk_spgemm_ab(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
+CSRK_API int csrk_spgemm_abt(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
+
+/* ---- dense-panel SpMM: C = A B, B dense row-major [ncols x k] --------------------------
+ * Not a reference entry point (the reference's mult_ab is sparse x sparse only); serves
+ * BASELINE.json configs[2].  Equals mult_ab(A, CSR(B)) densified.  ldb/ldc in elements. */
+CSRK_API int csrk_spmm_dense(csrk_handle_t a, const double *B, int32_t k, int64_t ldb,
+                             double *C, int64_t ldc);
+CSRK_API int csrk_spmm_dense_device(csrk_handle_t a, const double *d_B, int32_t k, int64_t ldb,
+                                    double *d_C, int64_t ldc, void *stream);
+
+/* ---- transpose ------------------------------------------------------------------------
+ * csr/structure.py:172-247 (_transpose_values / _transpose_structure / transpose).
+ * Bit-exact with the reference's stable counting sort: output rowptrs keep the input
+ * pointer width, output colinds are the source row ids in ascending source position,
+ * output values are float64 whatever the input dtype (:177).  with_values == 0, or a
+ * structure-only input, gives a structure-only result (:241-242).                      */
+CSRK_API int csrk_transpose(csrk_handle_t h, int with_values, csrk_handle_t *out);
+
+/* ---- row extents / counts ---------------------------------------------------------------
+ * csr/_rows.py:9-13 (extent), csr/csr.py:432-441 (row_nnzs = diff(rowptrs)).
+ * `out` has nrows entries of the handle's pointer width (int32 or int64).              */
+CSRK_API int csrk_row_nnzs(csrk_handle_t h, void *out);
+CSRK_API int csrk_row_extent(csrk_handle_t h, int32_t row, int64_t *start, int64_t *end);
+
+/* ---- row normalisation (IN PLACE on the handle's values) --------------------------------
+ * csr/transform.py:29-66 (unit_rows) and :13-26 (center_rows).  `out` receives nrows
+ * norms / means in the VALUES' dtype (float32 or float64), host memory.  Requires values. */
+CSRK_API int csrk_unit_rows(csrk_handle_t h, void *norms);
+CSRK_API int csrk_center_rows(csrk_handle_t h, void *means);
+
+/* ---- order_columns (IN PLACE) -------------------------------------------------------------
+ * csr/kernels/numba/__init__.py:47-52 -> csr/structure.py:156-169; lk_mkl_sporder.
+ * Stable sort of every row by column index; values follow.                              */
+CSRK_API int csrk_order_columns(csrk_handle_t h);
+
+/* ---- _filter_zeros ----------------------------------------------------------------------
+ * csr/_struct.py:61-76.  Returns a NEW handle without the entries whose value is
+ * exactly 0.0 (NaN is kept).  Requires float64 values.                                  */
+CSRK_API int csrk_filter_zeros(csrk_handle_t h, csrk_handle_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSRK_H */

@@ -1,0 +1,376 @@
+"""
+GPU parity for transpose, row extents, row normalisation, SpGEMM, order_columns,
+filter_zeros and the dense-panel SpMM -- all through the C ABI (csr_amd -> libcsrk.so)
+against the CPU oracle and the golden vectors captured from the reference.
+
+Bars: transpose / row_extent / row_nnzs / order_columns / filter_zeros are index work and
+must be BIT-EXACT (values are copied bits).  SpGEMM and SpMM are fp64: |c - c_ref| <=
+1e-6 * sum |a||b| (north_star's 1e-6 relative, stated against the magnitude of the summed
+terms so it is meaningful under cancellation).  unit/center: rel 1e-6 for f8 (the reference
+tests' own tolerance, tests/test_transform.py:128-149), 1e-5 for f4.
+"""
+import numpy as np
+import pytest
+
+from conftest import Mat, sort_within_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(m):
+    from csr_amd import CSR
+    return CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False)
+
+
+def _rand(rng, nrows, ncols, lens, dtype=np.float64, ptr64=False, values=True, sort=False):
+    from csr_amd import CSR
+    rp = np.zeros(nrows + 1, dtype=np.int64 if ptr64 else np.int32)
+    rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, ncols, size=nnz).astype(np.int32)
+    vs = rng.uniform(-1, 1, size=nnz).astype(dtype) if values else None
+    m = CSR(nrows, ncols, nnz, rp, ci, vs, _cast=False)
+    if sort:
+        ci2, vs2 = sort_within_rows(rp, ci, vs)
+        m = CSR(nrows, ncols, nnz, rp, ci2, vs2, _cast=False)
+    return m
+
+
+# ---- transpose ------------------------------------------------------------------------------
+
+def test_transpose_kat(golden):
+    "tests/test_transpose.py:11-46 of the reference"
+    g = golden('kat')
+    a = _csr(Mat(g, 'a_'))
+    t = a.transpose()
+    assert (t.nrows, t.ncols, t.nnz) == (3, 4, 4)
+    assert list(t.rowptrs) == [0, 1, 3, 4]
+    at = Mat(g, 'at_')
+    assert np.array_equal(t.colinds, at.colinds) and np.array_equal(t.values, at.values)
+    ts = a.transpose(False)
+    assert ts.values is None and list(ts.rowptrs) == [0, 1, 3, 4]
+    assert np.array_equal(ts.colinds, Mat(g, 'ats_').colinds)
+
+
+def test_transpose_golden(golden):
+    "bit-exact against the reference, incl. duplicate entries / unsorted rows / f4 / structure-only"
+    g = golden('transpose')
+    for c in range(int(g['n'])):
+        m = Mat(g, f'c{c}_')
+        t = _csr(m).transpose()
+        ref = Mat(g, f'c{c}_t_')
+        assert (t.nrows, t.ncols, t.nnz) == (ref.nrows, ref.ncols, ref.nnz)
+        assert t.rowptrs.dtype == m.rowptrs.dtype            # structure.py:175
+        assert np.array_equal(t.rowptrs, ref.rowptrs), c
+        assert np.array_equal(t.colinds, ref.colinds), c
+        if ref.values is None:
+            assert t.values is None
+        else:
+            assert t.values.dtype == np.float64                # structure.py:177
+            assert np.array_equal(t.values, ref.values), c
+        ts = _csr(m).transpose(False)
+        rs = Mat(g, f'c{c}_ts_')
+        assert ts.values is None
+        assert np.array_equal(ts.rowptrs, rs.rowptrs) and np.array_equal(ts.colinds, rs.colinds)
+
+
+@pytest.mark.parametrize('case', ['wide3pass', 'narrow1pass', 'ptr64_f32', 'skewed', 'empty'])
+def test_transpose_vs_oracle(case):
+    from oracle import oracle as O
+    rng = np.random.default_rng(abs(hash(case)) % 2**32)
+    if case == 'wide3pass':          # ncols > 65536: three radix passes
+        m = _rand(rng, 3000, 200000, rng.integers(0, 60, 3000))
+    elif case == 'narrow1pass':      # ncols <= 256: single pass; heavy duplicates
+        m = _rand(rng, 5000, 200, rng.integers(0, 30, 5000))
+    elif case == 'ptr64_f32':
+        m = _rand(rng, 4000, 5000, rng.integers(0, 50, 4000), dtype=np.float32, ptr64=True)
+    elif case == 'skewed':           # a few huge rows and a hot column
+        lens = np.minimum((rng.pareto(0.8, 20000) * 2).astype(np.int64), 50000)
+        m = _rand(rng, 20000, 30000, lens)
+        m.colinds[::7] = 17
+    else:
+        m = _rand(rng, 100, 50, np.zeros(100, dtype=np.int64))
+    t = m.transpose()
+    nr, nc, brp, bci, bvs = O.transpose(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values)
+    assert (t.nrows, t.ncols) == (nr, nc)
+    assert t.rowptrs.dtype == m.rowptrs.dtype
+    assert np.array_equal(t.rowptrs, brp)
+    assert np.array_equal(t.colinds, bci)
+    assert t.values.dtype == np.float64 and np.array_equal(t.values, bvs)
+    # involution property (size independent): transposing twice sorts rows stably
+    tt = t.transpose()
+    ci2, vs2 = sort_within_rows(m.rowptrs, m.colinds, m.values)
+    assert np.array_equal(tt.rowptrs, m.rowptrs) and np.array_equal(tt.colinds, ci2)
+    assert np.array_equal(tt.values, vs2.astype(np.float64))
+
+
+# ---- row extents -------------------------------------------------------------------------------
+
+def test_row_extent_and_nnzs(golden):
+    "tests/test_attributes.py:36-54 of the reference"
+    from csr_amd.kernels import hip as K
+    g = golden('kat')
+    a = _csr(Mat(g, 'a_'))
+    h = K.to_handle(a)
+    try:
+        assert [K.row_extent(h, i) for i in range(4)] == [(0, 2), (2, 3), (3, 3), (3, 4)]
+        assert np.array_equal(K.row_nnzs(h), g['a_row_nnzs'])
+        with pytest.raises(ValueError):
+            K.row_extent(h, 4)
+    finally:
+        K.release_handle(h)
+    g = golden('transpose')
+    for c in range(int(g['n'])):
+        m = Mat(g, f'c{c}_')
+        h = K.to_handle(_csr(m))
+        try:
+            out = K.row_nnzs(h)
+            assert out.dtype == m.rowptrs.dtype and np.array_equal(out, g[f'c{c}_row_nnzs'])
+        finally:
+            K.release_handle(h)
+
+
+# ---- handles -------------------------------------------------------------------------------------
+
+def test_handle_roundtrip(golden):
+    "tests/test_handles.py:10-21 and tests/test_mkl.py:51-63 of the reference"
+    from csr_amd.kernels import hip as K
+    g = golden('spmv')
+    for c in range(int(g['n'])):
+        m = Mat(g, f'c{c}_')
+        h = K.to_handle(_csr(m))
+        try:
+            c2 = K.from_handle(h)
+            assert (c2.nrows, c2.ncols, c2.nnz) == (m.nrows, m.ncols, m.nnz)
+            assert np.array_equal(c2.rowptrs, m.rowptrs) and np.array_equal(c2.colinds, m.colinds)
+            if m.values is None:
+                assert c2.values is None
+            else:
+                assert c2.values.dtype == m.values.dtype and np.array_equal(c2.values, m.values)
+        finally:
+            K.release_handle(h)
+    with pytest.raises(ValueError):
+        K.mult_vec(h, np.ones(m.ncols))       # released handle
+
+
+# ---- unit / center -----------------------------------------------------------------------------------
+
+def test_unit_center_golden(golden):
+    g = golden('rows')
+    for c in range(int(g['n'])):
+        m = Mat(g, f'c{c}_')
+        f4 = m.values.dtype == np.float32
+        rel = 1e-5 if f4 else 1e-6
+        a = _csr(m).copy()
+        with np.errstate(all='ignore'):
+            norms = a.normalize_rows('unit')
+        assert norms.dtype == m.values.dtype and a.values.dtype == m.values.dtype
+        assert norms == pytest.approx(g[f'c{c}_unit_norms'], rel=rel, abs=0, nan_ok=True), c
+        ref_v = g[f'c{c}_unit_values']
+        assert np.array_equal(np.isnan(a.values), np.isnan(ref_v)), c      # zero-norm rows -> NaN
+        assert a.values == pytest.approx(ref_v, rel=rel, abs=1e-300, nan_ok=True), c
+        b = _csr(m).copy()
+        means = b.normalize_rows('center')
+        scale = float(np.max(np.abs(m.values))) if m.nnz else 1.0
+        tol = scale * (1e-6 if f4 else 1e-12)
+        assert means.dtype == m.values.dtype
+        assert means == pytest.approx(g[f'c{c}_center_means'], rel=rel, abs=tol), c
+        assert b.values == pytest.approx(g[f'c{c}_center_values'], rel=rel, abs=tol), c
+
+
+def test_unit_rows_properties_large():
+    "tests/test_transform.py:128-149 of the reference, at a size with long and empty rows"
+    rng = np.random.default_rng(5)
+    lens = np.minimum((rng.pareto(0.9, 30000) * 3).astype(np.int64), 40000)
+    m = _rand(rng, 30000, 1000, lens)
+    m.values[:] *= rng.choice([1e-200, 1.0, 1e150], size=m.nnz)
+    orig = m.values.copy()
+    norms = m.normalize_rows('unit')
+    rows = np.repeat(np.arange(m.nrows), np.diff(m.rowptrs))
+    ss = np.zeros(m.nrows)
+    np.add.at(ss, rows, m.values ** 2)
+    nz = np.diff(m.rowptrs) > 0
+    assert np.all(norms[~nz] == 0)
+    assert ss[nz] == pytest.approx(1.0, rel=1e-9)
+    assert m.values * norms[rows] == pytest.approx(orig, rel=1e-9)
+
+
+# ---- SpGEMM ------------------------------------------------------------------------------------------
+
+def _dense(nr, nc, rp, ci, vs):
+    out = np.zeros((nr, nc))
+    rows = np.repeat(np.arange(nr), np.diff(rp))
+    np.add.at(out, (rows, ci), vs)
+    return out
+
+
+def test_spgemm_golden(golden):
+    "kernel-level mult_ab / mult_abt and CSR.multiply against the reference's outputs"
+    from csr_amd.kernels import hip as K
+    g = golden('spgemm')
+    for c in range(int(g['n'])):
+        A, B = Mat(g, f'c{c}_a_'), Mat(g, f'c{c}_b_')
+        raw = Mat(g, f'c{c}_raw_')
+        bound = 1e-6 * (np.abs(A.dense()) @ np.abs(B.dense())) + 1e-300
+        ah, bh = K.to_handle(_csr(A)), K.to_handle(_csr(B))
+        try:
+            ch = K.mult_ab(ah, bh)
+            C = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(ah)
+            K.release_handle(bh)
+        # structure: same rowptrs and the same column SET per row as the reference (explicit
+        # zeros kept); order inside a row is ascending here
+        assert C.rowptrs.dtype == np.int32 and np.array_equal(C.rowptrs, raw.rowptrs), c
+        rci, rvs = sort_within_rows(raw.rowptrs, raw.colinds, raw.values)
+        assert np.array_equal(C.colinds, rci), c
+        assert np.all(np.abs(C.values - rvs) <= bound[np.repeat(np.arange(C.nrows), np.diff(C.rowptrs)), C.colinds]), c
+        # CSR.multiply: filtered product (csr/csr.py:555), tests/test_multiply.py:14-44
+        P = _csr(A).multiply(_csr(B))
+        ab = Mat(g, f'c{c}_ab_')
+        assert (P.nrows, P.ncols) == (ab.nrows, ab.ncols)
+        if P.nnz:
+            assert np.all(P.values != 0)
+        assert np.all(np.abs(_dense(P.nrows, P.ncols, P.rowptrs, P.colinds, P.values) - ab.dense()) <= bound), c
+        # A B^T, tests/test_multiply.py:47-79
+        Bt = Mat(g, f'c{c}_bt_')
+        Pt = _csr(A).multiply(_csr(Bt), transpose=True)
+        abt = Mat(g, f'c{c}_abt_')
+        assert (Pt.nrows, Pt.ncols) == (abt.nrows, abt.ncols)
+        assert np.all(np.abs(_dense(Pt.nrows, Pt.ncols, Pt.rowptrs, Pt.colinds, Pt.values) - abt.dense()) <= bound), c
+
+
+@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'f32_ptr64'])
+def test_spgemm_vs_oracle(case):
+    "larger products: LDS-hash rows and dense-accumulator rows (product count > 1024) together"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(abs(hash(case)) % 2**32)
+    if case == 'sparse':
+        A = _rand(rng, 3000, 2000, rng.integers(0, 12, 3000), sort=True)
+        B = _rand(rng, 2000, 5000, rng.integers(0, 12, 2000), sort=True)
+    elif case == 'heavy_rows':
+        la = rng.integers(0, 8, 1500)
+        la[::50] = 400
+        A = _rand(rng, 1500, 1200, la)
+        lb = rng.integers(0, 30, 1200)
+        lb[::40] = 900
+        B = _rand(rng, 1200, 3000, lb)
+    else:
+        A = _rand(rng, 500, 400, rng.integers(0, 20, 500), dtype=np.float32, ptr64=True)
+        B = _rand(rng, 400, 300, rng.integers(0, 20, 400), dtype=np.float32)
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        ch = K.mult_ab(ah, bh)
+        C = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values),
+                                      (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values))
+    rci, rvs = sort_within_rows(crp, cci, cvs)
+    assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, rci)
+    _, _, _, _, babs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values)),
+                                 (B.nrows, B.ncols, B.rowptrs, B.colinds, np.abs(B.values)))
+    _, bsorted = sort_within_rows(crp, cci, babs)
+    assert np.all(np.abs(C.values - rvs) <= 1e-6 * bsorted + 1e-300)
+    assert np.all(np.abs(C.values - rvs) <= 1e-12 * bsorted + 1e-300)
+
+
+def test_multiply_sharded(golden):
+    "csr/csr.py:558-567: row sharding above max_nnz + _assemble_shards (tests/test_mkl.py:82-91)"
+    from csr_amd.kernels import hip as K
+    g = golden('spgemm')
+    save = K.max_nnz
+    hits = 0
+    try:
+        for c in range(int(g['n'])):
+            A, B = Mat(g, f'c{c}_a_'), Mat(g, f'c{c}_b_')
+            # B must fit (the reference test assumes B.nnz < max_nnz, tests/test_multiply.py:18)
+            lim = max(B.nnz, int(np.max(np.diff(A.rowptrs), initial=0)), 20)
+            if A.nnz <= 2 * lim:
+                continue
+            hits += 1
+            K.max_nnz = lim
+            P = _csr(A).multiply(_csr(B))
+            ab = Mat(g, f'c{c}_ab_')
+            bound = 1e-6 * (np.abs(A.dense()) @ np.abs(B.dense())) + 1e-300
+            assert (P.nrows, P.ncols) == (ab.nrows, ab.ncols)
+            assert np.all(np.abs(_dense(P.nrows, P.ncols, P.rowptrs, P.colinds, P.values) - ab.dense()) <= bound)
+    finally:
+        K.max_nnz = save
+    assert hits >= 2
+
+
+# ---- order_columns / filter_zeros ---------------------------------------------------------------------
+
+def test_order_columns_golden(golden):
+    "tests/test_transform.py:77-87 of the reference: bit-exact with sort_rows on unsorted rows"
+    from csr_amd.kernels import hip as K
+    g = golden('spgemm')
+    for c in range(int(g['n'])):
+        raw, srt = Mat(g, f'c{c}_raw_'), Mat(g, f'c{c}_rawsorted_')
+        h = K.to_handle(_csr(raw))
+        try:
+            K.order_columns(h)
+            c2 = K.from_handle(h)
+        finally:
+            K.release_handle(h)
+        assert np.array_equal(c2.rowptrs, srt.rowptrs)
+        assert np.array_equal(c2.colinds, srt.colinds) and np.array_equal(c2.values, srt.values)
+        assert all(np.all(np.diff(c2.colinds[c2.rowptrs[i]:c2.rowptrs[i + 1]]) > 0) for i in range(c2.nrows))
+    # f4 values and structure-only survive the round trip exactly
+    rng = np.random.default_rng(2)
+    for dt, vals in ((np.float32, True), (np.float64, False)):
+        m = _rand(rng, 300, 200, rng.integers(0, 40, 300), dtype=dt, values=vals)
+        ci, vs = sort_within_rows(m.rowptrs, m.colinds, m.values)
+        m.sort_rows()
+        assert np.array_equal(m.colinds, ci)
+        if vals:
+            assert m.values.dtype == dt and np.array_equal(m.values, vs)
+
+
+def test_filter_zeros(golden):
+    "csr/_struct.py:61-76 on the device: bit-exact"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(8)
+    m = _rand(rng, 2000, 500, rng.integers(0, 20, 2000))
+    m.values[rng.uniform(size=m.nnz) < 0.3] = 0.0
+    m.values[5] = np.nan
+    m.values[7] = -0.0
+    h = K.to_handle(m)
+    try:
+        fh = K.filter_zeros(h)
+        f = K.from_handle(fh)
+        K.release_handle(fh)
+    finally:
+        K.release_handle(h)
+    rp, ci, vs = O.filter_zeros(m.nrows, m.rowptrs, m.colinds, m.values)
+    assert f.nnz == len(ci)
+    assert np.array_equal(f.rowptrs, rp) and np.array_equal(f.colinds, ci)
+    assert np.array_equal(f.values, vs, equal_nan=True)
+
+
+# ---- dense-panel SpMM ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('k', [64, 7, 130])
+def test_spmm_dense(k):
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(k)
+    lens = np.minimum((rng.pareto(0.9, 8000) * 3).astype(np.int64), 9000)
+    A = _rand(rng, 8000, 6000, lens)
+    B = rng.uniform(-1, 1, (A.ncols, k))
+    h = K.to_handle(A)
+    try:
+        Cm = K.mult_dense(h, B)
+    finally:
+        K.release_handle(h)
+    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, A.values, B)
+    bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
+    assert Cm.shape == ref.shape
+    assert np.all(np.abs(Cm - ref) <= 1e-6 * bound + 1e-300)
+    assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
