@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: fp64 SpMV (the reference's mult_vec, csr/kernels/numba/__init__.py:55-67)
+on a 10M x 10M power-law CSR with nnz = 2e8, through the libcsrk C ABI on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in-process; for N > 1 the driver launches one rank per GPU
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`), the matrix is
+row-range partitioned (nnz balanced) with x replicated, and one step = local SpMV + the exchange
+that completes y on every rank (RCCL all-gather by default, `--collective allreduce` for the
+all-reduce north_star names).  The matrix is FIXED as N grows ("scaling": "strong").
+
+One JSON line is printed by rank 0:
+  value      whole-job GFLOP/s = 2 * nnz / (max-over-ranks wall time per step), inputs resident
+             in HBM before the timed region;
+  roofline   the dominant kernel (spmv_merge_kernel): algorithmic bytes per launch
+             (12 B/nnz + 4 B/row pointer + 8 B/row of y + 8 B/col of x) divided by its
+             mean duration, measured live with hipEvent pairs recorded around that kernel on
+             its launch stream during the timed steps (csrk_spmv_profile_begin/end);
+             peak = 8000 GB/s (HBM3E spec); traffic = per-launch HBM bytes from the committed
+             rocprofv3 PMC summary (profiles/), or null;
+  cpu_baseline  the oracle's sequential restatement of the reference loop (oracle/csr_oracle.c,
+             kind "port", 1 core) timed on this host on the same matrix, plus a full-size
+             parity check of the GPU result against it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink the matrix (testing only; INVALID as a result)')
+    ap.add_argument('--alpha', type=float, default=1.1)
+    ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
+    ap.add_argument('--collective', default='allgather', choices=['allgather', 'allreduce'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
+    ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
+    return ap.parse_args()
+
+
+def load_traffic(path, workload):
+    "per-launch HBM bytes of the dominant kernel from a committed PMC summary, or None"
+    cands = [path] if path else []
+    pdir = os.path.join(ROOT, 'profiles')
+    if os.path.isdir(pdir):
+        cands += sorted((os.path.join(pdir, f) for f in os.listdir(pdir) if f.endswith('_pmc_traffic.json')),
+                        reverse=True)
+    for p in cands:
+        try:
+            with open(p) as f:
+                d = json.load(f)
+            if d.get('workload') == workload and d.get('hbm_bytes_per_launch'):
+                return float(d['hbm_bytes_per_launch'])
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from csr_amd import synth
+    from csr_amd._lib import lib, check, handle_t, SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR
+    from csr_amd.dist import RowPartitionedSpMV, hip_local_spmv
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs the torch.distributed launcher '
+                     f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...)')
+        sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: no GPU is visible (the product has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    check(lib.csrk_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    nrows = ncols = int(round(10_000_000 * args.scale))
+    nnz = int(round(200_000_000 * args.scale))
+    workload = f'spmv_powerlaw_{nrows}x{ncols}_nnz{nnz}_fp64'
+
+    t_gen = time.time()
+    shard = synth.powerlaw_csr(nrows, ncols, nnz, alpha=args.alpha, device=dev, rank=rank, world=world)
+    x = synth.dense_vector(ncols, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    rp, ci, vs = shard['rowptrs'], shard['colinds'], shard['values']
+    n_loc = shard['row_end'] - shard['row_begin']
+    nnz_loc = int(ci.numel())
+
+    h = handle_t(0)
+    check(lib.csrk_create_device(n_loc, ncols, nnz_loc, rp.data_ptr(), int(rp.dtype == torch.int64),
+                                 ci.data_ptr(), vs.data_ptr(), 2, C.byref(h)))
+    algo_code = {'auto': SPMV_AUTO, 'merge': SPMV_MERGE, 'vector': SPMV_VECTOR, 'scalar': SPMV_SCALAR}[args.algo]
+    check(lib.csrk_set_spmv_algo(h, algo_code))
+    op = RowPartitionedSpMV(shard['bounds'], rank, world, hip_local_spmv(h.value), dev, mode=args.collective)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        op.step(x)
+    barrier()
+    check(lib.csrk_spmv_profile_begin(h, args.steps))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = op.step(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_rec, k_ms = C.c_int(0), C.c_float(0.0)
+    check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), C.byref(k_ms)))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    algo_name = lib.csrk_spmv_algo_name(h).decode()
+    n_tiles, tile_items = C.c_int64(0), C.c_int32(0)
+    check(lib.csrk_spmv_plan_info(h, C.byref(n_tiles), C.byref(tile_items)))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
+    # algorithmic bytes of ONE launch of the dominant kernel on this rank:
+    # colinds 4 B + values 8 B per nnz, one row pointer and one y entry per row, x read once
+    alg_bytes = nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8
+    achieved = alg_bytes / (k_ms.value * 1e-3) / 1e9 if k_ms.value > 0 else 0.0
+    roofline = {
+        'bound': 'hbm', 'kernel': f'spmv_{algo_name}_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+        'traffic': load_traffic(args.traffic_json, workload) if world == 1 else None,
+        'kernel_ms': round(k_ms.value, 4), 'launches_timed': n_rec.value, 'algorithmic_bytes': alg_bytes,
+        'frac_of_measured_copy_peak_6290': round(achieved / 6290.0, 4),
+    }
+
+    out = {
+        'metric': 'spmv_gflops', 'value': round(gflops, 2), 'unit': 'GFLOP/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': workload, 'nrows': nrows, 'ncols': ncols, 'nnz': nnz,
+                   'row_degree': f'power-law alpha={args.alpha}, max {int(min(1_000_000, ncols // 8))}',
+                   'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
+                   'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
+                   'parallelism': f'row-partition x{world}',
+                   'collective': args.collective if world > 1 else 'none'},
+        'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),
+        'roofline': roofline,
+        'gen_seconds': round(t_gen, 2),
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O       # the checker / baseline, never the thing measured above
+        rp_h, ci_h, vs_h = rp.cpu().numpy(), ci.cpu().numpy(), vs.cpu().numpy()
+        x_h = x.cpu().numpy()
+        y_gpu = y.cpu().numpy()
+        y_cpu = O.mult_vec(nrows, ncols, rp_h, ci_h, vs_h, x_h)          # warm-up + parity reference
+        reps, t_cpu = 0, 0.0
+        while reps < 1 or (t_cpu < args.cpu_seconds and reps < 10):
+            t1 = time.perf_counter()
+            O.mult_vec(nrows, ncols, rp_h, ci_h, vs_h, x_h)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        bound = O.mult_vec(nrows, ncols, rp_h, ci_h, np.abs(vs_h), np.abs(x_h))
+        err = np.abs(y_gpu - y_cpu)
+        worst = float(np.max(err / (bound + 1e-300)))
+        out['cpu_baseline'] = {
+            'value': round(2.0 * nnz / (t_cpu / reps) / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1, 'kind': 'port',
+            'sample': f'the full {nrows}x{ncols} nnz={nnz} matrix, {reps} timed passes of orc_mult_vec_i32 '
+                      f'({t_cpu / reps:.2f} s each)',
+            'host_cpus': os.cpu_count(),
+        }
+        out['parity'] = {'max_abs_err_over_sum_abs_terms': worst, 'tolerance': 1e-6, 'ok': bool(worst <= 1e-6),
+                         'rows_bit_identical': float(np.mean(y_gpu == y_cpu))}
+        if worst > 1e-6:
+            print(json.dumps(out))
+            sys.exit('PARITY FAILURE: GPU result differs from the oracle')
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    check(lib.csrk_free(h))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

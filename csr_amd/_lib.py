@@ -28,6 +28,16 @@ if not os.path.exists(LIB_PATH):
         f'{LIB_PATH} is not built: run `python csr_amd/build.py` (needs hipcc). '
         'csr_amd has no CPU fallback.')
 
+# One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
+# /opt/rocm's).  If torch initialises its copy AFTER libcsrk has pulled in the system copy, the
+# process ends up with two runtimes and the second one to touch the GPU sees no device.  Loading
+# torch's copy first makes the dynamic linker resolve libcsrk's DT_NEEDED to it.  torch is optional:
+# without it libcsrk simply uses /opt/rocm's runtime.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 handle_t = C.c_ssize_t     # intptr_t
@@ -53,6 +63,8 @@ SIGNATURES = {
     'csrk_set_spmv_algo': (_int, [handle_t, _int]),
     'csrk_spmv_algo_name': (C.c_char_p, [handle_t]),
     'csrk_spmv_plan_info': (_int, [handle_t, C.POINTER(_i64), C.POINTER(_i32)]),
+    'csrk_spmv_profile_begin': (_int, [handle_t, _int]),
+    'csrk_spmv_profile_end': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
     'csrk_spgemm_ab': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),

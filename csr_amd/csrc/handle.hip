@@ -4,9 +4,25 @@
 // row_extent / row_nnzs (csr/_rows.py:9-13, csr/csr.py:432-441).
 #include "common.h"
 
+#include <unordered_set>
+
 namespace csrk {
 
 static thread_local std::string g_last_error;
+
+// Live handles: a csrk_handle_t coming through the C ABI is validated against this set, so a
+// stale or garbage integer is an error return, never a wild pointer dereference.
+static std::mutex g_live_mu;
+static std::unordered_set<const Matrix *> &live_set()
+{
+    static std::unordered_set<const Matrix *> s;
+    return s;
+}
+static void register_matrix(const Matrix *m)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    live_set().insert(m);
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -28,12 +44,19 @@ Matrix::~Matrix()
         if (d_values) (void)hipFree(d_values);
     }
     magic = 0;
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    live_set().erase(this);
 }
 
 Matrix *from_handle(csrk_handle_t h)
 {
     Matrix *m = reinterpret_cast<Matrix *>(h);
-    if (!m || m->magic != 0x4353524b) {
+    bool ok = false;
+    if (m) {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        ok = live_set().count(m) != 0;
+    }
+    if (!ok || m->magic != 0x4353524b) {
         set_error("invalid csrk handle %p", (void *)h);
         return nullptr;
     }
@@ -47,6 +70,7 @@ int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_typ
         set_error("out of host memory");
         return CSRK_ERR_INVALID;
     }
+    register_matrix(m);
     m->nrows = nrows;
     m->ncols = ncols;
     m->nnz = nnz;
@@ -163,6 +187,7 @@ int csrk_create_device(int32_t nrows, int32_t ncols, int64_t nnz, const void *d_
     CSRK_REQUIRE(ptr_is_64 || nnz <= INT32_MAX, "nnz %lld needs 64-bit row pointers", (long long)nnz);
     Matrix *m = new (std::nothrow) Matrix();
     CSRK_REQUIRE(m, "out of host memory");
+    register_matrix(m);
     m->nrows = nrows;
     m->ncols = ncols;
     m->nnz = nnz;

@@ -29,6 +29,8 @@
 // csr/csr.py:254-262).
 #include "common.h"
 
+#include <vector>
+
 namespace csrk {
 
 // ---- value loads ------------------------------------------------------------------------
@@ -64,6 +66,32 @@ struct SpmvPlan {
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
     DevBuf seg_row;     // int32[n_segs]
     DevBuf seg_part;    // double[n_segs]
+    // kernel timing (csrk_spmv_profile_begin/end)
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    int ev_used = 0;
+    bool profiling = false;
+    ~SpmvPlan()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+struct KernelTimer {   // records an event pair around one launch when the plan is profiling
+    SpmvPlan *p;
+    hipStream_t s;
+    int slot = -1;
+    KernelTimer(SpmvPlan *p_, hipStream_t s_) : p(p_), s(s_)
+    {
+        if (p->profiling && p->ev_used + 2 <= (int)p->ev.size()) {
+            slot = p->ev_used;
+            p->ev_used += 2;
+            (void)hipEventRecord(p->ev[slot], s);
+        }
+    }
+    void stop()
+    {
+        if (slot >= 0) (void)hipEventRecord(p->ev[slot + 1], s);
+    }
 };
 
 void free_spmv_plan(SpmvPlan *p) { delete p; }
@@ -341,9 +369,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     if (m->nrows == 0) return CSRK_OK;
     switch (p->algo) {
     case CSRK_SPMV_MERGE: {
+        KernelTimer kt(p, s);
         spmv_merge_kernel<P, VT><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
             rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
             p->carry_row.as<int32_t>(), p->carry_val.as<double>());
+        kt.stop();
         CSRK_LAUNCH_CHECK();
         spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
             p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
@@ -352,9 +382,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     }
     case CSRK_SPMV_VECTOR: {
         if (p->n_segs > 0) {
+            KernelTimer kt(p, s);
             spmv_vector_kernel<P, VT><<<(unsigned)ceil_div(p->n_segs * WAVE, 256), 256, 0, s>>>(
                 rp, m->d_colinds, m->d_values, d_x, d_y, p->seg_off.as<int64_t>(), p->seg_row.as<int32_t>(),
                 p->n_segs, p->seg_part.as<double>());
+            kt.stop();
             CSRK_LAUNCH_CHECK();
             spmv_vector_fixup_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(
                 p->seg_off.as<int64_t>(), m->nrows, p->seg_part.as<double>(), d_y);
@@ -363,8 +395,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         break;
     }
     case CSRK_SPMV_SCALAR: {
+        KernelTimer kt(p, s);
         spmv_scalar_kernel<P, VT><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->d_colinds, m->d_values, d_x,
                                                                                   d_y, m->nrows);
+        kt.stop();
         CSRK_LAUNCH_CHECK();
         break;
     }
@@ -456,6 +490,47 @@ const char *csrk_spmv_algo_name(csrk_handle_t h)
     case CSRK_SPMV_SCALAR: return "scalar";
     default: return "auto";
     }
+}
+
+int csrk_spmv_profile_begin(csrk_handle_t h, int max_records)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(max_records > 0 && max_records <= 100000, "max_records out of range");
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));
+    std::lock_guard<std::mutex> lk(m->mu);
+    while ((int)p->ev.size() < 2 * max_records) {
+        hipEvent_t e;
+        CSRK_HIP(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    p->ev_used = 0;
+    p->profiling = true;
+    return CSRK_OK;
+}
+
+int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(n_records && mean_ms, "output is NULL");
+    std::lock_guard<std::mutex> lk(m->mu);
+    SpmvPlan *p = m->spmv_plan;
+    CSRK_REQUIRE(p && p->profiling, "profiling was not started on this handle");
+    p->profiling = false;
+    double tot = 0.0;
+    int n = p->ev_used / 2;
+    for (int i = 0; i < n; i++) {
+        float ms = 0.f;
+        CSRK_HIP(hipEventSynchronize(p->ev[2 * i + 1]));
+        CSRK_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        tot += ms;
+    }
+    *n_records = n;
+    *mean_ms = n ? (float)(tot / n) : 0.f;
+    p->ev_used = 0;
+    return CSRK_OK;
 }
 
 int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items)

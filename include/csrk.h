@@ -112,6 +112,14 @@ CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);
 /* Launch geometry of the dominant SpMV kernel (for roofline accounting in bench.py). */
 CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items);
 
+/* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
+ * this handle brackets its DOMINANT kernel (the tile / segment / row kernel, not the carry
+ * fix-up) with a hipEvent pair recorded on the launch stream; nothing synchronises until
+ * csrk_spmv_profile_end, which returns the number of recorded launches and their mean
+ * duration in milliseconds.  At most `max_records` launches are recorded. */
+CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
+CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);
+
 /* ---- mult_ab / mult_abt: sparse x sparse -> sparse ------------------------------------
  * csr/kernels/numba/multiply.py:13-57; lk_mkl_spmab / lk_mkl_spmabt (mkl_ops.h:30-31).
  * The product is a NEW handle owned by the caller (rowptrs int32 as in multiply.py:28,

@@ -1,0 +1,75 @@
+"""
+The C-ABI library loads and exports every symbol include/csrk.h declares; the ctypes table in
+csr_amd/_lib.py covers exactly that set; and without a GPU the product fails loudly instead of
+falling back to anything.  No compute on this path (CPU suite).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'csrk.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'CSRK_API\s+[\w\s\*]+?\b(csrk_\w+)\s*\(', text)))
+
+
+def test_header_symbols_exported():
+    names = _declared()
+    assert len(names) >= 25 and 'csrk_spmv' in names and 'csrk_transpose' in names
+    lib = ctypes.CDLL(os.path.join(ROOT, 'csr_amd', 'libcsrk.so'))
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/csrk.h but not exported'
+
+
+def test_ctypes_table_matches_header():
+    from csr_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_only_csrk_symbols_are_exported():
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', os.path.join(ROOT, 'csr_amd', 'libcsrk.so')],
+                         capture_output=True, text=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if ' T ' in l]
+    ours = [s for s in syms if not s.startswith('_') and not s.startswith('__hip')]
+    assert ours and all(s.startswith('csrk_') for s in ours), [s for s in ours if not s.startswith('csrk_')][:5]
+
+
+def test_version_and_error_string():
+    from csr_amd._lib import lib
+    assert lib.csrk_version() >= 1
+    assert lib.csrk_free(0) == 0            # idempotent on the null handle
+    assert lib.csrk_free(12345) != 0        # not a handle: error code, no crash
+    assert b'invalid csrk handle' in lib.csrk_last_error()
+
+
+def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
+    "the product package must not reference oracle/ in any form"
+    pkg = os.path.join(ROOT, 'csr_amd')
+    for dp, _, fns in os.walk(pkg):
+        if 'build' in dp.split(os.sep):
+            continue
+        for fn in fns:
+            if fn.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dp, fn)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'liboracle' not in text, fn
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip('a GPU is present')
+    from csr_amd import CSR
+    from csr_amd._lib import CsrkError
+    a = CSR.from_coo(np.array([0, 1]), np.array([1, 0]), np.array([1.0, 2.0]))
+    with pytest.raises(CsrkError) as ei:
+        a.mult_vec(np.ones(2))
+    assert 'hip' in str(ei.value).lower()
+    with pytest.raises(CsrkError):
+        a.transpose()
