@@ -61,6 +61,19 @@ struct SpmvPlan {
     DevBuf tile_row;    // int32[n_tiles + 1]: rows completed before each tile boundary
     DevBuf carry_row;   // int32[n_tiles]
     DevBuf carry_val;   // double[n_tiles]
+    // merge, heavy-row split (rows >= HEAVY_MIN entries are cut out of the merge path)
+    int32_t n_heavy = 0;
+    int64_t nnz_light = 0;
+    int64_t n_pieces = 0;
+    int32_t n_blocks = 0;
+    DevBuf rp_light;    // P[nrows + 1]: row pointers with the heavy rows collapsed to length 0
+    DevBuf cut_pos;     // int64[n_heavy]: light-index position of each heavy row
+    DevBuf cut_cum;     // int64[n_heavy + 1]: heavy entries before each heavy row (shift table)
+    DevBuf tile_cut;    // int32[n_tiles + 1]: cuts at or before each tile start
+    DevBuf heavy_row;   // int32[n_heavy]
+    DevBuf piece;       // HeavyPiece[n_pieces], column-block-major
+    DevBuf part_off;    // int64[n_heavy + 1]: first partial slot of each heavy row
+    DevBuf part;        // double[n_pieces]
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -126,18 +139,66 @@ __global__ void merge_plan_kernel(const P *__restrict__ rp, int32_t nrows, int64
     tile_row[t] = (int32_t)lo;
 }
 
-template <class P, int VT>
+// 4-byte-aligned pair types: tile starts fall on arbitrary nnz indices, and gfx950 global loads
+// only need dword alignment, so two consecutive colinds / values are fetched with one
+// dwordx2 / dwordx4 load per lane (512 B / 1 KiB per wave-instruction).
+typedef int32_t i32x2_t __attribute__((ext_vector_type(2)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef i32x2_t I32x2 __attribute__((aligned(4)));
+typedef f64x2_t F64x2 __attribute__((aligned(4)));
+typedef f32x2_t F32x2 __attribute__((aligned(4)));
+
+template <int VT>
+__device__ __forceinline__ void load_val_pair(const void *vs, int64_t k, bool two, double &v0, double &v1)
+{
+    if (VT == CSRK_VAL_F64) {
+        const double *p = (const double *)vs + k;
+        if (two) {
+            f64x2_t t = __builtin_nontemporal_load((const F64x2 *)p);
+            v0 = t.x;
+            v1 = t.y;
+        } else {
+            v0 = *p;
+            v1 = 0.0;
+        }
+    } else if (VT == CSRK_VAL_F32) {
+        const float *p = (const float *)vs + k;
+        if (two) {
+            f32x2_t t = *(const F32x2 *)p;
+            v0 = t.x;
+            v1 = t.y;
+        } else {
+            v0 = *p;
+            v1 = 0.0;
+        }
+    } else {
+        v0 = 1.0;
+        v1 = two ? 1.0 : 0.0;
+    }
+}
+
+constexpr int MERGE_PAIRS = MERGE_IPT / 2;
+
+// HEAVY: the path runs over the light view (rp = rp_light, nnz = nnz_light); a light entry index
+// jl maps to the actual entry jl + cut_cum[#cuts with cut_pos <= jl].
+template <class P, int VT, bool HEAVY>
 __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
-    int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
+    int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
+    const int32_t *__restrict__ tile_cut, const int64_t *__restrict__ cut_pos,
+    const int64_t *__restrict__ cut_cum)
 {
-    __shared__ double s_prod[MERGE_ITEMS];
-    __shared__ int32_t s_rend[MERGE_ITEMS + 1];
+    // One LDS buffer: nn products (8 B each) followed by nr + 1 tile-relative row ends (4 B each);
+    // nn + nr <= MERGE_ITEMS, so MERGE_ITEMS * 8 + 8 bytes always suffice (16.4 KB -> 8 tiles per CU).
+    __shared__ double s_buf[MERGE_ITEMS + 1];
     __shared__ int32_t s_long[MERGE_MAXLONG];
     __shared__ int32_t s_nlong;
+    __shared__ double s_wpart[MERGE_THREADS / WAVE];
 
     const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int64_t t = blockIdx.x;
     const int32_t i0 = tile_row[t], i1 = tile_row[t + 1];
     const int64_t total = (int64_t)nrows + nnz;
@@ -146,25 +207,106 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const int64_t j0 = d0 - i0;
     const int nn = (int)((d1 - i1) - j0);   // nnz in this tile
     const int nr = i1 - i0;                 // rows completed in this tile
-    if (tid == 0) s_nlong = 0;
 
-    // phase 1a: products, coalesced; issue every colind load before the dependent gathers
-    int32_t col[MERGE_IPT];
-#pragma unroll
-    for (int u = 0; u < MERGE_IPT; u++) {
-        int k = tid + u * MERGE_THREADS;
-        col[u] = k < nn ? __builtin_nontemporal_load(ci + j0 + k) : 0;
+    // light index -> actual entry index
+    int64_t ja = j0;                        // actual index of the tile's first entry
+    int32_t cb = 0, ce = 0;                 // cuts strictly inside the tile: [cb, ce)
+    if (HEAVY) {
+        cb = tile_cut[t];
+        ce = tile_cut[t + 1];
+        ja = j0 + cut_cum[cb];
     }
-    double a[MERGE_IPT];
+
+    // phase 1a: products.  Lane owns the consecutive pair (2q, 2q+1), q = tid + u*THREADS; all
+    // colind loads are issued before the dependent x gathers.
+    int32_t c0[MERGE_PAIRS], c1[MERGE_PAIRS];
+    double p0[MERGE_PAIRS], p1[MERGE_PAIRS];
+    if (!HEAVY || cb == ce) {
 #pragma unroll
-    for (int u = 0; u < MERGE_IPT; u++) {
-        int k = tid + u * MERGE_THREADS;
-        a[u] = k < nn ? ValLoad<VT>::at(vs, j0 + k) : 0.0;
+        for (int u = 0; u < MERGE_PAIRS; u++) {
+            const int k = 2 * (tid + u * MERGE_THREADS);
+            c0[u] = c1[u] = 0;
+            if (k + 1 < nn) {
+                i32x2_t cc = __builtin_nontemporal_load((const I32x2 *)(ci + ja + k));
+                c0[u] = cc.x;
+                c1[u] = cc.y;
+            } else if (k < nn) {
+                c0[u] = ci[ja + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MERGE_PAIRS; u++) {
+            const int k = 2 * (tid + u * MERGE_THREADS);
+            p0[u] = p1[u] = 0.0;
+            if (k < nn) load_val_pair<VT>(vs, ja + k, k + 1 < nn, p0[u], p1[u]);
+        }
+    } else {
+        // a heavy row was cut out somewhere inside this tile: per-entry shift (rare tiles)
+#pragma unroll
+        for (int u = 0; u < MERGE_PAIRS; u++) {
+            const int k = 2 * (tid + u * MERGE_THREADS);
+            c0[u] = c1[u] = 0;
+            p0[u] = p1[u] = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (k + h < nn) {
+                    const int64_t jl = j0 + k + h;
+                    int32_t lo = cb, hi = ce;
+                    while (lo < hi) {
+                        int32_t mid = (lo + hi) >> 1;
+                        if (cut_pos[mid] <= jl)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    const int64_t a = jl + cut_cum[lo];
+                    double v0, v1;
+                    load_val_pair<VT>(vs, a, false, v0, v1);
+                    if (h == 0) {
+                        c0[u] = ci[a];
+                        p0[u] = v0;
+                    } else {
+                        c1[u] = ci[a];
+                        p1[u] = v0;
+                    }
+                }
+            }
+        }
     }
 #pragma unroll
-    for (int u = 0; u < MERGE_IPT; u++) {
-        int k = tid + u * MERGE_THREADS;
-        if (k < nn) s_prod[k] = x[col[u]] * a[u];
+    for (int u = 0; u < MERGE_PAIRS; u++) {
+        const int k = 2 * (tid + u * MERGE_THREADS);
+        if (k < nn) p0[u] *= x[c0[u]];
+        if (k + 1 < nn) p1[u] *= x[c1[u]];
+    }
+
+    if (nr == 0) {
+        // The whole tile lies inside one row (a row longer than the tile): no LDS staging, each
+        // lane sums its products, wavefront __shfl_down tree, four wave partials in fixed order.
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < MERGE_PAIRS; u++) acc += p0[u] + p1[u];
+        acc = wave_sum(acc);
+        if (lane == 0) s_wpart[wv] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = s_wpart[0];
+#pragma unroll
+            for (int w = 1; w < MERGE_THREADS / WAVE; w++) tot += s_wpart[w];
+            carry_row[t] = i1 < nrows ? i1 : -1;
+            carry_val[t] = tot;
+        }
+        return;
+    }
+
+    double *s_prod = s_buf;
+    int32_t *s_rend = (int32_t *)(s_buf + nn);
+    if (tid == 0) s_nlong = 0;
+#pragma unroll
+    for (int u = 0; u < MERGE_PAIRS; u++) {
+        const int k = 2 * (tid + u * MERGE_THREADS);
+        if (k < nn) s_prod[k] = p0[u];
+        if (k + 1 < nn) s_prod[k + 1] = p1[u];
     }
     // phase 1b: tile-relative row ends; the tail segment (row i1, not completed here) ends at nn
     for (int r = tid; r < nr; r += MERGE_THREADS) s_rend[r] = (int32_t)((int64_t)rp[i0 + r + 1] - j0);
@@ -193,8 +335,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
 
     // phase 2b: long rows, one wavefront each
     const int nlong = s_nlong;
-    const int lane = tid & (WAVE - 1);
-    for (int q = tid / WAVE; q < nlong; q += MERGE_THREADS / WAVE) {
+    for (int q = wv; q < nlong; q += MERGE_THREADS / WAVE) {
         int r = s_long[q];
         int s = r ? s_rend[r - 1] : 0;
         int e = s_rend[r];
@@ -210,6 +351,192 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
             }
         }
     }
+}
+
+// ---- heavy rows: column-blocked segments ----------------------------------------------------
+// A row with thousands of entries sweeps a large part of x; with rows processed one after another
+// every gather misses L2 and is served by the Infinity Cache (measured: ~14.5 ps per gather against
+// ~2.9 ps for an L2 hit).  Rows with >= HEAVY_MIN entries are therefore taken
+// out of the merge path and cut at column-block boundaries (HEAVY_BLOCK columns = 1 MiB of x);
+// the pieces are processed block-major, so all pieces in flight read the same x window and it
+// stays in each XCD's 4 MiB L2.  Needs ascending columns inside heavy rows (checked at plan time;
+// otherwise the split is disabled).  One wavefront per piece, partials summed per row in column
+// order by a second kernel: deterministic.
+constexpr int HEAVY_MIN = 2048;
+constexpr int HEAVY_BLOCK = 131072;
+constexpr int HEAVY_PIECE = 1024;
+
+struct HeavyPiece {
+    int64_t start;     // first entry (index into colinds/values)
+    int32_t len;
+    int32_t pad;
+    int64_t slot;      // partial slot (row-major, column order inside the row)
+};
+
+template <class P>
+__global__ void heavy_flag_kernel(const P *__restrict__ rp, int32_t nrows, int32_t *__restrict__ flag,
+                                  int64_t *__restrict__ hlen)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    int64_t len = r < nrows ? (int64_t)rp[r + 1] - (int64_t)rp[r] : 0;
+    bool h = len >= HEAVY_MIN;
+    flag[r] = h ? 1 : 0;
+    hlen[r] = h ? len : 0;
+}
+
+template <class P>
+__global__ void heavy_view_kernel(const P *__restrict__ rp, int32_t nrows, const int32_t *__restrict__ hidx,
+                                  const int64_t *__restrict__ hbefore, P *__restrict__ rp_light,
+                                  int32_t *__restrict__ heavy_row, int64_t *__restrict__ cut_pos,
+                                  int64_t *__restrict__ cut_cum, int32_t n_heavy)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    const int64_t light = (int64_t)rp[r] - hbefore[r];
+    rp_light[r] = (P)light;
+    if (r < nrows && hidx[r + 1] != hidx[r]) {     // row r is heavy
+        const int32_t c = hidx[r];
+        heavy_row[c] = (int32_t)r;
+        cut_pos[c] = light;
+        cut_cum[c] = hbefore[r];
+    }
+    if (r == nrows) cut_cum[n_heavy] = hbefore[nrows];
+}
+
+template <class P>
+__global__ void heavy_sorted_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t *__restrict__ bad)
+{
+    const int c = blockIdx.x;
+    if (c >= n_heavy) return;
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    bool b = false;
+    for (int64_t k = s + threadIdx.x; k + 1 < e; k += blockDim.x) b |= ci[k] > ci[k + 1];
+    if (b) atomicOr(bad, 1);
+}
+
+__device__ __forceinline__ int64_t lower_bound_col(const int32_t *__restrict__ ci, int64_t lo, int64_t hi, int64_t col)
+{
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)ci[mid] < col)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// one thread per (heavy row c, column block b): number of pieces, in both orders
+template <class P>
+__global__ void heavy_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
+                                   int64_t *__restrict__ cnt_bh, int64_t *__restrict__ cnt_hb)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_heavy * n_blocks) return;
+    const int32_t c = (int32_t)(i / n_blocks), b = (int32_t)(i % n_blocks);
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
+    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
+    const int64_t n = (hi - lo + HEAVY_PIECE - 1) / HEAVY_PIECE;
+    cnt_bh[(int64_t)b * n_heavy + c] = n;
+    cnt_hb[i] = n;
+}
+
+template <class P>
+__global__ void heavy_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                  const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
+                                  const int64_t *__restrict__ off_bh, const int64_t *__restrict__ off_hb,
+                                  HeavyPiece *__restrict__ piece, int64_t *__restrict__ part_off)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_heavy * n_blocks) return;
+    const int32_t c = (int32_t)(i / n_blocks), b = (int32_t)(i % n_blocks);
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
+    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
+    int64_t pos = off_bh[(int64_t)b * n_heavy + c], slot = off_hb[i];
+    if (b == 0) part_off[c] = slot;
+    if (i == (int64_t)n_heavy * n_blocks - 1) part_off[n_heavy] = off_hb[i + 1];
+    for (int64_t k = lo; k < hi; k += HEAVY_PIECE) {
+        HeavyPiece pc;
+        pc.start = k;
+        pc.len = (int32_t)(hi - k < HEAVY_PIECE ? hi - k : HEAVY_PIECE);
+        pc.pad = 0;
+        pc.slot = slot++;
+        piece[pos++] = pc;
+    }
+}
+
+// cuts at or before each tile start: tile_cut[t] = #{c : cut_pos[c] <= j0(t)}
+__global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64_t n_tiles, int items, int64_t total,
+                                     const int64_t *__restrict__ cut_pos, int32_t n_heavy, int32_t *__restrict__ tile_cut)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    int64_t d = t * items;
+    if (d > total) d = total;
+    const int64_t j0 = d - tile_row[t];
+    int32_t lo = 0, hi = n_heavy;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (cut_pos[mid] <= j0)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    tile_cut[t] = lo;
+}
+
+template <int VT>
+__global__ __launch_bounds__(256) void spmv_heavy_kernel(const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                        const double *__restrict__ x,
+                                                        const HeavyPiece *__restrict__ piece, int64_t n_pieces,
+                                                        double *__restrict__ part)
+{
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (q >= n_pieces) return;
+    const HeavyPiece pc = piece[q];
+    const int64_t s = pc.start;
+    const int n = pc.len;
+    double acc = 0.0;
+    // lane owns consecutive pairs: 512 B of colinds / 1 KiB of values per wave-instruction
+    for (int k = 2 * lane; k < n; k += 2 * WAVE) {
+        if (k + 1 < n) {
+            i32x2_t cc = __builtin_nontemporal_load((const I32x2 *)(ci + s + k));
+            double v0, v1;
+            load_val_pair<VT>(vs, s + k, true, v0, v1);
+            acc += v0 * x[cc.x];
+            acc += v1 * x[cc.y];
+        } else {
+            double v0, v1;
+            load_val_pair<VT>(vs, s + k, false, v0, v1);
+            acc += v0 * x[ci[s + k]];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[pc.slot] = acc;
+}
+
+// one wavefront per heavy row: partials in column order (lane-strided, then the shfl tree)
+__global__ __launch_bounds__(256) void spmv_heavy_reduce_kernel(const int32_t *__restrict__ heavy_row,
+                                                               const int64_t *__restrict__ part_off, int32_t n_heavy,
+                                                               const double *__restrict__ part, double *__restrict__ y)
+{
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (c >= n_heavy) return;
+    const int64_t a = part_off[c], b = part_off[c + 1];
+    double acc = 0.0;
+    for (int64_t q = a + lane; q < b; q += WAVE) acc += part[q];
+    acc = wave_sum(acc);
+    if (lane == 0) y[heavy_row[c]] = acc;
 }
 
 // One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
@@ -307,21 +634,105 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+static int g_heavy_split = 1;   // CSRK_SPMV_HEAVY_SPLIT=0 disables the heavy-row path (A/B runs)
+
+// Cut the heavy rows out of the merge path and build their column-blocked piece list.
+template <class P>
+static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    p->n_heavy = 0;
+    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
+    if ((env && env[0] == '0') || !g_heavy_split || m->nrows == 0 || m->nnz < HEAVY_MIN) return CSRK_OK;
+    const P *rp = (const P *)m->d_rowptrs;
+    const int32_t nr = m->nrows;
+    const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);
+    DevBuf flag, hlen, bad;
+    CSRK_TRY(flag.alloc((size_t)(nr + 2) * 4));
+    CSRK_TRY(hlen.alloc((size_t)(nr + 2) * 8));
+    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(flag.as<int32_t>(), flag.as<int32_t>(), nr, s));      // -> heavy index
+    CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> heavy nnz before
+    int32_t n_heavy = 0;
+    int64_t nnz_heavy = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_heavy, flag.as<int32_t>() + nr, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipMemcpyAsync(&nnz_heavy, hlen.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    if (n_heavy == 0) return CSRK_OK;
+    const int32_t n_blocks = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, HEAVY_BLOCK);
+    if ((int64_t)n_heavy * n_blocks > (64ll << 20)) return CSRK_OK;   // pair table too large: keep one path
+
+    CSRK_TRY(p->rp_light.alloc((size_t)(nr + 1) * sizeof(P)));
+    CSRK_TRY(p->heavy_row.alloc((size_t)n_heavy * 4));
+    CSRK_TRY(p->cut_pos.alloc((size_t)n_heavy * 8));
+    CSRK_TRY(p->cut_cum.alloc((size_t)(n_heavy + 1) * 8));
+    heavy_view_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), p->rp_light.as<P>(),
+                                          p->heavy_row.as<int32_t>(), p->cut_pos.as<int64_t>(),
+                                          p->cut_cum.as<int64_t>(), n_heavy);
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(bad.alloc(4));
+    CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    heavy_sorted_kernel<P><<<(unsigned)n_heavy, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy,
+                                                           bad.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    int32_t is_bad = 0;
+    CSRK_HIP(hipMemcpyAsync(&is_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    if (is_bad) return CSRK_OK;      // unsorted columns in a heavy row: column blocking needs order
+
+    const int64_t pairs = (int64_t)n_heavy * n_blocks;
+    DevBuf c_bh, c_hb;
+    CSRK_TRY(c_bh.alloc((size_t)(pairs + 1) * 8));
+    CSRK_TRY(c_hb.alloc((size_t)(pairs + 1) * 8));
+    const unsigned g2 = (unsigned)ceil_div(pairs, 256);
+    heavy_count_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
+                                           c_bh.as<int64_t>(), c_hb.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(c_bh.as<int64_t>(), c_bh.as<int64_t>(), pairs, s));
+    CSRK_TRY(exclusive_scan_i64(c_hb.as<int64_t>(), c_hb.as<int64_t>(), pairs, s));
+    int64_t n_pieces = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_pieces, c_bh.as<int64_t>() + pairs, 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    CSRK_TRY(p->piece.alloc((size_t)n_pieces * sizeof(HeavyPiece)));
+    CSRK_TRY(p->part.alloc((size_t)n_pieces * 8));
+    CSRK_TRY(p->part_off.alloc((size_t)(n_heavy + 1) * 8));
+    heavy_fill_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
+                                          c_bh.as<int64_t>(), c_hb.as<int64_t>(), p->piece.as<HeavyPiece>(),
+                                          p->part_off.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipStreamSynchronize(s));
+    p->n_heavy = n_heavy;
+    p->n_blocks = n_blocks;
+    p->n_pieces = n_pieces;
+    p->nnz_light = m->nnz - nnz_heavy;
+    return CSRK_OK;
+}
+
 template <class P>
 static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
     if (p->algo == CSRK_SPMV_MERGE) {
         p->tile_items = MERGE_ITEMS;
-        int64_t total = (int64_t)m->nrows + m->nnz;
+        p->nnz_light = m->nnz;
+        CSRK_TRY(build_heavy_split<P>(m, p, s));
+        const P *rp_path = p->n_heavy ? p->rp_light.as<P>() : rp;
+        int64_t total = (int64_t)m->nrows + p->nnz_light;
         p->n_tiles = ceil_div(total, MERGE_ITEMS);
         CSRK_TRY(p->tile_row.alloc((size_t)(p->n_tiles + 1) * 4));
         CSRK_TRY(p->carry_row.alloc((size_t)p->n_tiles * 4));
         CSRK_TRY(p->carry_val.alloc((size_t)p->n_tiles * 8));
         int64_t nthr = p->n_tiles + 1;
-        merge_plan_kernel<P><<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(rp, m->nrows, m->nnz, MERGE_ITEMS,
+        merge_plan_kernel<P><<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(rp_path, m->nrows, p->nnz_light, MERGE_ITEMS,
                                                                           p->n_tiles, p->tile_row.as<int32_t>());
         CSRK_LAUNCH_CHECK();
+        if (p->n_heavy) {
+            CSRK_TRY(p->tile_cut.alloc((size_t)(p->n_tiles + 1) * 4));
+            heavy_tilecut_kernel<<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(
+                p->tile_row.as<int32_t>(), p->n_tiles, MERGE_ITEMS, total, p->cut_pos.as<int64_t>(), p->n_heavy,
+                p->tile_cut.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+        }
     } else if (p->algo == CSRK_SPMV_VECTOR) {
         CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
         if (m->nrows > 0) {
@@ -370,14 +781,28 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     switch (p->algo) {
     case CSRK_SPMV_MERGE: {
         KernelTimer kt(p, s);
-        spmv_merge_kernel<P, VT><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
-            rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
-            p->carry_row.as<int32_t>(), p->carry_val.as<double>());
+        if (p->n_heavy)
+            spmv_merge_kernel<P, VT, true><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
+                p->rp_light.as<P>(), m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows,
+                p->nnz_light, p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(),
+                p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>());
+        else
+            spmv_merge_kernel<P, VT, false><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
+                rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
+                p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr);
         kt.stop();
         CSRK_LAUNCH_CHECK();
         spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
             p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
         CSRK_LAUNCH_CHECK();
+        if (p->n_heavy) {
+            spmv_heavy_kernel<VT><<<(unsigned)ceil_div(p->n_pieces * WAVE, 256), 256, 0, s>>>(
+                m->d_colinds, m->d_values, d_x, p->piece.as<HeavyPiece>(), p->n_pieces, p->part.as<double>());
+            CSRK_LAUNCH_CHECK();
+            spmv_heavy_reduce_kernel<<<(unsigned)ceil_div((int64_t)p->n_heavy * WAVE, 256), 256, 0, s>>>(
+                p->heavy_row.as<int32_t>(), p->part_off.as<int64_t>(), p->n_heavy, p->part.as<double>(), d_y);
+            CSRK_LAUNCH_CHECK();
+        }
         break;
     }
     case CSRK_SPMV_VECTOR: {

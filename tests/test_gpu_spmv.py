@@ -90,11 +90,14 @@ def test_kat_and_protocol(golden):
         A.mult_vec(np.ones(4))
 
 
-def _random_csr(rng, nrows, ncols, lens, dtype=np.float64, ptr64=False):
+def _random_csr(rng, nrows, ncols, lens, dtype=np.float64, ptr64=False, sort=False):
     rp = np.zeros(nrows + 1, dtype=np.int64 if ptr64 else np.int32)
     rp[1:] = np.cumsum(lens)
     nnz = int(rp[-1])
     ci = rng.integers(0, ncols, size=nnz).astype(np.int32)
+    if sort:     # ascending columns inside rows (duplicates allowed): enables the heavy-row split
+        rows = np.repeat(np.arange(nrows), np.diff(rp))
+        ci = ci[np.lexsort((ci, rows))]
     vs = rng.uniform(-1, 1, size=nnz).astype(dtype)
 
     class M:
@@ -104,27 +107,50 @@ def _random_csr(rng, nrows, ncols, lens, dtype=np.float64, ptr64=False):
     return m
 
 
+SHAPES = ['powerlaw', 'powerlaw_sorted', 'tile_edges', 'tile_edges_sorted', 'one_huge_row', 'one_huge_row_sorted',
+          'adjacent_heavy_sorted', 'all_heavy_sorted', 'all_empty', 'ptr64_f32', 'ptr64_heavy_sorted']
+
+
 @pytest.mark.parametrize('algo', ALGOS)
-@pytest.mark.parametrize('shape', ['powerlaw', 'tile_edges', 'one_huge_row', 'all_empty', 'ptr64_f32'])
+@pytest.mark.parametrize('shape', SHAPES)
 def test_spmv_shapes(algo, shape):
-    "row-length distributions that stress tile boundaries, carries and the long-row path"
+    """
+    Row-length distributions that stress tile boundaries, carries, the long-row path and -- with
+    ascending columns -- the heavy-row split (rows >= 2048 entries cut out of the merge path and
+    processed in column blocks): heavy rows next to each other, at the matrix ends, heavy rows
+    only, wide matrices with several column blocks.
+    """
     from oracle import oracle as O
-    rng = np.random.default_rng(hash(shape) % 2**32)
-    if shape == 'powerlaw':
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    srt = shape.endswith('_sorted')
+    if shape.startswith('powerlaw'):
         nrows = 30000
         lens = np.minimum((rng.pareto(0.9, nrows) * 2).astype(np.int64), 60000)
-        m = _random_csr(rng, nrows, 50000, lens)
-    elif shape == 'tile_edges':
+        m = _random_csr(rng, nrows, 400000, lens, sort=srt)
+    elif shape.startswith('tile_edges'):
         # rows of exactly 2047/2048/2049/63/64/65 entries interleaved with empties
         lens = np.array([2047, 0, 2048, 1, 2049, 0, 0, 63, 64, 65, 4096, 1, 1, 1, 6000] * 40)
-        m = _random_csr(rng, len(lens), 5000, lens)
-    elif shape == 'one_huge_row':
+        m = _random_csr(rng, len(lens), 5000, lens, sort=srt)
+    elif shape.startswith('one_huge_row'):
         lens = np.zeros(5000, dtype=np.int64)
         lens[2500] = 700000
         lens[10] = 3
-        m = _random_csr(rng, 5000, 100000, lens)
+        m = _random_csr(rng, 5000, 1000000, lens, sort=srt)
+    elif shape == 'adjacent_heavy_sorted':
+        lens = rng.integers(0, 6, size=3000)
+        lens[0] = 5000          # first row heavy
+        lens[100:104] = [3000, 2048, 0, 9000]
+        lens[-1] = 2500         # last row heavy
+        m = _random_csr(rng, 3000, 300000, lens, sort=True)
+    elif shape == 'all_heavy_sorted':
+        m = _random_csr(rng, 40, 200000, np.full(40, 3000), sort=True)
     elif shape == 'all_empty':
         m = _random_csr(rng, 100000, 10, np.zeros(100000, dtype=np.int64))
+    elif shape == 'ptr64_heavy_sorted':
+        lens = rng.integers(0, 10, size=5000)
+        lens[::500] = 4000
+        m = _random_csr(rng, 5000, 150000, lens, dtype=np.float32, ptr64=True, sort=True)
     else:
         lens = rng.integers(0, 40, size=20000)
         m = _random_csr(rng, 20000, 3000, lens, dtype=np.float32, ptr64=True)
@@ -138,7 +164,7 @@ def test_spmv_deterministic():
     "no float atomics: repeated launches are bitwise identical"
     rng = np.random.default_rng(11)
     lens = np.minimum((rng.pareto(0.8, 20000) * 3).astype(np.int64), 100000)
-    m = _random_csr(rng, 20000, 40000, lens)
+    m = _random_csr(rng, 20000, 400000, lens, sort=True)
     x = rng.uniform(-1, 1, size=m.ncols)
     ys = [_mult_vec(m, x, 'merge') for _ in range(3)]
     assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
