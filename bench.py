@@ -52,8 +52,8 @@ def parse():
     return ap.parse_args()
 
 
-def load_traffic(path, workload):
-    "per-launch HBM bytes of the dominant kernel from a committed PMC summary, or None"
+def load_traffic(path, workload, kernel):
+    "per-launch HBM bytes of `kernel` from a committed PMC summary, or None"
     cands = [path] if path else []
     pdir = os.path.join(ROOT, 'profiles')
     if os.path.isdir(pdir):
@@ -63,8 +63,8 @@ def load_traffic(path, workload):
         try:
             with open(p) as f:
                 d = json.load(f)
-            if d.get('workload') == workload and d.get('hbm_bytes_per_launch'):
-                return float(d['hbm_bytes_per_launch'])
+            if d.get('workload') == workload and kernel in d.get('hbm_bytes_per_launch', {}):
+                return float(d['hbm_bytes_per_launch'][kernel])
         except (OSError, ValueError):
             continue
     return None
@@ -131,8 +131,8 @@ def main():
         y = op.step(x)
     barrier()
     elapsed = time.perf_counter() - t0
-    n_rec, k_ms = C.c_int(0), C.c_float(0.0)
-    check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), C.byref(k_ms)))
+    n_rec, k_ms2 = C.c_int(0), (C.c_float * 2)(0.0, 0.0)
+    check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,16 +144,29 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    # algorithmic bytes of ONE launch of the dominant kernel on this rank:
-    # colinds 4 B + values 8 B per nnz, one row pointer and one y entry per row, x read once
-    alg_bytes = nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8
-    achieved = alg_bytes / (k_ms.value * 1e-3) / 1e9 if k_ms.value > 0 else 0.0
+    st = (C.c_int64 * 8)()
+    check(lib.csrk_spmv_plan_stats(h, st, 8))
+    n_heavy, nnz_path, n_pieces = int(st[2]), int(st[3]), int(st[4])
+    # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
+    # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer
+    # and writes one y entry per row; each kernel reads x once; the heavy kernel reads one 24-B piece
+    # record and writes one 8-B partial per piece.
+    kernels = [{'kernel': f'spmv_{algo_name}_kernel', 'ms': k_ms2[0], 'entries': nnz_path,
+                'algorithmic_bytes': nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8}]
+    if n_heavy:
+        kernels.append({'kernel': 'spmv_heavy_kernel', 'ms': k_ms2[1], 'entries': nnz_loc - nnz_path,
+                        'algorithmic_bytes': (nnz_loc - nnz_path) * 12 + n_pieces * 32 + ncols * 8})
+    for k in kernels:
+        k['achieved_gbs'] = round(k['algorithmic_bytes'] / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
+        k['ms'] = round(k['ms'], 4)
+    dom = max(kernels, key=lambda k: k['ms'])
     roofline = {
-        'bound': 'hbm', 'kernel': f'spmv_{algo_name}_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-        'traffic': load_traffic(args.traffic_json, workload) if world == 1 else None,
-        'kernel_ms': round(k_ms.value, 4), 'launches_timed': n_rec.value, 'algorithmic_bytes': alg_bytes,
-        'frac_of_measured_copy_peak_6290': round(achieved / 6290.0, 4),
+        'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved_gbs'], 'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s', 'frac': round(dom['achieved_gbs'] / HBM_PEAK_GBS, 4),
+        'traffic': load_traffic(args.traffic_json, workload, dom['kernel']) if world == 1 else None,
+        'kernel_ms': dom['ms'], 'launches_timed': n_rec.value, 'algorithmic_bytes': dom['algorithmic_bytes'],
+        'frac_of_measured_copy_peak_6290': round(dom['achieved_gbs'] / 6290.0, 4),
+        'all_kernels': kernels,
     }
 
     out = {
@@ -165,6 +178,8 @@ def main():
                    'row_degree': f'power-law alpha={args.alpha}, max {int(min(1_000_000, ncols // 8))}',
                    'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
+                   'heavy_rows': n_heavy, 'heavy_pieces': n_pieces, 'heavy_threshold': int(st[6]),
+                   'column_block': int(st[7]),
                    'parallelism': f'row-partition x{world}',
                    'collective': args.collective if world > 1 else 'none'},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),

@@ -74,6 +74,8 @@ struct SpmvPlan {
     DevBuf piece;       // HeavyPiece[n_pieces], column-block-major
     DevBuf part_off;    // int64[n_heavy + 1]: first partial slot of each heavy row
     DevBuf part;        // double[n_pieces]
+    int64_t stream_off[9] = {0};   // piece range of each XCD stream
+    int64_t heavy_grid = 0;
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -81,6 +83,7 @@ struct SpmvPlan {
     DevBuf seg_part;    // double[n_segs]
     // kernel timing (csrk_spmv_profile_begin/end)
     std::vector<hipEvent_t> ev;   // start/stop pairs
+    std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1 = heavy-row kernel
     int ev_used = 0;
     bool profiling = false;
     ~SpmvPlan()
@@ -93,11 +96,12 @@ struct KernelTimer {   // records an event pair around one launch when the plan 
     SpmvPlan *p;
     hipStream_t s;
     int slot = -1;
-    KernelTimer(SpmvPlan *p_, hipStream_t s_) : p(p_), s(s_)
+    KernelTimer(SpmvPlan *p_, hipStream_t s_, int chan = 0) : p(p_), s(s_)
     {
         if (p->profiling && p->ev_used + 2 <= (int)p->ev.size()) {
             slot = p->ev_used;
             p->ev_used += 2;
+            p->ev_chan[slot / 2] = chan;
             (void)hipEventRecord(p->ev[slot], s);
         }
     }
@@ -362,9 +366,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
 // stays in each XCD's 4 MiB L2.  Needs ascending columns inside heavy rows (checked at plan time;
 // otherwise the split is disabled).  One wavefront per piece, partials summed per row in column
 // order by a second kernel: deterministic.
-constexpr int HEAVY_MIN = 2048;
-constexpr int HEAVY_BLOCK = 131072;
-constexpr int HEAVY_PIECE = 1024;
+// defaults; CSRK_HEAVY_MIN / CSRK_HEAVY_BLOCK / CSRK_HEAVY_PIECE override them at plan time (tuning)
+static int HEAVY_MIN = 2048;
+static int HEAVY_BLOCK = 131072;
+static int HEAVY_PIECE = 1024;
 
 struct HeavyPiece {
     int64_t start;     // first entry (index into colinds/values)
@@ -375,7 +380,7 @@ struct HeavyPiece {
 
 template <class P>
 __global__ void heavy_flag_kernel(const P *__restrict__ rp, int32_t nrows, int32_t *__restrict__ flag,
-                                  int64_t *__restrict__ hlen)
+                                  int64_t *__restrict__ hlen, int HEAVY_MIN)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nrows) return;
@@ -429,11 +434,23 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t *__restrict__ c
     return lo;
 }
 
+// Processing order of the pieces.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+// labels the XCD group; a speed assumption only, never correctness), and each XCD has its own L2, so
+// column block b is given to XCD group b % 8: stream g holds the blocks b = g, g + 8, ... in
+// ascending order, rows ascending inside a block.  Each x window is then loaded into ONE L2, not 8.
+constexpr int HEAVY_STREAMS = 8;
+__host__ __device__ __forceinline__ int64_t heavy_order_index(int32_t b, int32_t c, int32_t n_heavy, int32_t n_blocks)
+{
+    const int64_t per_stream = (n_blocks + HEAVY_STREAMS - 1) / HEAVY_STREAMS;
+    return (((int64_t)(b % HEAVY_STREAMS)) * per_stream + b / HEAVY_STREAMS) * n_heavy + c;
+}
+
 // one thread per (heavy row c, column block b): number of pieces, in both orders
 template <class P>
 __global__ void heavy_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int64_t *__restrict__ cnt_bh, int64_t *__restrict__ cnt_hb)
+                                   int64_t *__restrict__ cnt_bh, int64_t *__restrict__ cnt_hb, int HEAVY_BLOCK,
+                                   int HEAVY_PIECE)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -443,7 +460,7 @@ __global__ void heavy_count_kernel(const P *__restrict__ rp, const int32_t *__re
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
     const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
     const int64_t n = (hi - lo + HEAVY_PIECE - 1) / HEAVY_PIECE;
-    cnt_bh[(int64_t)b * n_heavy + c] = n;
+    cnt_bh[heavy_order_index(b, c, n_heavy, n_blocks)] = n;
     cnt_hb[i] = n;
 }
 
@@ -451,7 +468,8 @@ template <class P>
 __global__ void heavy_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
                                   const int64_t *__restrict__ off_bh, const int64_t *__restrict__ off_hb,
-                                  HeavyPiece *__restrict__ piece, int64_t *__restrict__ part_off)
+                                  HeavyPiece *__restrict__ piece, int64_t *__restrict__ part_off, int HEAVY_BLOCK,
+                                  int HEAVY_PIECE)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -460,7 +478,7 @@ __global__ void heavy_fill_kernel(const P *__restrict__ rp, const int32_t *__res
     const int64_t s = rp[r], e = rp[r + 1];
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
     const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
-    int64_t pos = off_bh[(int64_t)b * n_heavy + c], slot = off_hb[i];
+    int64_t pos = off_bh[heavy_order_index(b, c, n_heavy, n_blocks)], slot = off_hb[i];
     if (b == 0) part_off[c] = slot;
     if (i == (int64_t)n_heavy * n_blocks - 1) part_off[n_heavy] = off_hb[i + 1];
     for (int64_t k = lo; k < hi; k += HEAVY_PIECE) {
@@ -493,15 +511,21 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
     tile_cut[t] = lo;
 }
 
+struct HeavyStreams {
+    int64_t off[HEAVY_STREAMS + 1];   // piece range of each XCD stream
+};
+
 template <int VT>
 __global__ __launch_bounds__(256) void spmv_heavy_kernel(const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                                         const double *__restrict__ x,
-                                                        const HeavyPiece *__restrict__ piece, int64_t n_pieces,
+                                                        const HeavyPiece *__restrict__ piece, HeavyStreams st,
                                                         double *__restrict__ part)
 {
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    // workgroup w serves stream w % 8 (its XCD group) and takes that stream's next 4 pieces
+    const int g = blockIdx.x % HEAVY_STREAMS;
+    const int64_t q = st.off[g] + (int64_t)(blockIdx.x / HEAVY_STREAMS) * (256 / WAVE) + threadIdx.x / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
-    if (q >= n_pieces) return;
+    if (q >= st.off[g + 1]) return;
     const HeavyPiece pc = piece[q];
     const int64_t s = pc.start;
     const int n = pc.len;
@@ -642,14 +666,18 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
 {
     p->n_heavy = 0;
     const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
-    if ((env && env[0] == '0') || !g_heavy_split || m->nrows == 0 || m->nnz < HEAVY_MIN) return CSRK_OK;
+    if ((env && env[0] == '0') || !g_heavy_split) return CSRK_OK;
+    if (const char *e = getenv("CSRK_HEAVY_MIN")) HEAVY_MIN = atoi(e) > 64 ? atoi(e) : 64;
+    if (const char *e = getenv("CSRK_HEAVY_BLOCK")) HEAVY_BLOCK = atoi(e) > 1024 ? atoi(e) : 1024;
+    if (const char *e = getenv("CSRK_HEAVY_PIECE")) HEAVY_PIECE = atoi(e) > 64 ? atoi(e) : 64;
+    if (m->nrows == 0 || m->nnz < HEAVY_MIN) return CSRK_OK;
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nr = m->nrows;
     const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);
     DevBuf flag, hlen, bad;
     CSRK_TRY(flag.alloc((size_t)(nr + 2) * 4));
     CSRK_TRY(hlen.alloc((size_t)(nr + 2) * 8));
-    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>());
+    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), HEAVY_MIN);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i32(flag.as<int32_t>(), flag.as<int32_t>(), nr, s));      // -> heavy index
     CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> heavy nnz before
@@ -681,24 +709,33 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
     if (is_bad) return CSRK_OK;      // unsorted columns in a heavy row: column blocking needs order
 
     const int64_t pairs = (int64_t)n_heavy * n_blocks;
+    const int64_t per_stream = ceil_div(n_blocks, HEAVY_STREAMS);
+    const int64_t slots = HEAVY_STREAMS * per_stream * n_heavy;     // >= pairs; padding slots count 0
     DevBuf c_bh, c_hb;
-    CSRK_TRY(c_bh.alloc((size_t)(pairs + 1) * 8));
+    CSRK_TRY(c_bh.alloc((size_t)(slots + 1) * 8));
     CSRK_TRY(c_hb.alloc((size_t)(pairs + 1) * 8));
+    CSRK_HIP(hipMemsetAsync(c_bh.p, 0, (size_t)(slots + 1) * 8, s));
     const unsigned g2 = (unsigned)ceil_div(pairs, 256);
     heavy_count_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
-                                           c_bh.as<int64_t>(), c_hb.as<int64_t>());
+                                           c_bh.as<int64_t>(), c_hb.as<int64_t>(), HEAVY_BLOCK, HEAVY_PIECE);
     CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(c_bh.as<int64_t>(), c_bh.as<int64_t>(), pairs, s));
+    CSRK_TRY(exclusive_scan_i64(c_bh.as<int64_t>(), c_bh.as<int64_t>(), slots, s));
     CSRK_TRY(exclusive_scan_i64(c_hb.as<int64_t>(), c_hb.as<int64_t>(), pairs, s));
-    int64_t n_pieces = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_pieces, c_bh.as<int64_t>() + pairs, 8, hipMemcpyDeviceToHost, s));
+    for (int g = 0; g <= HEAVY_STREAMS; g++)
+        CSRK_HIP(hipMemcpyAsync(&p->stream_off[g], c_bh.as<int64_t>() + (int64_t)g * per_stream * n_heavy, 8,
+                                hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
+    const int64_t n_pieces = p->stream_off[HEAVY_STREAMS];
+    int64_t longest = 0;
+    for (int g = 0; g < HEAVY_STREAMS; g++)
+        longest = longest > p->stream_off[g + 1] - p->stream_off[g] ? longest : p->stream_off[g + 1] - p->stream_off[g];
+    p->heavy_grid = HEAVY_STREAMS * ceil_div(longest, 256 / WAVE);
     CSRK_TRY(p->piece.alloc((size_t)n_pieces * sizeof(HeavyPiece)));
     CSRK_TRY(p->part.alloc((size_t)n_pieces * 8));
     CSRK_TRY(p->part_off.alloc((size_t)(n_heavy + 1) * 8));
     heavy_fill_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
                                           c_bh.as<int64_t>(), c_hb.as<int64_t>(), p->piece.as<HeavyPiece>(),
-                                          p->part_off.as<int64_t>());
+                                          p->part_off.as<int64_t>(), HEAVY_BLOCK, HEAVY_PIECE);
     CSRK_LAUNCH_CHECK();
     CSRK_HIP(hipStreamSynchronize(s));
     p->n_heavy = n_heavy;
@@ -796,8 +833,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
         CSRK_LAUNCH_CHECK();
         if (p->n_heavy) {
-            spmv_heavy_kernel<VT><<<(unsigned)ceil_div(p->n_pieces * WAVE, 256), 256, 0, s>>>(
-                m->d_colinds, m->d_values, d_x, p->piece.as<HeavyPiece>(), p->n_pieces, p->part.as<double>());
+            HeavyStreams st;
+            for (int g = 0; g <= HEAVY_STREAMS; g++) st.off[g] = p->stream_off[g];
+            KernelTimer kh(p, s, 1);
+            spmv_heavy_kernel<VT><<<(unsigned)p->heavy_grid, 256, 0, s>>>(
+                m->d_colinds, m->d_values, d_x, p->piece.as<HeavyPiece>(), st, p->part.as<double>());
+            kh.stop();
             CSRK_LAUNCH_CHECK();
             spmv_heavy_reduce_kernel<<<(unsigned)ceil_div((int64_t)p->n_heavy * WAVE, 256), 256, 0, s>>>(
                 p->heavy_row.as<int32_t>(), p->part_off.as<int64_t>(), p->n_heavy, p->part.as<double>(), d_y);
@@ -925,11 +966,12 @@ int csrk_spmv_profile_begin(csrk_handle_t h, int max_records)
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
     std::lock_guard<std::mutex> lk(m->mu);
-    while ((int)p->ev.size() < 2 * max_records) {
+    while ((int)p->ev.size() < 4 * max_records) {      // two timed kernels per launch
         hipEvent_t e;
         CSRK_HIP(hipEventCreate(&e));
         p->ev.push_back(e);
     }
+    p->ev_chan.assign(p->ev.size() / 2, 0);
     p->ev_used = 0;
     p->profiling = true;
     return CSRK_OK;
@@ -944,17 +986,35 @@ int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
     SpmvPlan *p = m->spmv_plan;
     CSRK_REQUIRE(p && p->profiling, "profiling was not started on this handle");
     p->profiling = false;
-    double tot = 0.0;
+    double tot[2] = {0.0, 0.0};
+    int cnt[2] = {0, 0};
     int n = p->ev_used / 2;
     for (int i = 0; i < n; i++) {
         float ms = 0.f;
         CSRK_HIP(hipEventSynchronize(p->ev[2 * i + 1]));
         CSRK_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
-        tot += ms;
+        tot[p->ev_chan[i]] += ms;
+        cnt[p->ev_chan[i]]++;
     }
-    *n_records = n;
-    *mean_ms = n ? (float)(tot / n) : 0.f;
+    *n_records = cnt[0];
+    mean_ms[0] = cnt[0] ? (float)(tot[0] / cnt[0]) : 0.f;
+    mean_ms[1] = cnt[1] ? (float)(tot[1] / cnt[1]) : 0.f;
     p->ev_used = 0;
+    return CSRK_OK;
+}
+
+int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(out && n >= 0, "out is NULL");
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));
+    const int64_t v[8] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+                          p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
+                          p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
+                          p->n_pieces, p->n_blocks, HEAVY_MIN, HEAVY_BLOCK};
+    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

@@ -112,11 +112,16 @@ CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);
 /* Launch geometry of the dominant SpMV kernel (for roofline accounting in bench.py). */
 CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items);
 
+/* out[0..n) <- {tiles (or segments), items per tile, heavy rows, entries on the tile path,
+ * heavy pieces, column blocks, heavy-row threshold, column-block width}; n <= 8. */
+CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
+
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
- * this handle brackets its DOMINANT kernel (the tile / segment / row kernel, not the carry
- * fix-up) with a hipEvent pair recorded on the launch stream; nothing synchronises until
- * csrk_spmv_profile_end, which returns the number of recorded launches and their mean
- * duration in milliseconds.  At most `max_records` launches are recorded. */
+ * this handle brackets its two streaming kernels -- [0] the tile / segment / row kernel and
+ * [1] the heavy-row kernel (merge algorithm only) -- with hipEvent pairs recorded on the launch
+ * stream; nothing synchronises until csrk_spmv_profile_end, which returns the number of recorded
+ * launches and mean_ms[2], their mean durations in milliseconds (0 if a kernel did not run).
+ * At most `max_records` launches are recorded. */
 CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
 CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);
 
