@@ -76,6 +76,13 @@ struct SpmvPlan {
     DevBuf part;        // double[n_pieces]
     int64_t stream_off[9] = {0};   // piece range of each XCD stream
     int64_t heavy_grid = 0;
+    // heavy rows, panel form
+    bool panel = false;
+    bool panel64 = false;          // M' row pointers are int64
+    int32_t panel_blocks = 0;
+    int64_t panel_rows = 0, panel_tiles = 0, panel_nnz = 0;
+    DevBuf p_rp, p_ci, p_vs, p_tiles, p_groups, p_carry_row, p_carry_val, p_y, p_tmp;
+    int64_t panel_groups = 0;
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -182,7 +189,45 @@ __device__ __forceinline__ void load_val_pair(const void *vs, int64_t k, bool tw
     }
 }
 
+// Branch-free tile loads.  hipcc turns `if (k < nn) v = p[k];` inside an unrolled loop into a branch
+// around each load followed by s_waitcnt vmcnt(0), which serialises the loads (one memory round trip
+// per element).  These helpers always load -- from an address clamped into the array -- and mask
+// afterwards, so all of a lane's loads are in flight together.  `last_pair` = n_total - 2 (the last
+// index at which a 2-entry load is in bounds; requires n_total >= 2).  A lane whose pair would start
+// at the array's final entry loads the pair one entry earlier and takes its second half.
+template <int VT>
+__device__ __forceinline__ void load_pair_clamped(const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                  int64_t a, int64_t tile_first, int nn, int64_t last_pair,
+                                                  int32_t &c0, int32_t &c1, double &v0, double &v1)
+{
+    // Lanes past the tile's end re-read the tile's own last pair (same cache lines as their
+    // neighbours: no extra traffic, and their x gather is the neighbours' address); the tile's final
+    // odd entry is taken from the second half of the pair that starts one entry earlier.
+    int64_t q = tile_first + (nn >= 2 ? nn - 2 : 0);
+    q = a < q ? a : q;
+    q = q < last_pair ? q : last_pair;
+    q = q > 0 ? q : 0;
+    const bool second = q != a;
+    const i32x2_t cc = __builtin_nontemporal_load((const I32x2 *)(ci + q));
+    c0 = second ? cc.y : cc.x;
+    c1 = cc.y;
+    if (VT == CSRK_VAL_F64) {
+        const f64x2_t t = __builtin_nontemporal_load((const F64x2 *)((const double *)vs + q));
+        v0 = second ? t.y : t.x;
+        v1 = t.y;
+    } else if (VT == CSRK_VAL_F32) {
+        const f32x2_t t = *(const F32x2 *)((const float *)vs + q);
+        v0 = second ? t.y : t.x;
+        v1 = t.y;
+    } else {
+        v0 = v1 = 1.0;
+    }
+}
+
 constexpr int MERGE_PAIRS = MERGE_IPT / 2;
+#ifndef MERGE_GATHER_PAIRS
+#define MERGE_GATHER_PAIRS 4
+#endif
 
 // HEAVY: the path runs over the light view (rp = rp_light, nnz = nnz_light); a light entry index
 // jl maps to the actual entry jl + cut_cum[#cuts with cut_pos <= jl].
@@ -192,7 +237,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
     int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
     const int32_t *__restrict__ tile_cut, const int64_t *__restrict__ cut_pos,
-    const int64_t *__restrict__ cut_cum)
+    const int64_t *__restrict__ cut_cum, int64_t nnz_total)
 {
     // One LDS buffer: nn products (8 B each) followed by nr + 1 tile-relative row ends (4 B each);
     // nn + nr <= MERGE_ITEMS, so MERGE_ITEMS * 8 + 8 bytes always suffice (16.4 KB -> 8 tiles per CU).
@@ -222,27 +267,24 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     }
 
     // phase 1a: products.  Lane owns the consecutive pair (2q, 2q+1), q = tid + u*THREADS; all
-    // colind loads are issued before the dependent x gathers.
+    // colind / value / row-end loads are issued before the dependent x gathers.
     int32_t c0[MERGE_PAIRS], c1[MERGE_PAIRS];
     double p0[MERGE_PAIRS], p1[MERGE_PAIRS];
+    constexpr int RPT = MERGE_ITEMS / MERGE_THREADS;
+    int32_t rv[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        const int r = tid + u * MERGE_THREADS;
+        const int rc = r < nr ? r : (nr > 0 ? nr - 1 : 0);       // clamped: always a valid row pointer
+        rv[u] = (int32_t)((int64_t)rp[i0 + rc + 1] - j0);
+    }
     if (!HEAVY || cb == ce) {
 #pragma unroll
         for (int u = 0; u < MERGE_PAIRS; u++) {
             const int k = 2 * (tid + u * MERGE_THREADS);
-            c0[u] = c1[u] = 0;
-            if (k + 1 < nn) {
-                i32x2_t cc = __builtin_nontemporal_load((const I32x2 *)(ci + ja + k));
-                c0[u] = cc.x;
-                c1[u] = cc.y;
-            } else if (k < nn) {
-                c0[u] = ci[ja + k];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < MERGE_PAIRS; u++) {
-            const int k = 2 * (tid + u * MERGE_THREADS);
-            p0[u] = p1[u] = 0.0;
-            if (k < nn) load_val_pair<VT>(vs, ja + k, k + 1 < nn, p0[u], p1[u]);
+            load_pair_clamped<VT>(ci, vs, ja + k, ja, nn, nnz_total - 2, c0[u], c1[u], p0[u], p1[u]);
+            p0[u] = k < nn ? p0[u] : 0.0;
+            p1[u] = k + 1 < nn ? p1[u] : 0.0;
         }
     } else {
         // a heavy row was cut out somewhere inside this tile: per-entry shift (rare tiles)
@@ -277,11 +319,14 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
             }
         }
     }
+    // x gathers, MERGE_GATHER_PAIRS pairs (2 gathers each) in flight per lane at a time: with all 8
+    // in flight a wavefront has 512 lines outstanding, twice the 256-line L1, and the popular x
+    // entries that would hit in L1 are evicted between uses (measured: tools/probe notes in DESIGN.md).
 #pragma unroll
     for (int u = 0; u < MERGE_PAIRS; u++) {
-        const int k = 2 * (tid + u * MERGE_THREADS);
-        if (k < nn) p0[u] *= x[c0[u]];
-        if (k + 1 < nn) p1[u] *= x[c1[u]];
+        p0[u] *= x[c0[u]];        // masked entries hold a valid column and a zero value
+        p1[u] *= x[c1[u]];
+        if ((u + 1) % MERGE_GATHER_PAIRS == 0 && u + 1 < MERGE_PAIRS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     if (nr == 0) {
@@ -313,7 +358,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
         if (k + 1 < nn) s_prod[k + 1] = p1[u];
     }
     // phase 1b: tile-relative row ends; the tail segment (row i1, not completed here) ends at nn
-    for (int r = tid; r < nr; r += MERGE_THREADS) s_rend[r] = (int32_t)((int64_t)rp[i0 + r + 1] - j0);
+#pragma unroll
+    for (int u = 0; u < RPT; u++) {
+        const int r = tid + u * MERGE_THREADS;
+        if (r < nr) s_rend[r] = rv[u];
+    }
     if (tid == 0) s_rend[nr] = nn;
     __syncthreads();
 
@@ -563,6 +612,308 @@ __global__ __launch_bounds__(256) void spmv_heavy_reduce_kernel(const int32_t *_
     if (lane == 0) y[heavy_row[c]] = acc;
 }
 
+
+// ---- heavy rows, panel form: x window in LDS ---------------------------------------------------
+// PMC on the piece kernel above: 88 % of its L2 accesses hit, yet it runs at the chip's L1-miss
+// request rate (~150-170 G 64-B requests/s): every gather is its own L2 round trip.  The panel form
+// removes the gathers.  At plan time the heavy rows' entries are re-sorted column-block-major into a
+// panel matrix M' whose rows are (column block b, heavy row h) pairs, blocks of PANEL_CB columns
+// (32 KiB of x); values are widened to float64.  Per call the merge-tile algorithm runs over M' with
+// tiles confined to one block: the workgroup first copies the block's x window into LDS with
+// coalesced loads (512 requests instead of 2048 gathers per tile), then multiplies from LDS.  Row
+// sums of M' are the per-(block, row) partials y'[b][h]; they are reduced over b in block order by
+// panel_reduce kernels.  Still no float atomics: deterministic.
+constexpr int PANEL_CB = 4096;
+
+template <class P>
+__global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
+                                   int64_t *__restrict__ cnt)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_heavy * n_blocks) return;
+    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);      // index = b * H + c
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * PANEL_CB);
+    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * PANEL_CB);
+    cnt[i] = hi - lo;
+}
+
+template <class P, int VT, class PP>
+__global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                  const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
+                                  const int64_t *__restrict__ off, PP *__restrict__ prp, int32_t *__restrict__ pci,
+                                  double *__restrict__ pvs)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pairs = (int64_t)n_heavy * n_blocks;
+    if (i > pairs) return;
+    prp[i] = (PP)off[i];
+    if (i == pairs) return;
+    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * PANEL_CB);
+    const int64_t n = off[i + 1] - off[i];
+    int64_t o = off[i];
+    for (int64_t k = lo; k < lo + n; k++, o++) {
+        pci[o] = ci[k];
+        pvs[o] = ValLoad<VT>::at(vs, k);
+    }
+}
+
+struct PanelTile {
+    int64_t j0;      // first entry of the tile in M'
+    int32_t i0, i1;  // rows of M' completed before the tile start / end
+    int32_t nn;      // entries in the tile
+    int32_t blk;     // column block
+};
+
+// one thread per tile: merge-path coordinates inside the tile's block
+template <class PP>
+__global__ void panel_plan_kernel(const PP *__restrict__ prp, int32_t n_heavy, int32_t n_blocks,
+                                  const int64_t *__restrict__ blk_tile0, int64_t n_tiles, int items,
+                                  PanelTile *__restrict__ tiles)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int32_t lo = 0, hi = n_blocks;                 // block with blk_tile0[b] <= t < blk_tile0[b+1]
+    while (hi - lo > 1) {
+        int32_t mid = (lo + hi) >> 1;
+        if (blk_tile0[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int32_t b = lo;
+    const int64_t r0 = (int64_t)b * n_heavy;                    // first row of the block in M'
+    const int64_t e0 = (int64_t)prp[r0], e1 = (int64_t)prp[r0 + n_heavy];
+    const int64_t total = (int64_t)n_heavy + (e1 - e0);
+    const int64_t lt = t - blk_tile0[b];
+    int64_t coord[2];
+    for (int q = 0; q < 2; q++) {
+        int64_t d = (lt + q) * items;
+        if (d > total) d = total;
+        int64_t a = d - (e1 - e0) > 0 ? d - (e1 - e0) : 0, z = d < n_heavy ? d : n_heavy;
+        while (a < z) {
+            int64_t mid = (a + z) >> 1;
+            if ((int64_t)prp[r0 + mid + 1] - e0 <= d - mid - 1)
+                a = mid + 1;
+            else
+                z = mid;
+        }
+        coord[q] = a;                                           // rows of the block consumed before d
+    }
+    int64_t d0 = lt * items, d1 = (lt + 1) * items;
+    if (d0 > total) d0 = total;
+    if (d1 > total) d1 = total;
+    PanelTile pt;
+    pt.i0 = (int32_t)(r0 + coord[0]);
+    pt.i1 = (int32_t)(r0 + coord[1]);
+    pt.j0 = e0 + (d0 - coord[0]);
+    pt.nn = (int32_t)((d1 - coord[1]) - (d0 - coord[0]));
+    pt.blk = b;
+    tiles[t] = pt;
+}
+
+struct PanelGroup {
+    int64_t t0;      // first tile
+    int32_t nt;      // tiles handled by this workgroup (all in one column block)
+    int32_t blk;
+};
+constexpr int PANEL_TPW = 8;     // tiles per workgroup: the x window is copied once per group
+
+template <class PP>
+__global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
+    const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
+    const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
+    const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
+    double *__restrict__ carry_val, int64_t pnnz)
+{
+    __shared__ double s_x[PANEL_CB];
+    __shared__ double s_buf[MERGE_ITEMS + 1];
+    __shared__ int32_t s_long[MERGE_MAXLONG];
+    __shared__ int32_t s_nlong;
+    __shared__ double s_wpart[MERGE_THREADS / WAVE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const PanelGroup grp = groups[blockIdx.x];
+    const int32_t w0 = grp.blk * PANEL_CB;
+
+    // the block's x window -> LDS, coalesced 16-B loads, all in flight before the first store
+    {
+        const int wlen = ncols - w0 < PANEL_CB ? ncols - w0 : PANEL_CB;
+        const f64x2_t *src = (const f64x2_t *)(x + w0);
+        if (wlen == PANEL_CB) {
+            f64x2_t v[PANEL_CB / 2 / MERGE_THREADS];
+#pragma unroll
+            for (int u = 0; u < PANEL_CB / 2 / MERGE_THREADS; u++) v[u] = src[tid + u * MERGE_THREADS];
+#pragma unroll
+            for (int u = 0; u < PANEL_CB / 2 / MERGE_THREADS; u++) ((f64x2_t *)s_x)[tid + u * MERGE_THREADS] = v[u];
+        } else {
+            for (int k = tid; k < wlen; k += MERGE_THREADS) s_x[k] = x[w0 + k];
+        }
+    }
+
+    // Software pipeline over the group's tiles: the entries (and row ends) of tile it+1 are loaded
+    // into registers while tile it is reduced out of LDS, so one global-load latency is exposed per
+    // group instead of two per tile.
+    constexpr int RPT = MERGE_ITEMS / MERGE_THREADS;     // row ends a lane may have to fetch
+    int32_t c0[MERGE_PAIRS], c1[MERGE_PAIRS], rv[RPT];
+    double p0[MERGE_PAIRS], p1[MERGE_PAIRS];
+    PanelTile pt = tiles[grp.t0];
+
+#define PANEL_LOAD_TILE(T)                                                                            \
+    {                                                                                                 \
+        const int64_t j0_ = (T).j0;                                                                   \
+        const int nn_ = (T).nn, nr_ = (T).i1 - (T).i0;                                                \
+        _Pragma("unroll") for (int u = 0; u < MERGE_PAIRS; u++)                                       \
+        {                                                                                             \
+            const int k = 2 * (tid + u * MERGE_THREADS);                                              \
+            load_pair_clamped<CSRK_VAL_F64>(pci, pvs, j0_ + k, j0_, nn_, pnnz - 2, c0[u], c1[u], p0[u], p1[u]); \
+            p0[u] = k < nn_ ? p0[u] : 0.0;                                                            \
+            p1[u] = k + 1 < nn_ ? p1[u] : 0.0;                                                        \
+            c0[u] = k < nn_ ? c0[u] : w0;                                                             \
+            c1[u] = k + 1 < nn_ ? c1[u] : w0;                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < RPT; u++)                                               \
+        {                                                                                             \
+            const int r = tid + u * MERGE_THREADS;                                                    \
+            const int rc = r < nr_ ? r : (nr_ > 0 ? nr_ - 1 : 0);                                     \
+            rv[u] = (int32_t)((int64_t)prp[(T).i0 + rc + 1] - j0_);                                   \
+        }                                                                                             \
+    }
+
+    PANEL_LOAD_TILE(pt);
+    for (int it = 0; it < grp.nt; it++) {
+        const int64_t t = grp.t0 + it;
+        const int32_t i0 = pt.i0, i1 = pt.i1;
+        const int nn = pt.nn;
+        const int nr = i1 - i0;
+        PanelTile nx = pt;
+        const bool more = it + 1 < grp.nt;
+        if (more) nx = tiles[t + 1];
+
+        __syncthreads();      // window visible (first pass); previous tile's LDS reads finished
+#pragma unroll
+        for (int u = 0; u < MERGE_PAIRS; u++) {
+            const int k = 2 * (tid + u * MERGE_THREADS);
+            p0[u] *= s_x[c0[u] - w0];
+            p1[u] *= s_x[c1[u] - w0];
+        }
+
+        if (nr == 0) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < MERGE_PAIRS; u++) acc += p0[u] + p1[u];
+            if (more) PANEL_LOAD_TILE(nx);
+            acc = wave_sum(acc);
+            if (lane == 0) s_wpart[wv] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = s_wpart[0];
+#pragma unroll
+                for (int w = 1; w < MERGE_THREADS / WAVE; w++) tot += s_wpart[w];
+                carry_row[t] = i1 < n_prows ? i1 : -1;
+                carry_val[t] = tot;
+            }
+            pt = nx;
+            continue;         // the barrier at the top of the next pass orders the s_wpart reuse
+        }
+
+        double *s_prod = s_buf;
+        int32_t *s_rend = (int32_t *)(s_buf + nn);
+        if (tid == 0) s_nlong = 0;
+#pragma unroll
+        for (int u = 0; u < MERGE_PAIRS; u++) {
+            const int k = 2 * (tid + u * MERGE_THREADS);
+            if (k < nn) s_prod[k] = p0[u];
+            if (k + 1 < nn) s_prod[k + 1] = p1[u];
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+            const int r = tid + u * MERGE_THREADS;
+            if (r < nr) s_rend[r] = rv[u];
+        }
+        if (tid == 0) s_rend[nr] = nn;
+        if (more) PANEL_LOAD_TILE(nx);       // registers are free again: next tile's loads in flight
+        __syncthreads();
+
+        for (int r = tid; r <= nr; r += MERGE_THREADS) {
+            int s = r ? s_rend[r - 1] : 0;
+            int e = s_rend[r];
+            if (e - s >= MERGE_LONG) {
+                int q = atomicAdd(&s_nlong, 1);
+                s_long[q] = r;
+                continue;
+            }
+            double acc = 0.0;
+            for (int k = s; k < e; k++) acc += s_prod[k];
+            if (r < nr) {
+                yp[i0 + r] = acc;
+            } else {
+                carry_row[t] = i1 < n_prows ? i1 : -1;
+                carry_val[t] = acc;
+            }
+        }
+        __syncthreads();
+        const int nlong = s_nlong;
+        for (int q = wv; q < nlong; q += MERGE_THREADS / WAVE) {
+            int r = s_long[q];
+            int s = r ? s_rend[r - 1] : 0;
+            int e = s_rend[r];
+            double acc = 0.0;
+            for (int k = s + lane; k < e; k += WAVE) acc += s_prod[k];
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                if (r < nr) {
+                    yp[i0 + r] = acc;
+                } else {
+                    carry_row[t] = i1 < n_prows ? i1 : -1;
+                    carry_val[t] = acc;
+                }
+            }
+        }
+        pt = nx;
+    }
+#undef PANEL_LOAD_TILE
+}
+
+// y'[b][h] -> chunk sums over b (lane = heavy row: coalesced), then -> y[heavy_row[h]] in chunk order
+constexpr int PANEL_RCHUNKS = 32;
+__global__ __launch_bounds__(256) void panel_reduce1_kernel(const double *__restrict__ yp, int32_t n_heavy,
+                                                           int32_t n_blocks, double *__restrict__ tmp)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (h >= n_heavy) return;
+    const int per = (n_blocks + PANEL_RCHUNKS - 1) / PANEL_RCHUNKS;
+    const int b0 = ch * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    double acc = 0.0;
+    for (int b = b0; b < b1; b++) acc += yp[(int64_t)b * n_heavy + h];
+    tmp[(int64_t)ch * n_heavy + h] = acc;
+}
+
+__global__ __launch_bounds__(256) void panel_reduce2_kernel(const double *__restrict__ tmp, int32_t n_heavy,
+                                                           const int32_t *__restrict__ heavy_row, double *__restrict__ y)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_heavy) return;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int ch = 0; ch < PANEL_RCHUNKS; ch++) acc += tmp[(int64_t)ch * n_heavy + h];
+    y[heavy_row[h]] = acc;
+}
+
+__global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
+                                       int64_t *__restrict__ out)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= n_blocks) out[b] = off[(int64_t)b * n_heavy];
+}
+
 // One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
 // in tile order, onto the y entry written by the tile that completed the row.
 __global__ __launch_bounds__(256) void spmv_merge_fixup_kernel(const int32_t *__restrict__ carry_row,
@@ -660,6 +1011,80 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
 // ---- host side ----------------------------------------------------------------------------------
 static int g_heavy_split = 1;   // CSRK_SPMV_HEAVY_SPLIT=0 disables the heavy-row path (A/B runs)
 
+// Panel form of the heavy rows: M' (column-block-major copy, float64 values) + its tile list.
+template <class P, int VT>
+static int build_panel(Matrix *m, SpmvPlan *p, int32_t n_heavy, int32_t nb, int64_t nnz_heavy, hipStream_t s)
+{
+    const P *rp = (const P *)m->d_rowptrs;
+    const int64_t pairs = (int64_t)n_heavy * nb;
+    DevBuf off, bends;
+    CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
+    const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
+    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, nb, off.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
+    p->panel64 = nnz_heavy > INT32_MAX;
+    CSRK_TRY(p->p_rp.alloc((size_t)(pairs + 1) * (p->panel64 ? 8 : 4)));
+    CSRK_TRY(p->p_ci.alloc((size_t)nnz_heavy * 4));
+    CSRK_TRY(p->p_vs.alloc((size_t)nnz_heavy * 8));
+    if (p->panel64)
+        panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, p->heavy_row.as<int32_t>(), n_heavy,
+                                                          nb, off.as<int64_t>(), p->p_rp.as<int64_t>(),
+                                                          p->p_ci.as<int32_t>(), p->p_vs.as<double>());
+    else
+        panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, p->heavy_row.as<int32_t>(), n_heavy,
+                                                          nb, off.as<int64_t>(), p->p_rp.as<int32_t>(),
+                                                          p->p_ci.as<int32_t>(), p->p_vs.as<double>());
+    CSRK_LAUNCH_CHECK();
+    // tiles per block (host: nb is a few thousand)
+    CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
+    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n_heavy, nb, bends.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
+    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    t0[0] = 0;
+    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n_heavy + be[b + 1] - be[b], MERGE_ITEMS);
+    const int64_t n_tiles = t0[nb];
+    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(p->p_tiles.alloc((size_t)n_tiles * sizeof(PanelTile)));
+    if (p->panel64)
+        panel_plan_kernel<int64_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
+            p->p_rp.as<int64_t>(), n_heavy, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, p->p_tiles.as<PanelTile>());
+    else
+        panel_plan_kernel<int32_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
+            p->p_rp.as<int32_t>(), n_heavy, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, p->p_tiles.as<PanelTile>());
+    CSRK_LAUNCH_CHECK();
+    {
+        int tpw = PANEL_TPW;
+        if (const char *e = getenv("CSRK_PANEL_TPW")) tpw = atoi(e) > 0 ? atoi(e) : PANEL_TPW;
+        std::vector<PanelGroup> groups;
+        for (int32_t b = 0; b < nb; b++)
+            for (int64_t t = t0[b]; t < t0[b + 1]; t += tpw) {
+                PanelGroup gq;
+                gq.t0 = t;
+                gq.nt = (int32_t)(t0[b + 1] - t < tpw ? t0[b + 1] - t : tpw);
+                gq.blk = b;
+                groups.push_back(gq);
+            }
+        p->panel_groups = (int64_t)groups.size();
+        CSRK_TRY(p->p_groups.alloc(groups.size() * sizeof(PanelGroup)));
+        CSRK_HIP(hipMemcpyAsync(p->p_groups.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+    }
+    CSRK_TRY(p->p_carry_row.alloc((size_t)n_tiles * 4));
+    CSRK_TRY(p->p_carry_val.alloc((size_t)n_tiles * 8));
+    CSRK_TRY(p->p_y.alloc((size_t)pairs * 8));
+    CSRK_TRY(p->p_tmp.alloc((size_t)PANEL_RCHUNKS * n_heavy * 8));
+    CSRK_HIP(hipStreamSynchronize(s));
+    p->panel = true;
+    p->panel_blocks = nb;
+    p->panel_rows = pairs;
+    p->panel_tiles = n_tiles;
+    p->panel_nnz = nnz_heavy;
+    return CSRK_OK;
+}
+
 // Cut the heavy rows out of the merge path and build their column-blocked piece list.
 template <class P>
 static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
@@ -707,6 +1132,20 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_HIP(hipMemcpyAsync(&is_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
     if (is_bad) return CSRK_OK;      // unsorted columns in a heavy row: column blocking needs order
+
+    const char *mode = getenv("CSRK_SPMV_HEAVY_MODE");
+    const int32_t pnb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB);
+    if (!(mode && mode[0] == 'p' && mode[1] == 'i') && (int64_t)n_heavy * pnb <= (256ll << 20)) {
+        int rc;
+        if (m->val_type == CSRK_VAL_F64) rc = build_panel<P, CSRK_VAL_F64>(m, p, n_heavy, pnb, nnz_heavy, s);
+        else if (m->val_type == CSRK_VAL_F32) rc = build_panel<P, CSRK_VAL_F32>(m, p, n_heavy, pnb, nnz_heavy, s);
+        else rc = build_panel<P, CSRK_VAL_NONE>(m, p, n_heavy, pnb, nnz_heavy, s);
+        if (rc != CSRK_OK) return rc;
+        p->n_heavy = n_heavy;
+        p->n_blocks = pnb;
+        p->nnz_light = m->nnz - nnz_heavy;
+        return CSRK_OK;
+    }
 
     const int64_t pairs = (int64_t)n_heavy * n_blocks;
     const int64_t per_stream = ceil_div(n_blocks, HEAVY_STREAMS);
@@ -815,24 +1254,49 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 {
     const P *rp = (const P *)m->d_rowptrs;
     if (m->nrows == 0) return CSRK_OK;
-    switch (p->algo) {
+    int algo = p->algo;
+    if (algo == CSRK_SPMV_MERGE && m->nnz < 2) algo = CSRK_SPMV_SCALAR;   // the tile kernel's pair loads need >= 2 entries
+    switch (algo) {
     case CSRK_SPMV_MERGE: {
         KernelTimer kt(p, s);
         if (p->n_heavy)
             spmv_merge_kernel<P, VT, true><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
                 p->rp_light.as<P>(), m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows,
                 p->nnz_light, p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(),
-                p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>());
+                p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>(), m->nnz);
         else
             spmv_merge_kernel<P, VT, false><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
                 rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
-                p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr);
+                p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz);
         kt.stop();
         CSRK_LAUNCH_CHECK();
         spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
             p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
         CSRK_LAUNCH_CHECK();
-        if (p->n_heavy) {
+        if (p->n_heavy && p->panel) {
+            KernelTimer kh(p, s, 1);
+            if (p->panel64)
+                spmv_panel_kernel<int64_t><<<(unsigned)p->panel_groups, MERGE_THREADS, 0, s>>>(
+                    p->p_rp.as<int64_t>(), p->p_ci.as<int32_t>(), p->p_vs.as<double>(), d_x, m->ncols, p->p_y.as<double>(),
+                    p->p_tiles.as<PanelTile>(), p->p_groups.as<PanelGroup>(), p->panel_rows,
+                    p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_nnz);
+            else
+                spmv_panel_kernel<int32_t><<<(unsigned)p->panel_groups, MERGE_THREADS, 0, s>>>(
+                    p->p_rp.as<int32_t>(), p->p_ci.as<int32_t>(), p->p_vs.as<double>(), d_x, m->ncols, p->p_y.as<double>(),
+                    p->p_tiles.as<PanelTile>(), p->p_groups.as<PanelGroup>(), p->panel_rows,
+                    p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_nnz);
+            kh.stop();
+            CSRK_LAUNCH_CHECK();
+            spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->panel_tiles * WAVE, 256), 256, 0, s>>>(
+                p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_tiles, p->p_y.as<double>());
+            CSRK_LAUNCH_CHECK();
+            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(p->n_heavy, 256), PANEL_RCHUNKS), 256, 0, s>>>(
+                p->p_y.as<double>(), p->n_heavy, p->panel_blocks, p->p_tmp.as<double>());
+            CSRK_LAUNCH_CHECK();
+            panel_reduce2_kernel<<<(unsigned)ceil_div(p->n_heavy, 256), 256, 0, s>>>(
+                p->p_tmp.as<double>(), p->n_heavy, p->heavy_row.as<int32_t>(), d_y);
+            CSRK_LAUNCH_CHECK();
+        } else if (p->n_heavy) {
             HeavyStreams st;
             for (int g = 0; g <= HEAVY_STREAMS; g++) st.off[g] = p->stream_off[g];
             KernelTimer kh(p, s, 1);
@@ -1010,11 +1474,13 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     CSRK_REQUIRE(out && n >= 0, "out is NULL");
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
-    const int64_t v[8] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
-                          p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
-                          p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
-                          p->n_pieces, p->n_blocks, HEAVY_MIN, HEAVY_BLOCK};
-    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+    const int64_t v[12] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+                           p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
+                           p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
+                           p->panel ? p->panel_tiles : p->n_pieces, p->n_blocks, HEAVY_MIN,
+                           p->panel ? PANEL_CB : HEAVY_BLOCK,
+                           p->n_heavy ? (p->panel ? 2 : 1) : 0, p->panel_rows, 0, 0};
+    for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

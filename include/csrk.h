@@ -113,7 +113,8 @@ CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);
 CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items);
 
 /* out[0..n) <- {tiles (or segments), items per tile, heavy rows, entries on the tile path,
- * heavy pieces, column blocks, heavy-row threshold, column-block width}; n <= 8. */
+ * heavy tiles (panel) or pieces, column blocks, heavy-row threshold, column-block width,
+ * heavy mode (0 none, 1 pieces, 2 panel), panel rows, 0, 0}; n <= 12. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on

@@ -4,7 +4,9 @@ from csr_amd._lib import lib, check, handle_t
 nrows = 10_000_000; nnz = 200_000_000; dev='cuda'
 m = synth.powerlaw_csr(nrows, nrows, nnz, device=dev)
 x = synth.dense_vector(nrows, device=dev); y = torch.empty(nrows, dtype=torch.float64, device=dev)
+ref = None
 def run(name, **env):
+    global ref
     for k,v in env.items(): os.environ[k]=str(v)
     h = handle_t(0)
     check(lib.csrk_create_device(nrows, nrows, nnz, m['rowptrs'].data_ptr(), 0, m['colinds'].data_ptr(), m['values'].data_ptr(), 2, C.byref(h)))
@@ -13,10 +15,14 @@ def run(name, **env):
     check(lib.csrk_spmv_profile_begin(h, 10)); e0.record()
     for _ in range(10): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
     e1.record(); torch.cuda.synchronize(); ms=e0.elapsed_time(e1)/10
-    n=C.c_int(); k=C.c_float(); check(lib.csrk_spmv_profile_end(h, C.byref(n), C.byref(k)))
-    print(f'{name:34s} total {ms:.3f} ms  merge {k.value:.3f}  heavy+rest {ms-k.value:.3f}', flush=True)
+    n=C.c_int(); k=(C.c_float*2)(); check(lib.csrk_spmv_profile_end(h, C.byref(n), k))
+    st=(C.c_int64*12)(); check(lib.csrk_spmv_plan_stats(h, st, 12))
+    yy = y.clone()
+    if ref is None: ref = yy
+    print(f'{name:26s} total {ms:.3f} ms  light {k[0]:.3f}  heavy {k[1]:.3f}  other {ms-k[0]-k[1]:.3f}  maxdiff {float((yy-ref).abs().max()):.2e} heavy_rows {st[2]} light_nnz {st[3]}', flush=True)
     check(lib.csrk_free(h))
-for W in (32768, 65536, 131072, 262144, 524288, 1048576):
-    run(f'W={W}', CSRK_HEAVY_BLOCK=W, CSRK_HEAVY_PIECE=1024, CSRK_HEAVY_MIN=2048)
-for M in (1024, 4096):
-    run(f'W=262144 min={M}', CSRK_HEAVY_BLOCK=262144, CSRK_HEAVY_PIECE=1024, CSRK_HEAVY_MIN=M)
+run('pieces', CSRK_SPMV_HEAVY_MODE='pieces')
+for tpw in (1, 4, 8, 16, 64):
+    run(f'panel min=2048 tpw={tpw}', CSRK_SPMV_HEAVY_MODE='panel', CSRK_HEAVY_MIN=2048, CSRK_PANEL_TPW=tpw)
+for mn in (1024, 512, 256):
+    run(f'panel min={mn} tpw=8', CSRK_HEAVY_MIN=mn, CSRK_PANEL_TPW=8)
