@@ -144,8 +144,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 8)()
-    check(lib.csrk_spmv_plan_stats(h, st, 8))
+    st = (C.c_int64 * 12)()
+    check(lib.csrk_spmv_plan_stats(h, st, 12))
     n_heavy, nnz_path, n_pieces = int(st[2]), int(st[3]), int(st[4])
     # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
     # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer
@@ -153,7 +153,13 @@ def main():
     # record and writes one 8-B partial per piece.
     kernels = [{'kernel': f'spmv_{algo_name}_kernel', 'ms': k_ms2[0], 'entries': nnz_path,
                 'algorithmic_bytes': nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8}]
-    if n_heavy:
+    heavy_mode = int(st[8])
+    if heavy_mode == 2:
+        # panel form: 12 B per entry of M', one 4-B row pointer + one 8-B partial per (block, row) pair,
+        # x read once (each column block's window is copied to LDS by the workgroups of that block)
+        kernels.append({'kernel': 'spmv_panel_kernel', 'ms': k_ms2[1], 'entries': nnz_loc - nnz_path,
+                        'algorithmic_bytes': (nnz_loc - nnz_path) * 12 + int(st[9]) * 12 + ncols * 8})
+    elif heavy_mode == 1:
         kernels.append({'kernel': 'spmv_heavy_kernel', 'ms': k_ms2[1], 'entries': nnz_loc - nnz_path,
                         'algorithmic_bytes': (nnz_loc - nnz_path) * 12 + n_pieces * 32 + ncols * 8})
     for k in kernels:
@@ -178,8 +184,8 @@ def main():
                    'row_degree': f'power-law alpha={args.alpha}, max {int(min(1_000_000, ncols // 8))}',
                    'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
-                   'heavy_rows': n_heavy, 'heavy_pieces': n_pieces, 'heavy_threshold': int(st[6]),
-                   'column_block': int(st[7]),
+                   'heavy_rows': n_heavy, 'heavy_mode': {0: 'none', 1: 'pieces', 2: 'panel'}[int(st[8])],
+                   'heavy_tiles': n_pieces, 'heavy_threshold': int(st[6]), 'column_block': int(st[7]),
                    'parallelism': f'row-partition x{world}',
                    'collective': args.collective if world > 1 else 'none'},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),

@@ -18,7 +18,8 @@
 //
 // HBM bytes per nnz, two passes with values: 4 (hist) + 12 (read) + 16 (write)
 //   + 4 (hist) + 16 (read) + 12 (write) = 64; structure only: 32.
-// Output rowptrs = exclusive scan of the column histogram (structure.py:180-188).
+// Output rowptrs are read off the sorted keys (= the reference's histogram + running sum,
+// structure.py:180-188), which avoids a contended global-atomic histogram.
 #include "common.h"
 
 namespace csrk {
@@ -28,13 +29,19 @@ constexpr int RX_ROUNDS = 16;
 constexpr int RX_CHUNK = RX_THREADS * RX_ROUNDS;
 constexpr int RX_WAVES = RX_THREADS / WAVE;
 
-// ---- column histogram -> output row pointers --------------------------------------------
-template <class C>
-__global__ void col_hist_kernel(const int32_t *__restrict__ ci, int64_t nnz, C *__restrict__ counts)
+// ---- output row pointers from the sorted keys ----------------------------------------------
+// A histogram with global atomics serialises on popular columns (1.8 ms for the MovieLens-shaped
+// matrix, more than the sort itself); the sorted key sequence gives the same pointers for free:
+// brp[c] = first position whose key is >= c (the reference's histogram + running sum,
+// csr/structure.py:180-188).
+template <class P>
+__global__ void rowptr_from_sorted_keys(const int32_t *__restrict__ keys, int64_t n, int32_t ncols, P *__restrict__ brp)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < nnz; i += stride) atomicAdd((C *)&counts[ci[i]], (C)1);
+    if (i > n) return;
+    const int64_t lo = i == 0 ? 0 : (int64_t)keys[i - 1] + 1;
+    const int64_t hi = i == n ? (int64_t)ncols : (int64_t)keys[i];
+    for (int64_t c = lo; c <= hi; c++) brp[c] = (P)i;
 }
 
 // ---- radix pass: histogram ----------------------------------------------------------------
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
             for (int k = 0; k < RX_WAVES; k++)
                 if (k < w) pre += s_wcnt[k][d];
             const int64_t o = s_goff[d] + pre + below;
-            if (!LAST) keys_out[o] = key;
+            if (keys_out) keys_out[o] = key;
             rows_out[o] = row;
             if (VT != CSRK_VAL_NONE) vals_out[o] = val;
         }
@@ -157,29 +164,20 @@ static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
     const int32_t ncols = a->ncols;
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
 
-    // output row pointers: histogram of columns, then exclusive scan (structure.py:180-188)
-    CSRK_HIP(hipMemsetAsync(t->d_rowptrs, 0, (size_t)(ncols + 1) * sizeof(P), s));
-    if (nnz > 0) {
-        int grid = (int)(ceil_div(nnz, 256) < 8192 ? ceil_div(nnz, 256) : 8192);
-        if (sizeof(P) == 8)
-            col_hist_kernel<unsigned long long><<<grid, 256, 0, s>>>(a->d_colinds, nnz, (unsigned long long *)t->d_rowptrs);
-        else
-            col_hist_kernel<int32_t><<<grid, 256, 0, s>>>(a->d_colinds, nnz, (int32_t *)t->d_rowptrs);
-        CSRK_LAUNCH_CHECK();
+    if (nnz == 0) {
+        CSRK_HIP(hipMemsetAsync(t->d_rowptrs, 0, (size_t)(ncols + 1) * sizeof(P), s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        return CSRK_OK;
     }
-    if (sizeof(P) == 8)
-        CSRK_TRY(exclusive_scan_i64((const int64_t *)t->d_rowptrs, (int64_t *)t->d_rowptrs, ncols, s));
-    else
-        CSRK_TRY(exclusive_scan_i32((const int32_t *)t->d_rowptrs, (int32_t *)t->d_rowptrs, ncols, s));
-    if (nnz == 0) return CSRK_OK;
 
     int bits = 0;
     while (bits < 31 && (1ll << bits) < (int64_t)ncols) bits++;
     int passes = bits <= 8 ? 1 : (bits + 7) / 8;
     const int64_t n_chunks = ceil_div(nnz, RX_CHUNK);
 
-    DevBuf table, keyA, keyB, rowA, rowB, valA, valB;
+    DevBuf table, keyA, keyB, rowA, rowB, valA, valB, keyL;
     CSRK_TRY(table.alloc((size_t)(256 * n_chunks + 1) * 8));
+    CSRK_TRY(keyL.alloc((size_t)nnz * 4));        // sorted keys of the last pass -> output row pointers
     if (passes > 1) {
         CSRK_TRY(keyA.alloc((size_t)nnz * 4));
         CSRK_TRY(rowA.alloc((size_t)nnz * 4));
@@ -197,7 +195,7 @@ static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
     for (int p = 0; p < passes; p++) {
         const bool first = p == 0, last = p == passes - 1;
         const int shift = 8 * p;
-        int32_t *k_out = last ? nullptr : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
+        int32_t *k_out = last ? keyL.as<int32_t>() : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
         int32_t *r_out = last ? t->d_colinds : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
         double *v_out = !HAS_V ? nullptr : (last ? (double *)t->d_values : ((p & 1) ? valB.as<double>() : valA.as<double>()));
         rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, nnz, shift, n_chunks, table.as<int64_t>());
@@ -220,6 +218,9 @@ static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
         r_in = r_out;
         v_in = v_out;
     }
+    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(nnz + 1, 256), 256, 0, s>>>(keyL.as<int32_t>(), nnz, ncols,
+                                                                              (P *)t->d_rowptrs);
+    CSRK_LAUNCH_CHECK();
     CSRK_HIP(hipStreamSynchronize(s));   // temporaries are released on return
     return CSRK_OK;
 }

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""
+Measurements for BASELINE.json configs[2] (dense-panel SpMM, A 2M x 2M nnz 5e7, k = 64) and
+configs[4] (transpose + A B^T on a MovieLens-25M-shaped 162541 x 59047 matrix, nnz 2.5e7), with
+size-independent parity properties at full size.  Not the driver's bench (bench.py is); the numbers
+go into DESIGN.md.   PYTHONPATH=. python tools/bench_configs.py [spmm|transpose|abt|all]
+"""
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+from csr_amd import synth
+from csr_amd._lib import lib, check, handle_t
+
+dev = 'cuda'
+what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+
+
+def timed(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def mk(m, nrows, ncols):
+    h = handle_t(0)
+    nnz = int(m['colinds'].numel())
+    check(lib.csrk_create_device(nrows, ncols, nnz, m['rowptrs'].data_ptr(), 0, m['colinds'].data_ptr(),
+                                 m['values'].data_ptr(), 2, C.byref(h)))
+    return h
+
+
+if what in ('spmm', 'all'):
+    n, nnz, k = 2_000_000, 50_000_000, 64
+    m = synth.powerlaw_csr(n, n, nnz, device=dev, max_degree=250_000)
+    h = mk(m, n, n)
+    B = synth.dense_vector(n * k, device=dev, stream=7).view(n, k)
+    Cm = torch.empty(n, k, dtype=torch.float64, device=dev)
+    ms = timed(lambda: check(lib.csrk_spmm_dense_device(h, B.data_ptr(), k, k, Cm.data_ptr(), k, None)))
+    alg = nnz * 12 + (n + 1) * 4 + 2 * n * k * 8
+    # linearity property: A (B1 + 2 B2) == A B1 + 2 A B2 (to rounding), and column 0 equals SpMV with B[:,0]
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    x0 = B[:, 0].contiguous()
+    check(lib.csrk_spmv_device(h, x0.data_ptr(), y.data_ptr(), None))
+    torch.cuda.synchronize()
+    absA = (m['values'].abs())
+    habs = handle_t(0)
+    check(lib.csrk_create_device(n, n, nnz, m['rowptrs'].data_ptr(), 0, m['colinds'].data_ptr(), absA.data_ptr(), 2, C.byref(habs)))
+    bound = torch.empty(n, dtype=torch.float64, device=dev)
+    xa = x0.abs().contiguous()
+    check(lib.csrk_spmv_device(habs, xa.data_ptr(), bound.data_ptr(), None))
+    torch.cuda.synchronize()
+    err = float(((Cm[:, 0] - y).abs() / (bound + 1e-300)).max())
+    print(json.dumps({'config': 'spmm_dense 2Mx2M nnz5e7 k64 f64', 'ms': round(ms, 3), 'gflops': round(2 * nnz * k / ms / 1e6, 1),
+                      'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBs_alg': round(alg / ms / 1e6, 1),
+                      'col0_vs_spmv_max_err_over_bound': err}), flush=True)
+    check(lib.csrk_free(h)); check(lib.csrk_free(habs))
+    del m, B, Cm
+
+if what in ('transpose', 'abt', 'all'):
+    nr, nc, nnz = 162_541, 59_047, 25_000_095
+    m = synth.powerlaw_csr(nr, nc, nnz, device=dev, alpha=0.9, max_degree=7000)
+    # MovieLens-like ratings 0.5 .. 5.0
+    m['values'] = (torch.floor((m['values'] + 1.0) * 5.0).clamp_(0, 9) + 1.0) * 0.5
+    h = mk(m, nr, nc)
+
+if what in ('transpose', 'all'):
+    outs = []
+
+    def tr():
+        t = handle_t(0)
+        check(lib.csrk_transpose(h, 1, C.byref(t)))
+        outs.append(t)
+    tr()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        tr()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    # properties: transpose(transpose(A)) == A bit for bit (rows are column-sorted); rowptrs of A^T = column histogram
+    t = outs[-1]
+    tt = handle_t(0)
+    check(lib.csrk_transpose(t, 1, C.byref(tt)))
+    rp2 = np.empty(nr + 1, np.int32); ci2 = np.empty(nnz, np.int32); vs2 = np.empty(nnz)
+    check(lib.csrk_export(tt, rp2.ctypes.data_as(C.c_void_p), ci2.ctypes.data_as(C.c_void_p), vs2.ctypes.data_as(C.c_void_p)))
+    ok = (np.array_equal(rp2, m['rowptrs'].cpu().numpy()) and np.array_equal(ci2, m['colinds'].cpu().numpy())
+          and np.array_equal(vs2, m['values'].cpu().numpy()))
+    rpt = np.empty(nc + 1, np.int32)
+    check(lib.csrk_export(t, rpt.ctypes.data_as(C.c_void_p), None, None))
+    hist_ok = np.array_equal(np.diff(rpt), np.bincount(m['colinds'].cpu().numpy(), minlength=nc))
+    alg = 4 * nnz + (4 + 8) * nnz + (4 + 8) * nnz + (nr + nc + 2) * 4
+    print(json.dumps({'config': 'transpose ML25M-shape 162541x59047 nnz 25000095 (incl. allocation of the result)',
+                      'ms': round(ms, 3), 'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBs_alg': round(alg / ms / 1e6, 1),
+                      'double_transpose_bit_exact': bool(ok), 'rowptrs_match_histogram': bool(hist_ok)}), flush=True)
+    for o in outs:
+        check(lib.csrk_free(o))
+    check(lib.csrk_free(tt))
+
+if what in ('abt', 'all'):
+    # A_blk B^T with A_blk = first 2000 rows (users), B = first 20000 rows: product rows are dense-ish
+    def sub(r1):
+        rp = m['rowptrs'][:r1 + 1].contiguous()
+        e = int(rp[-1].item())
+        hh = handle_t(0)
+        check(lib.csrk_create_device(r1, nc, e, rp.data_ptr(), 0, m['colinds'].data_ptr(), m['values'].data_ptr(), 2, C.byref(hh)))
+        return hh, rp, e
+    ha, rpa, ea = sub(2000)
+    hb, rpb, eb = sub(20000)
+    c = handle_t(0)
+    t0 = time.perf_counter()
+    check(lib.csrk_spgemm_abt(ha, hb, C.byref(c)))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    nrc, ncc, nnzc = C.c_int32(), C.c_int32(), C.c_int64()
+    check(lib.csrk_info(c, C.byref(nrc), C.byref(ncc), C.byref(nnzc), None, None))
+    # checksum property: sum of all entries of A B^T == (1^T A) . (1^T B) summed over columns
+    rpc = np.empty(nrc.value + 1, np.int32); cic = np.empty(nnzc.value, np.int32); vsc = np.empty(nnzc.value)
+    check(lib.csrk_export(c, rpc.ctypes.data_as(C.c_void_p), cic.ctypes.data_as(C.c_void_p), vsc.ctypes.data_as(C.c_void_p)))
+    ca = torch.zeros(nc, dtype=torch.float64, device=dev).index_add_(0, m['colinds'][:ea].long(), m['values'][:ea])
+    cb = torch.zeros(nc, dtype=torch.float64, device=dev).index_add_(0, m['colinds'][:eb].long(), m['values'][:eb])
+    want = float((ca * cb).sum())
+    got = float(vsc.sum())
+    print(json.dumps({'config': 'mult_abt (2000 x 59047) x (20000 x 59047)^T, ML25M-shape rows', 'ms_first_call': round(ms, 1),
+                      'product_nnz': nnzc.value, 'checksum_rel_err': abs(got - want) / abs(want),
+                      'cols_sorted': bool(all(np.all(np.diff(cic[rpc[i]:rpc[i + 1]]) > 0) for i in range(0, 2000, 97)))}), flush=True)
+    check(lib.csrk_free(c)); check(lib.csrk_free(ha)); check(lib.csrk_free(hb))

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>/ (tools/collect_profiles.sh) into committed files under profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):
+    "gpurun merges into gpurun_out/ without deleting earlier files: take the most recent match"
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = f'gpurun_out/{tag}'
+os.makedirs('profiles', exist_ok=True)
+bench = json.loads(open(f'{src}/bench.json').read().strip().splitlines()[-1])
+shutil.copy(f'{src}/bench.json', f'profiles/{tag}_bench.json')
+# kernel stats: keep our kernels + the total
+rows = list(csv.DictReader(open(newest(f'{src}/kt/*/*_kernel_stats.csv'))))
+with open(f'profiles/{tag}_spmv_kernel_stats.csv', 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
+    for r in rows:
+        if 'csrk::' in r['Name']:
+            w.writerow([r[k] for k in ['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev']])
+def pmc(d):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(newest(f'{src}/{d}/*/*_counter_collection.csv'))):
+        if 'csrk::spmv' in r['Kernel_Name'] or 'csrk::panel' in r['Kernel_Name']:
+            name = r['Kernel_Name'].split('csrk::')[1].split('(')[0].split('<')[0]
+            agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+allc = {}
+for d in ('fetch', 'write', 'tcc', 'tcp'):
+    allc.update(pmc(d))
+with open(f'profiles/{tag}_spmv_pmc_counters.csv', 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'counter', 'mean_per_launch'])
+    for (k, c), v in sorted(allc.items()):
+        w.writerow([k, c, f'{v:.6g}'])
+traffic = {}
+for (k, c), v in allc.items():
+    if c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        traffic[k] = traffic.get(k, 0.0) + v * 1024.0       # counters are in KB
+out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
+       'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slots), each with '
+                 '--kernel-trace only; mean over the recorded launches; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024. '
+                 'The guide\'s x2 correction of FETCH_SIZE holds for 16-B-per-lane coalesced streams; these kernels mix '
+                 '4/8/16-B loads and gathers, so the raw value is reported (it can under-count the read side).'}
+json.dump(out, open(f'profiles/{tag}_spmv_pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(out['hbm_bytes_per_launch']))
+print({k: v for k, v in bench['roofline'].items() if k != 'all_kernels'})
