@@ -131,7 +131,7 @@ def main():
         y = op.step(x)
     barrier()
     elapsed = time.perf_counter() - t0
-    n_rec, k_ms2 = C.c_int(0), (C.c_float * 2)(0.0, 0.0)
+    n_rec, k_ms2 = C.c_int(0), (C.c_float * 3)(0.0, 0.0, 0.0)
     check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -144,24 +144,21 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 12)()
-    check(lib.csrk_spmv_plan_stats(h, st, 12))
-    n_heavy, nnz_path, n_pieces = int(st[2]), int(st[3]), int(st[4])
+    st = (C.c_int64 * 16)()
+    check(lib.csrk_spmv_plan_stats(h, st, 16))
+    n_heavy, nnz_path = int(st[2]), int(st[3])
     # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
-    # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer
-    # and writes one y entry per row; each kernel reads x once; the heavy kernel reads one 24-B piece
-    # record and writes one 8-B partial per piece.
+    # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer and
+    # writes one y entry per row; a panel kernel reads one 4-B row pointer and writes one 8-B partial per
+    # (column block, row) pair of its tier; each kernel reads x once.
     kernels = [{'kernel': f'spmv_{algo_name}_kernel', 'ms': k_ms2[0], 'entries': nnz_path,
                 'algorithmic_bytes': nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8}]
-    heavy_mode = int(st[8])
-    if heavy_mode == 2:
-        # panel form: 12 B per entry of M', one 4-B row pointer + one 8-B partial per (block, row) pair,
-        # x read once (each column block's window is copied to LDS by the workgroups of that block)
-        kernels.append({'kernel': 'spmv_panel_kernel', 'ms': k_ms2[1], 'entries': nnz_loc - nnz_path,
-                        'algorithmic_bytes': (nnz_loc - nnz_path) * 12 + int(st[9]) * 12 + ncols * 8})
-    elif heavy_mode == 1:
-        kernels.append({'kernel': 'spmv_heavy_kernel', 'ms': k_ms2[1], 'entries': nnz_loc - nnz_path,
-                        'algorithmic_bytes': (nnz_loc - nnz_path) * 12 + n_pieces * 32 + ncols * 8})
+    if int(st[10]):
+        kernels.append({'kernel': 'spmv_panel_kernel<tier0: x window in LDS>', 'ms': k_ms2[1], 'entries': int(st[10]),
+                        'algorithmic_bytes': int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8})
+    if int(st[13]):
+        kernels.append({'kernel': 'spmv_panel_kernel<tier1: x window in L2>', 'ms': k_ms2[2], 'entries': int(st[13]),
+                        'algorithmic_bytes': int(st[13]) * 12 + int(st[12]) * 12 + ncols * 8})
     for k in kernels:
         k['achieved_gbs'] = round(k['algorithmic_bytes'] / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
         k['ms'] = round(k['ms'], 4)
@@ -184,8 +181,8 @@ def main():
                    'row_degree': f'power-law alpha={args.alpha}, max {int(min(1_000_000, ncols // 8))}',
                    'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
-                   'heavy_rows': n_heavy, 'heavy_mode': {0: 'none', 1: 'pieces', 2: 'panel'}[int(st[8])],
-                   'heavy_tiles': n_pieces, 'heavy_threshold': int(st[6]), 'column_block': int(st[7]),
+                   'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9])},
+                   'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
                    'parallelism': f'row-partition x{world}',
                    'collective': args.collective if world > 1 else 'none'},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),

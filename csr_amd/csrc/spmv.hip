@@ -52,7 +52,34 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Sum p[s..e) strictly left to right (the reference's order), four LDS loads in flight at a time: a
+// plain `for (k) acc += p[k]` is a load -> wait -> add chain of ~100 cycles per entry.
+__device__ __forceinline__ double ordered_sum(const double *p, int s, int e)
+{
+    double acc = 0.0;
+    int k = s;
+    for (; k + 4 <= e; k += 4) {
+        const double a = p[k], b = p[k + 1], c = p[k + 2], d = p[k + 3];
+        acc += a;
+        acc += b;
+        acc += c;
+        acc += d;
+    }
+    for (; k < e; k++) acc += p[k];
+    return acc;
+}
+
 // ---- plan ---------------------------------------------------------------------------------
+// One column-blocked panel: the entries of a set of long rows re-sorted block-major into a matrix
+// M' whose rows are (column block, long row) pairs; see "long rows, panel form" below.
+struct Panel {
+    bool on = false, p64 = false, window = false;
+    int32_t cb = 0, nb = 0, nrow = 0;            // block width (columns), blocks, long rows in this tier
+    int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
+    DevBuf row_list;                             // int32[nrow]: original row ids, ascending
+    DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y, tmp;
+};
+
 struct SpmvPlan {
     int algo = CSRK_SPMV_MERGE;
     // merge
@@ -61,28 +88,17 @@ struct SpmvPlan {
     DevBuf tile_row;    // int32[n_tiles + 1]: rows completed before each tile boundary
     DevBuf carry_row;   // int32[n_tiles]
     DevBuf carry_val;   // double[n_tiles]
-    // merge, heavy-row split (rows >= HEAVY_MIN entries are cut out of the merge path)
-    int32_t n_heavy = 0;
+    // merge, long-row split: rows >= the cut threshold are taken out of the merge path (light view)
+    // and served by one or two column-blocked panels
+    int32_t n_heavy = 0;          // rows cut out
     int64_t nnz_light = 0;
-    int64_t n_pieces = 0;
-    int32_t n_blocks = 0;
-    DevBuf rp_light;    // P[nrows + 1]: row pointers with the heavy rows collapsed to length 0
-    DevBuf cut_pos;     // int64[n_heavy]: light-index position of each heavy row
-    DevBuf cut_cum;     // int64[n_heavy + 1]: heavy entries before each heavy row (shift table)
+    DevBuf rp_light;    // P[nrows + 1]: row pointers with the cut rows collapsed to length 0
+    DevBuf cut_pos;     // int64[n_heavy]: light-index position of each cut row
+    DevBuf cut_cum;     // int64[n_heavy + 1]: cut entries before each cut row (shift table)
     DevBuf tile_cut;    // int32[n_tiles + 1]: cuts at or before each tile start
     DevBuf heavy_row;   // int32[n_heavy]
-    DevBuf piece;       // HeavyPiece[n_pieces], column-block-major
-    DevBuf part_off;    // int64[n_heavy + 1]: first partial slot of each heavy row
-    DevBuf part;        // double[n_pieces]
-    int64_t stream_off[9] = {0};   // piece range of each XCD stream
-    int64_t heavy_grid = 0;
-    // heavy rows, panel form
-    bool panel = false;
-    bool panel64 = false;          // M' row pointers are int64
-    int32_t panel_blocks = 0;
-    int64_t panel_rows = 0, panel_tiles = 0, panel_nnz = 0;
-    DevBuf p_rp, p_ci, p_vs, p_tiles, p_groups, p_carry_row, p_carry_val, p_y, p_tmp;
-    int64_t panel_groups = 0;
+    Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS; [1] mid rows, 131072-column
+                        // blocks, x window kept in L2 by block-major, XCD-aware scheduling
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -90,7 +106,7 @@ struct SpmvPlan {
     DevBuf seg_part;    // double[n_segs]
     // kernel timing (csrk_spmv_profile_begin/end)
     std::vector<hipEvent_t> ev;   // start/stop pairs
-    std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1 = heavy-row kernel
+    std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1/2 = panel tier 0/1
     int ev_used = 0;
     bool profiling = false;
     ~SpmvPlan()
@@ -375,8 +391,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
             s_long[q] = r;
             continue;
         }
-        double acc = 0.0;
-        for (int k = s; k < e; k++) acc += s_prod[k];
+        double acc = ordered_sum(s_prod, s, e);
         if (r < nr) {
             y[i0 + r] = acc;
         } else {
@@ -406,35 +421,25 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     }
 }
 
-// ---- heavy rows: column-blocked segments ----------------------------------------------------
-// A row with thousands of entries sweeps a large part of x; with rows processed one after another
-// every gather misses L2 and is served by the Infinity Cache (measured: ~14.5 ps per gather against
-// ~2.9 ps for an L2 hit).  Rows with >= HEAVY_MIN entries are therefore taken
-// out of the merge path and cut at column-block boundaries (HEAVY_BLOCK columns = 1 MiB of x);
-// the pieces are processed block-major, so all pieces in flight read the same x window and it
-// stays in each XCD's 4 MiB L2.  Needs ascending columns inside heavy rows (checked at plan time;
-// otherwise the split is disabled).  One wavefront per piece, partials summed per row in column
-// order by a second kernel: deterministic.
-// defaults; CSRK_HEAVY_MIN / CSRK_HEAVY_BLOCK / CSRK_HEAVY_PIECE override them at plan time (tuning)
-static int HEAVY_MIN = 2048;
-static int HEAVY_BLOCK = 131072;
-static int HEAVY_PIECE = 1024;
-
-struct HeavyPiece {
-    int64_t start;     // first entry (index into colinds/values)
-    int32_t len;
-    int32_t pad;
-    int64_t slot;      // partial slot (row-major, column order inside the row)
-};
+// ---- long rows: cut out of the merge path ------------------------------------------------------
+// What limits SpMV on a power-law matrix is the x[col] gathers, not the 12 B/entry stream
+// (measured, DESIGN.md section 4: a gather served by L2 costs ~2.9 ps of chip time, one served by the
+// Infinity Cache ~14.5 ps, and every row with thousands of entries sweeps most of x).  Rows with at
+// least `cut` entries are therefore removed from the merge path -- the tile kernel runs on a light
+// view of the row pointers (rp_light + a cut table; colinds/values are not copied for it) -- and are
+// served by the column-blocked panels below.  Needs ascending columns inside those rows (checked at
+// plan time; otherwise no split).
+static int HEAVY_MIN = 2048;      // tier 0 threshold (CSRK_HEAVY_MIN)
+static int TIERB_MIN = 128;       // tier 1 threshold (CSRK_TIERB_MIN; 0 disables tier 1)
 
 template <class P>
 __global__ void heavy_flag_kernel(const P *__restrict__ rp, int32_t nrows, int32_t *__restrict__ flag,
-                                  int64_t *__restrict__ hlen, int HEAVY_MIN)
+                                  int64_t *__restrict__ hlen, int cut_min)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nrows) return;
     int64_t len = r < nrows ? (int64_t)rp[r + 1] - (int64_t)rp[r] : 0;
-    bool h = len >= HEAVY_MIN;
+    bool h = len >= cut_min;
     flag[r] = h ? 1 : 0;
     hlen[r] = h ? len : 0;
 }
@@ -443,17 +448,18 @@ template <class P>
 __global__ void heavy_view_kernel(const P *__restrict__ rp, int32_t nrows, const int32_t *__restrict__ hidx,
                                   const int64_t *__restrict__ hbefore, P *__restrict__ rp_light,
                                   int32_t *__restrict__ heavy_row, int64_t *__restrict__ cut_pos,
-                                  int64_t *__restrict__ cut_cum, int32_t n_heavy)
+                                  int64_t *__restrict__ cut_cum, int64_t *__restrict__ cut_len, int32_t n_heavy)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nrows) return;
     const int64_t light = (int64_t)rp[r] - hbefore[r];
     rp_light[r] = (P)light;
-    if (r < nrows && hidx[r + 1] != hidx[r]) {     // row r is heavy
+    if (r < nrows && hidx[r + 1] != hidx[r]) {     // row r is cut out
         const int32_t c = hidx[r];
         heavy_row[c] = (int32_t)r;
         cut_pos[c] = light;
         cut_cum[c] = hbefore[r];
+        cut_len[c] = (int64_t)rp[r + 1] - (int64_t)rp[r];
     }
     if (r == nrows) cut_cum[n_heavy] = hbefore[nrows];
 }
@@ -483,63 +489,6 @@ __device__ __forceinline__ int64_t lower_bound_col(const int32_t *__restrict__ c
     return lo;
 }
 
-// Processing order of the pieces.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
-// labels the XCD group; a speed assumption only, never correctness), and each XCD has its own L2, so
-// column block b is given to XCD group b % 8: stream g holds the blocks b = g, g + 8, ... in
-// ascending order, rows ascending inside a block.  Each x window is then loaded into ONE L2, not 8.
-constexpr int HEAVY_STREAMS = 8;
-__host__ __device__ __forceinline__ int64_t heavy_order_index(int32_t b, int32_t c, int32_t n_heavy, int32_t n_blocks)
-{
-    const int64_t per_stream = (n_blocks + HEAVY_STREAMS - 1) / HEAVY_STREAMS;
-    return (((int64_t)(b % HEAVY_STREAMS)) * per_stream + b / HEAVY_STREAMS) * n_heavy + c;
-}
-
-// one thread per (heavy row c, column block b): number of pieces, in both orders
-template <class P>
-__global__ void heavy_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int64_t *__restrict__ cnt_bh, int64_t *__restrict__ cnt_hb, int HEAVY_BLOCK,
-                                   int HEAVY_PIECE)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t c = (int32_t)(i / n_blocks), b = (int32_t)(i % n_blocks);
-    const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
-    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
-    const int64_t n = (hi - lo + HEAVY_PIECE - 1) / HEAVY_PIECE;
-    cnt_bh[heavy_order_index(b, c, n_heavy, n_blocks)] = n;
-    cnt_hb[i] = n;
-}
-
-template <class P>
-__global__ void heavy_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                  const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                  const int64_t *__restrict__ off_bh, const int64_t *__restrict__ off_hb,
-                                  HeavyPiece *__restrict__ piece, int64_t *__restrict__ part_off, int HEAVY_BLOCK,
-                                  int HEAVY_PIECE)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t c = (int32_t)(i / n_blocks), b = (int32_t)(i % n_blocks);
-    const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * HEAVY_BLOCK);
-    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * HEAVY_BLOCK);
-    int64_t pos = off_bh[heavy_order_index(b, c, n_heavy, n_blocks)], slot = off_hb[i];
-    if (b == 0) part_off[c] = slot;
-    if (i == (int64_t)n_heavy * n_blocks - 1) part_off[n_heavy] = off_hb[i + 1];
-    for (int64_t k = lo; k < hi; k += HEAVY_PIECE) {
-        HeavyPiece pc;
-        pc.start = k;
-        pc.len = (int32_t)(hi - k < HEAVY_PIECE ? hi - k : HEAVY_PIECE);
-        pc.pad = 0;
-        pc.slot = slot++;
-        piece[pos++] = pc;
-    }
-}
-
 // cuts at or before each tile start: tile_cut[t] = #{c : cut_pos[c] <= j0(t)}
 __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64_t n_tiles, int items, int64_t total,
                                      const int64_t *__restrict__ cut_pos, int32_t n_heavy, int32_t *__restrict__ tile_cut)
@@ -560,91 +509,45 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
     tile_cut[t] = lo;
 }
 
-struct HeavyStreams {
-    int64_t off[HEAVY_STREAMS + 1];   // piece range of each XCD stream
-};
-
-template <int VT>
-__global__ __launch_bounds__(256) void spmv_heavy_kernel(const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                                        const double *__restrict__ x,
-                                                        const HeavyPiece *__restrict__ piece, HeavyStreams st,
-                                                        double *__restrict__ part)
-{
-    // workgroup w serves stream w % 8 (its XCD group) and takes that stream's next 4 pieces
-    const int g = blockIdx.x % HEAVY_STREAMS;
-    const int64_t q = st.off[g] + (int64_t)(blockIdx.x / HEAVY_STREAMS) * (256 / WAVE) + threadIdx.x / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (q >= st.off[g + 1]) return;
-    const HeavyPiece pc = piece[q];
-    const int64_t s = pc.start;
-    const int n = pc.len;
-    double acc = 0.0;
-    // lane owns consecutive pairs: 512 B of colinds / 1 KiB of values per wave-instruction
-    for (int k = 2 * lane; k < n; k += 2 * WAVE) {
-        if (k + 1 < n) {
-            i32x2_t cc = __builtin_nontemporal_load((const I32x2 *)(ci + s + k));
-            double v0, v1;
-            load_val_pair<VT>(vs, s + k, true, v0, v1);
-            acc += v0 * x[cc.x];
-            acc += v1 * x[cc.y];
-        } else {
-            double v0, v1;
-            load_val_pair<VT>(vs, s + k, false, v0, v1);
-            acc += v0 * x[ci[s + k]];
-        }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) part[pc.slot] = acc;
-}
-
-// one wavefront per heavy row: partials in column order (lane-strided, then the shfl tree)
-__global__ __launch_bounds__(256) void spmv_heavy_reduce_kernel(const int32_t *__restrict__ heavy_row,
-                                                               const int64_t *__restrict__ part_off, int32_t n_heavy,
-                                                               const double *__restrict__ part, double *__restrict__ y)
-{
-    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (c >= n_heavy) return;
-    const int64_t a = part_off[c], b = part_off[c + 1];
-    double acc = 0.0;
-    for (int64_t q = a + lane; q < b; q += WAVE) acc += part[q];
-    acc = wave_sum(acc);
-    if (lane == 0) y[heavy_row[c]] = acc;
-}
-
-
-// ---- heavy rows, panel form: x window in LDS ---------------------------------------------------
-// PMC on the piece kernel above: 88 % of its L2 accesses hit, yet it runs at the chip's L1-miss
-// request rate (~150-170 G 64-B requests/s): every gather is its own L2 round trip.  The panel form
-// removes the gathers.  At plan time the heavy rows' entries are re-sorted column-block-major into a
-// panel matrix M' whose rows are (column block b, heavy row h) pairs, blocks of PANEL_CB columns
-// (32 KiB of x); values are widened to float64.  Per call the merge-tile algorithm runs over M' with
-// tiles confined to one block: the workgroup first copies the block's x window into LDS with
-// coalesced loads (512 requests instead of 2048 gathers per tile), then multiplies from LDS.  Row
-// sums of M' are the per-(block, row) partials y'[b][h]; they are reduced over b in block order by
-// panel_reduce kernels.  Still no float atomics: deterministic.
-constexpr int PANEL_CB = 4096;
+// ---- long rows, panel form ---------------------------------------------------------------------
+// At plan time the long rows' entries are re-sorted column-block-major into a panel matrix M' whose
+// rows are (column block b, long row h) pairs; values are widened to float64.  Per call the
+// merge-tile algorithm runs over M' with tiles confined to one block; row sums of M' are the
+// per-(block, row) partials y'[b][h], reduced over b in block order by the panel_reduce kernels.
+// No float atomics: deterministic.
+//   tier 0 (rows >= 2048 entries, 46-64 % of a power-law matrix): blocks of 4096 columns; the
+//     workgroup copies the block's 32 KiB x window into LDS with coalesced 16-B loads (512 requests
+//     instead of 2048 gathers per tile) and multiplies from LDS.  A first version that only
+//     re-ordered the rows' pieces block-major (x window in L2) had an 88 % L2 hit rate and still ran
+//     at the chip's L1-miss request rate (~150-170 G 64-B requests/s): every gather is its own L2
+//     round trip, so the gathers themselves had to go.
+//   tier 1 (rows of 128..2047 entries): a (row, block) pair of 4096 columns would hold < 1 entry, so
+//     blocks are 131072 columns (1 MiB of x) and x is gathered from global memory; tiles run
+//     block-major and block b is served only by workgroups with blockIdx % 8 == b % 8 (one XCD, so ONE
+//     L2 holds the window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.
+constexpr int PANEL_CB0 = 4096;
+constexpr int PANEL_CB1 = 131072;
 
 template <class P>
 __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int64_t *__restrict__ cnt)
+                                   int32_t cb, int64_t *__restrict__ cnt)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
     const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);      // index = b * H + c
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * PANEL_CB);
-    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * PANEL_CB);
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
+    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * cb);
     cnt[i] = hi - lo;
 }
 
 template <class P, int VT, class PP>
 __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                  const int64_t *__restrict__ off, PP *__restrict__ prp, int32_t *__restrict__ pci,
-                                  double *__restrict__ pvs)
+                                  int32_t cb, const int64_t *__restrict__ off, PP *__restrict__ prp,
+                                  int32_t *__restrict__ pci, double *__restrict__ pvs)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pairs = (int64_t)n_heavy * n_blocks;
@@ -654,7 +557,7 @@ __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__res
     const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * PANEL_CB);
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
     const int64_t n = off[i + 1] - off[i];
     int64_t o = off[i];
     for (int64_t k = lo; k < lo + n; k++, o++) {
@@ -724,14 +627,14 @@ struct PanelGroup {
 };
 constexpr int PANEL_TPW = 8;     // tiles per workgroup: the x window is copied once per group
 
-template <class PP>
+template <class PP, int CB, bool WINDOW>
 __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
     double *__restrict__ carry_val, int64_t pnnz)
 {
-    __shared__ double s_x[PANEL_CB];
+    __shared__ double s_x[WINDOW ? CB : 1];
     __shared__ double s_buf[MERGE_ITEMS + 1];
     __shared__ int32_t s_long[MERGE_MAXLONG];
     __shared__ int32_t s_nlong;
@@ -740,18 +643,20 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wv = tid / WAVE;
     const PanelGroup grp = groups[blockIdx.x];
-    const int32_t w0 = grp.blk * PANEL_CB;
+    if (grp.nt == 0) return;                      // padding group of an XCD stream
+    const int32_t w0 = WINDOW ? grp.blk * CB : 0; // without a window, columns index x directly
 
     // the block's x window -> LDS, coalesced 16-B loads, all in flight before the first store
-    {
-        const int wlen = ncols - w0 < PANEL_CB ? ncols - w0 : PANEL_CB;
+    if (WINDOW) {
+        const int wlen = ncols - w0 < CB ? ncols - w0 : CB;
         const f64x2_t *src = (const f64x2_t *)(x + w0);
-        if (wlen == PANEL_CB) {
-            f64x2_t v[PANEL_CB / 2 / MERGE_THREADS];
+        constexpr int WL = WINDOW ? CB / 2 / MERGE_THREADS : 1;
+        if (wlen == CB) {
+            f64x2_t v[WL];
 #pragma unroll
-            for (int u = 0; u < PANEL_CB / 2 / MERGE_THREADS; u++) v[u] = src[tid + u * MERGE_THREADS];
+            for (int u = 0; u < WL; u++) v[u] = src[tid + u * MERGE_THREADS];
 #pragma unroll
-            for (int u = 0; u < PANEL_CB / 2 / MERGE_THREADS; u++) ((f64x2_t *)s_x)[tid + u * MERGE_THREADS] = v[u];
+            for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * MERGE_THREADS] = v[u];
         } else {
             for (int k = tid; k < wlen; k += MERGE_THREADS) s_x[k] = x[w0 + k];
         }
@@ -775,8 +680,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
             load_pair_clamped<CSRK_VAL_F64>(pci, pvs, j0_ + k, j0_, nn_, pnnz - 2, c0[u], c1[u], p0[u], p1[u]); \
             p0[u] = k < nn_ ? p0[u] : 0.0;                                                            \
             p1[u] = k + 1 < nn_ ? p1[u] : 0.0;                                                        \
-            c0[u] = k < nn_ ? c0[u] : w0;                                                             \
-            c1[u] = k + 1 < nn_ ? c1[u] : w0;                                                         \
+            if (WINDOW) {                                                                             \
+                c0[u] = k < nn_ ? c0[u] : w0;                                                         \
+                c1[u] = k + 1 < nn_ ? c1[u] : w0;                                                     \
+            }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int u = 0; u < RPT; u++)                                               \
         {                                                                                             \
@@ -800,8 +707,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
 #pragma unroll
         for (int u = 0; u < MERGE_PAIRS; u++) {
             const int k = 2 * (tid + u * MERGE_THREADS);
-            p0[u] *= s_x[c0[u] - w0];
-            p1[u] *= s_x[c1[u] - w0];
+            p0[u] *= WINDOW ? s_x[c0[u] - w0] : x[c0[u]];
+            p1[u] *= WINDOW ? s_x[c1[u] - w0] : x[c1[u]];
         }
 
         if (nr == 0) {
@@ -849,8 +756,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
                 s_long[q] = r;
                 continue;
             }
-            double acc = 0.0;
-            for (int k = s; k < e; k++) acc += s_prod[k];
+            double acc = ordered_sum(s_prod, s, e);
             if (r < nr) {
                 yp[i0 + r] = acc;
             } else {
@@ -1011,176 +917,188 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
 // ---- host side ----------------------------------------------------------------------------------
 static int g_heavy_split = 1;   // CSRK_SPMV_HEAVY_SPLIT=0 disables the heavy-row path (A/B runs)
 
-// Panel form of the heavy rows: M' (column-block-major copy, float64 values) + its tile list.
+constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (speed assumption only)
+
+// Build one panel tier: M' (column-block-major copy of the listed rows, float64 values), its tiles and
+// the workgroup list.  `xcd_streams`: order the groups so that column block b is served by workgroups
+// with blockIdx % 8 == b % 8.
 template <class P, int VT>
-static int build_panel(Matrix *m, SpmvPlan *p, int32_t n_heavy, int32_t nb, int64_t nnz_heavy, hipStream_t s)
+static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
+                       bool window, int tpw, bool xcd_streams, hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
-    const int64_t pairs = (int64_t)n_heavy * nb;
+    const int32_t n = (int32_t)rows.size();
+    const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, cb);
+    const int64_t pairs = (int64_t)n * nb;
+    CSRK_TRY(pn->row_list.alloc((size_t)n * 4));
+    CSRK_HIP(hipMemcpyAsync(pn->row_list.p, rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
     DevBuf off, bends;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
     const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
-    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, nb, off.as<int64_t>());
+    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
-    p->panel64 = nnz_heavy > INT32_MAX;
-    CSRK_TRY(p->p_rp.alloc((size_t)(pairs + 1) * (p->panel64 ? 8 : 4)));
-    CSRK_TRY(p->p_ci.alloc((size_t)nnz_heavy * 4));
-    CSRK_TRY(p->p_vs.alloc((size_t)nnz_heavy * 8));
-    if (p->panel64)
-        panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, p->heavy_row.as<int32_t>(), n_heavy,
-                                                          nb, off.as<int64_t>(), p->p_rp.as<int64_t>(),
-                                                          p->p_ci.as<int32_t>(), p->p_vs.as<double>());
+    pn->p64 = nnz_rows > INT32_MAX;
+    CSRK_TRY(pn->rp.alloc((size_t)(pairs + 1) * (pn->p64 ? 8 : 4)));
+    CSRK_TRY(pn->ci.alloc((size_t)nnz_rows * 4));
+    CSRK_TRY(pn->vs.alloc((size_t)nnz_rows * 8));
+    if (pn->p64)
+        panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
+                                                          cb, off.as<int64_t>(), pn->rp.as<int64_t>(),
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
     else
-        panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, p->heavy_row.as<int32_t>(), n_heavy,
-                                                          nb, off.as<int64_t>(), p->p_rp.as<int32_t>(),
-                                                          p->p_ci.as<int32_t>(), p->p_vs.as<double>());
+        panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
+                                                          cb, off.as<int64_t>(), pn->rp.as<int32_t>(),
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
     CSRK_LAUNCH_CHECK();
-    // tiles per block (host: nb is a few thousand)
+    // tiles per block (host: nb is at most a few thousand)
     CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
-    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n_heavy, nb, bends.as<int64_t>());
+    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
     CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
     t0[0] = 0;
-    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n_heavy + be[b + 1] - be[b], MERGE_ITEMS);
+    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n + be[b + 1] - be[b], MERGE_ITEMS);
     const int64_t n_tiles = t0[nb];
     CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
-    CSRK_TRY(p->p_tiles.alloc((size_t)n_tiles * sizeof(PanelTile)));
-    if (p->panel64)
+    CSRK_TRY(pn->tile.alloc((size_t)n_tiles * sizeof(PanelTile)));
+    if (pn->p64)
         panel_plan_kernel<int64_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-            p->p_rp.as<int64_t>(), n_heavy, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, p->p_tiles.as<PanelTile>());
+            pn->rp.as<int64_t>(), n, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, pn->tile.as<PanelTile>());
     else
         panel_plan_kernel<int32_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-            p->p_rp.as<int32_t>(), n_heavy, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, p->p_tiles.as<PanelTile>());
+            pn->rp.as<int32_t>(), n, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, pn->tile.as<PanelTile>());
     CSRK_LAUNCH_CHECK();
-    {
-        int tpw = PANEL_TPW;
-        if (const char *e = getenv("CSRK_PANEL_TPW")) tpw = atoi(e) > 0 ? atoi(e) : PANEL_TPW;
-        std::vector<PanelGroup> groups;
-        for (int32_t b = 0; b < nb; b++)
-            for (int64_t t = t0[b]; t < t0[b + 1]; t += tpw) {
-                PanelGroup gq;
-                gq.t0 = t;
-                gq.nt = (int32_t)(t0[b + 1] - t < tpw ? t0[b + 1] - t : tpw);
-                gq.blk = b;
-                groups.push_back(gq);
-            }
-        p->panel_groups = (int64_t)groups.size();
-        CSRK_TRY(p->p_groups.alloc(groups.size() * sizeof(PanelGroup)));
-        CSRK_HIP(hipMemcpyAsync(p->p_groups.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
-        CSRK_HIP(hipStreamSynchronize(s));
+
+    // workgroup list: `tpw` consecutive tiles of one block per workgroup
+    std::vector<PanelGroup> groups;
+    auto block_groups = [&](int32_t b, std::vector<PanelGroup> &out) {
+        for (int64_t t = t0[b]; t < t0[b + 1]; t += tpw) {
+            PanelGroup gq;
+            gq.t0 = t;
+            gq.nt = (int32_t)(t0[b + 1] - t < tpw ? t0[b + 1] - t : tpw);
+            gq.blk = b;
+            out.push_back(gq);
+        }
+    };
+    if (!xcd_streams) {
+        for (int32_t b = 0; b < nb; b++) block_groups(b, groups);
+    } else {
+        std::vector<PanelGroup> st[HEAVY_STREAMS];
+        size_t longest = 0;
+        for (int32_t b = 0; b < nb; b++) block_groups(b, st[b % HEAVY_STREAMS]);
+        for (int q = 0; q < HEAVY_STREAMS; q++) longest = st[q].size() > longest ? st[q].size() : longest;
+        PanelGroup pad;
+        pad.t0 = 0;
+        pad.nt = 0;
+        pad.blk = 0;
+        groups.reserve(longest * HEAVY_STREAMS);
+        for (size_t i = 0; i < longest; i++)
+            for (int q = 0; q < HEAVY_STREAMS; q++) groups.push_back(i < st[q].size() ? st[q][i] : pad);
     }
-    CSRK_TRY(p->p_carry_row.alloc((size_t)n_tiles * 4));
-    CSRK_TRY(p->p_carry_val.alloc((size_t)n_tiles * 8));
-    CSRK_TRY(p->p_y.alloc((size_t)pairs * 8));
-    CSRK_TRY(p->p_tmp.alloc((size_t)PANEL_RCHUNKS * n_heavy * 8));
-    CSRK_HIP(hipStreamSynchronize(s));
-    p->panel = true;
-    p->panel_blocks = nb;
-    p->panel_rows = pairs;
-    p->panel_tiles = n_tiles;
-    p->panel_nnz = nnz_heavy;
+    pn->groups = (int64_t)groups.size();
+    CSRK_TRY(pn->group.alloc(groups.size() * sizeof(PanelGroup)));
+    CSRK_HIP(hipMemcpyAsync(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
+    CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
+    CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
+    CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
+    CSRK_TRY(pn->tmp.alloc((size_t)PANEL_RCHUNKS * n * 8));
+    CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
+    pn->on = true;
+    pn->window = window;
+    pn->cb = cb;
+    pn->nb = nb;
+    pn->nrow = n;
+    pn->rows = pairs;
+    pn->tiles = n_tiles;
+    pn->nnz = nnz_rows;
     return CSRK_OK;
 }
 
-// Cut the heavy rows out of the merge path and build their column-blocked piece list.
+// Cut the long rows out of the merge path and build their panel tiers.
 template <class P>
-static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s)
+static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_tier1 = true)
 {
     p->n_heavy = 0;
     const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
-    if ((env && env[0] == '0') || !g_heavy_split) return CSRK_OK;
+    if (env && env[0] == '0') return CSRK_OK;
     if (const char *e = getenv("CSRK_HEAVY_MIN")) HEAVY_MIN = atoi(e) > 64 ? atoi(e) : 64;
-    if (const char *e = getenv("CSRK_HEAVY_BLOCK")) HEAVY_BLOCK = atoi(e) > 1024 ? atoi(e) : 1024;
-    if (const char *e = getenv("CSRK_HEAVY_PIECE")) HEAVY_PIECE = atoi(e) > 64 ? atoi(e) : 64;
-    if (m->nrows == 0 || m->nnz < HEAVY_MIN) return CSRK_OK;
+    if (const char *e = getenv("CSRK_TIERB_MIN")) TIERB_MIN = atoi(e) >= 0 ? atoi(e) : 0;
+    const bool tier1 = allow_tier1 && TIERB_MIN > 0 && TIERB_MIN < HEAVY_MIN;
+    const int cut_min = tier1 ? TIERB_MIN : HEAVY_MIN;
+    if (m->nrows == 0 || m->nnz < cut_min) return CSRK_OK;
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nr = m->nrows;
     const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);
-    DevBuf flag, hlen, bad;
+    DevBuf flag, hlen, bad, clen;
     CSRK_TRY(flag.alloc((size_t)(nr + 2) * 4));
     CSRK_TRY(hlen.alloc((size_t)(nr + 2) * 8));
-    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), HEAVY_MIN);
+    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), cut_min);
     CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(flag.as<int32_t>(), flag.as<int32_t>(), nr, s));      // -> heavy index
-    CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> heavy nnz before
-    int32_t n_heavy = 0;
-    int64_t nnz_heavy = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_heavy, flag.as<int32_t>() + nr, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(&nnz_heavy, hlen.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(exclusive_scan_i32(flag.as<int32_t>(), flag.as<int32_t>(), nr, s));      // -> cut-row index
+    CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> cut entries before
+    int32_t n_cut = 0;
+    int64_t nnz_cut = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_cut, flag.as<int32_t>() + nr, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipMemcpyAsync(&nnz_cut, hlen.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
-    if (n_heavy == 0) return CSRK_OK;
-    const int32_t n_blocks = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, HEAVY_BLOCK);
-    if ((int64_t)n_heavy * n_blocks > (64ll << 20)) return CSRK_OK;   // pair table too large: keep one path
+    if (n_cut == 0) return CSRK_OK;
 
     CSRK_TRY(p->rp_light.alloc((size_t)(nr + 1) * sizeof(P)));
-    CSRK_TRY(p->heavy_row.alloc((size_t)n_heavy * 4));
-    CSRK_TRY(p->cut_pos.alloc((size_t)n_heavy * 8));
-    CSRK_TRY(p->cut_cum.alloc((size_t)(n_heavy + 1) * 8));
+    CSRK_TRY(p->heavy_row.alloc((size_t)n_cut * 4));
+    CSRK_TRY(p->cut_pos.alloc((size_t)n_cut * 8));
+    CSRK_TRY(p->cut_cum.alloc((size_t)(n_cut + 1) * 8));
+    CSRK_TRY(clen.alloc((size_t)n_cut * 8));
     heavy_view_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), p->rp_light.as<P>(),
                                           p->heavy_row.as<int32_t>(), p->cut_pos.as<int64_t>(),
-                                          p->cut_cum.as<int64_t>(), n_heavy);
+                                          p->cut_cum.as<int64_t>(), clen.as<int64_t>(), n_cut);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(bad.alloc(4));
     CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, s));
-    heavy_sorted_kernel<P><<<(unsigned)n_heavy, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy,
-                                                           bad.as<int32_t>());
+    heavy_sorted_kernel<P><<<(unsigned)n_cut, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_cut,
+                                                         bad.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     int32_t is_bad = 0;
+    std::vector<int32_t> rows((size_t)n_cut);
+    std::vector<int64_t> lens((size_t)n_cut);
     CSRK_HIP(hipMemcpyAsync(&is_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipMemcpyAsync(rows.data(), p->heavy_row.p, (size_t)n_cut * 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipMemcpyAsync(lens.data(), clen.p, (size_t)n_cut * 8, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
-    if (is_bad) return CSRK_OK;      // unsorted columns in a heavy row: column blocking needs order
+    if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
 
-    const char *mode = getenv("CSRK_SPMV_HEAVY_MODE");
-    const int32_t pnb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB);
-    if (!(mode && mode[0] == 'p' && mode[1] == 'i') && (int64_t)n_heavy * pnb <= (256ll << 20)) {
-        int rc;
-        if (m->val_type == CSRK_VAL_F64) rc = build_panel<P, CSRK_VAL_F64>(m, p, n_heavy, pnb, nnz_heavy, s);
-        else if (m->val_type == CSRK_VAL_F32) rc = build_panel<P, CSRK_VAL_F32>(m, p, n_heavy, pnb, nnz_heavy, s);
-        else rc = build_panel<P, CSRK_VAL_NONE>(m, p, n_heavy, pnb, nnz_heavy, s);
-        if (rc != CSRK_OK) return rc;
-        p->n_heavy = n_heavy;
-        p->n_blocks = pnb;
-        p->nnz_light = m->nnz - nnz_heavy;
-        return CSRK_OK;
+    std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
+    int64_t nnz0 = 0, nnz1 = 0;
+    for (int32_t c = 0; c < n_cut; c++) {
+        if (lens[c] >= HEAVY_MIN) {
+            r0.push_back(rows[c]);
+            nnz0 += lens[c];
+        } else {
+            r1.push_back(rows[c]);
+            nnz1 += lens[c];
+        }
     }
+    const int64_t pair_cap = 256ll << 20;
+    const int64_t pairs0 = (int64_t)r0.size() * ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB0);
+    const int64_t pairs1 = (int64_t)r1.size() * ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB1);
+    if (pairs0 > pair_cap) return CSRK_OK;                       // pair table too large: keep one path
+    if (pairs1 > pair_cap && tier1) return build_heavy_split<P>(m, p, s, false);
 
-    const int64_t pairs = (int64_t)n_heavy * n_blocks;
-    const int64_t per_stream = ceil_div(n_blocks, HEAVY_STREAMS);
-    const int64_t slots = HEAVY_STREAMS * per_stream * n_heavy;     // >= pairs; padding slots count 0
-    DevBuf c_bh, c_hb;
-    CSRK_TRY(c_bh.alloc((size_t)(slots + 1) * 8));
-    CSRK_TRY(c_hb.alloc((size_t)(pairs + 1) * 8));
-    CSRK_HIP(hipMemsetAsync(c_bh.p, 0, (size_t)(slots + 1) * 8, s));
-    const unsigned g2 = (unsigned)ceil_div(pairs, 256);
-    heavy_count_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
-                                           c_bh.as<int64_t>(), c_hb.as<int64_t>(), HEAVY_BLOCK, HEAVY_PIECE);
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(c_bh.as<int64_t>(), c_bh.as<int64_t>(), slots, s));
-    CSRK_TRY(exclusive_scan_i64(c_hb.as<int64_t>(), c_hb.as<int64_t>(), pairs, s));
-    for (int g = 0; g <= HEAVY_STREAMS; g++)
-        CSRK_HIP(hipMemcpyAsync(&p->stream_off[g], c_bh.as<int64_t>() + (int64_t)g * per_stream * n_heavy, 8,
-                                hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    const int64_t n_pieces = p->stream_off[HEAVY_STREAMS];
-    int64_t longest = 0;
-    for (int g = 0; g < HEAVY_STREAMS; g++)
-        longest = longest > p->stream_off[g + 1] - p->stream_off[g] ? longest : p->stream_off[g + 1] - p->stream_off[g];
-    p->heavy_grid = HEAVY_STREAMS * ceil_div(longest, 256 / WAVE);
-    CSRK_TRY(p->piece.alloc((size_t)n_pieces * sizeof(HeavyPiece)));
-    CSRK_TRY(p->part.alloc((size_t)n_pieces * 8));
-    CSRK_TRY(p->part_off.alloc((size_t)(n_heavy + 1) * 8));
-    heavy_fill_kernel<P><<<g2, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_heavy, n_blocks,
-                                          c_bh.as<int64_t>(), c_hb.as<int64_t>(), p->piece.as<HeavyPiece>(),
-                                          p->part_off.as<int64_t>(), HEAVY_BLOCK, HEAVY_PIECE);
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipStreamSynchronize(s));
-    p->n_heavy = n_heavy;
-    p->n_blocks = n_blocks;
-    p->n_pieces = n_pieces;
-    p->nnz_light = m->nnz - nnz_heavy;
+    int tpw0 = 8, tpw1 = 1;
+    if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
+    if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
+#define BUILD(VT)                                                                                                  \
+    do {                                                                                                           \
+        if (!r0.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[0], r0, nnz0, PANEL_CB0, true, tpw0, false, s))); \
+        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
+    } while (0)
+    if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
+    else if (m->val_type == CSRK_VAL_F32) BUILD(CSRK_VAL_F32);
+    else BUILD(CSRK_VAL_NONE);
+#undef BUILD
+    p->n_heavy = n_cut;
+    p->nnz_light = m->nnz - nnz_cut;
     return CSRK_OK;
 }
 
@@ -1273,39 +1191,33 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
             p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
         CSRK_LAUNCH_CHECK();
-        if (p->n_heavy && p->panel) {
-            KernelTimer kh(p, s, 1);
-            if (p->panel64)
-                spmv_panel_kernel<int64_t><<<(unsigned)p->panel_groups, MERGE_THREADS, 0, s>>>(
-                    p->p_rp.as<int64_t>(), p->p_ci.as<int32_t>(), p->p_vs.as<double>(), d_x, m->ncols, p->p_y.as<double>(),
-                    p->p_tiles.as<PanelTile>(), p->p_groups.as<PanelGroup>(), p->panel_rows,
-                    p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_nnz);
-            else
-                spmv_panel_kernel<int32_t><<<(unsigned)p->panel_groups, MERGE_THREADS, 0, s>>>(
-                    p->p_rp.as<int32_t>(), p->p_ci.as<int32_t>(), p->p_vs.as<double>(), d_x, m->ncols, p->p_y.as<double>(),
-                    p->p_tiles.as<PanelTile>(), p->p_groups.as<PanelGroup>(), p->panel_rows,
-                    p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_nnz);
+        for (int q = 0; q < 2 && p->n_heavy; q++) {
+            Panel *pn = &p->tier[q];
+            if (!pn->on) continue;
+            KernelTimer kh(p, s, 1 + q);
+#define PANEL_ARGS(PP)                                                                                              \
+    pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
+        pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
+        pn->carry_val.as<double>(), pn->nnz
+            const unsigned grid = (unsigned)pn->groups;
+            if (q == 0) {
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int32_t));
+            } else {
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int32_t));
+            }
+#undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
-            spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->panel_tiles * WAVE, 256), 256, 0, s>>>(
-                p->p_carry_row.as<int32_t>(), p->p_carry_val.as<double>(), p->panel_tiles, p->p_y.as<double>());
+            spmv_merge_fixup_kernel<<<(unsigned)ceil_div(pn->tiles * WAVE, 256), 256, 0, s>>>(
+                pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
             CSRK_LAUNCH_CHECK();
-            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(p->n_heavy, 256), PANEL_RCHUNKS), 256, 0, s>>>(
-                p->p_y.as<double>(), p->n_heavy, p->panel_blocks, p->p_tmp.as<double>());
+            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(pn->nrow, 256), PANEL_RCHUNKS), 256, 0, s>>>(
+                pn->y.as<double>(), pn->nrow, pn->nb, pn->tmp.as<double>());
             CSRK_LAUNCH_CHECK();
-            panel_reduce2_kernel<<<(unsigned)ceil_div(p->n_heavy, 256), 256, 0, s>>>(
-                p->p_tmp.as<double>(), p->n_heavy, p->heavy_row.as<int32_t>(), d_y);
-            CSRK_LAUNCH_CHECK();
-        } else if (p->n_heavy) {
-            HeavyStreams st;
-            for (int g = 0; g <= HEAVY_STREAMS; g++) st.off[g] = p->stream_off[g];
-            KernelTimer kh(p, s, 1);
-            spmv_heavy_kernel<VT><<<(unsigned)p->heavy_grid, 256, 0, s>>>(
-                m->d_colinds, m->d_values, d_x, p->piece.as<HeavyPiece>(), st, p->part.as<double>());
-            kh.stop();
-            CSRK_LAUNCH_CHECK();
-            spmv_heavy_reduce_kernel<<<(unsigned)ceil_div((int64_t)p->n_heavy * WAVE, 256), 256, 0, s>>>(
-                p->heavy_row.as<int32_t>(), p->part_off.as<int64_t>(), p->n_heavy, p->part.as<double>(), d_y);
+            panel_reduce2_kernel<<<(unsigned)ceil_div(pn->nrow, 256), 256, 0, s>>>(
+                pn->tmp.as<double>(), pn->nrow, pn->row_list.as<int32_t>(), d_y);
             CSRK_LAUNCH_CHECK();
         }
         break;
@@ -1430,7 +1342,7 @@ int csrk_spmv_profile_begin(csrk_handle_t h, int max_records)
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
     std::lock_guard<std::mutex> lk(m->mu);
-    while ((int)p->ev.size() < 4 * max_records) {      // two timed kernels per launch
+    while ((int)p->ev.size() < 6 * max_records) {      // up to three timed kernels per launch
         hipEvent_t e;
         CSRK_HIP(hipEventCreate(&e));
         p->ev.push_back(e);
@@ -1450,8 +1362,8 @@ int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
     SpmvPlan *p = m->spmv_plan;
     CSRK_REQUIRE(p && p->profiling, "profiling was not started on this handle");
     p->profiling = false;
-    double tot[2] = {0.0, 0.0};
-    int cnt[2] = {0, 0};
+    double tot[3] = {0.0, 0.0, 0.0};
+    int cnt[3] = {0, 0, 0};
     int n = p->ev_used / 2;
     for (int i = 0; i < n; i++) {
         float ms = 0.f;
@@ -1463,6 +1375,7 @@ int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
     *n_records = cnt[0];
     mean_ms[0] = cnt[0] ? (float)(tot[0] / cnt[0]) : 0.f;
     mean_ms[1] = cnt[1] ? (float)(tot[1] / cnt[1]) : 0.f;
+    mean_ms[2] = cnt[2] ? (float)(tot[2] / cnt[2]) : 0.f;
     p->ev_used = 0;
     return CSRK_OK;
 }
@@ -1474,13 +1387,13 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     CSRK_REQUIRE(out && n >= 0, "out is NULL");
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
-    const int64_t v[12] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    const Panel &t0 = p->tier[0], &t1 = p->tier[1];
+    const int64_t v[16] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
-                           p->panel ? p->panel_tiles : p->n_pieces, p->n_blocks, HEAVY_MIN,
-                           p->panel ? PANEL_CB : HEAVY_BLOCK,
-                           p->n_heavy ? (p->panel ? 2 : 1) : 0, p->panel_rows, 0, 0};
-    for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
+                           t0.tiles, t0.nb, HEAVY_MIN, t0.cb, p->n_heavy ? 2 : 0, t0.rows, t0.nnz,
+                           t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb};
+    for (int i = 0; i < n && i < 16; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

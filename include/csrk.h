@@ -112,16 +112,17 @@ CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);
 /* Launch geometry of the dominant SpMV kernel (for roofline accounting in bench.py). */
 CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items);
 
-/* out[0..n) <- {tiles (or segments), items per tile, heavy rows, entries on the tile path,
- * heavy tiles (panel) or pieces, column blocks, heavy-row threshold, column-block width,
- * heavy mode (0 none, 1 pieces, 2 panel), panel rows, 0, 0}; n <= 12. */
+/* out[0..n) <- {0 tiles (or segments), 1 items per tile, 2 rows cut out of the tile path, 3 entries on
+ * the tile path, 4 tier-0 tiles, 5 tier-0 column blocks, 6 tier-0 row threshold, 7 tier-0 block width,
+ * 8 split mode (0 none, 2 panels), 9 tier-0 (block,row) pairs, 10 tier-0 entries, 11 tier-1 rows,
+ * 12 tier-1 pairs, 13 tier-1 entries, 14 tier-1 row threshold, 15 tier-1 block width}; n <= 16. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
- * this handle brackets its two streaming kernels -- [0] the tile / segment / row kernel and
- * [1] the heavy-row kernel (merge algorithm only) -- with hipEvent pairs recorded on the launch
- * stream; nothing synchronises until csrk_spmv_profile_end, which returns the number of recorded
- * launches and mean_ms[2], their mean durations in milliseconds (0 if a kernel did not run).
+ * this handle brackets its streaming kernels -- [0] the tile / segment / row kernel, [1] and [2]
+ * the panel kernels of tier 0 and tier 1 (merge algorithm only) -- with hipEvent pairs recorded on
+ * the launch stream; nothing synchronises until csrk_spmv_profile_end, which returns the number of
+ * recorded launches and mean_ms[3], their mean durations in milliseconds (0 if a kernel did not run).
  * At most `max_records` launches are recorded. */
 CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
 CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);

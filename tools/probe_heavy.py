@@ -15,13 +15,14 @@ def run(name, **env):
     check(lib.csrk_spmv_profile_begin(h, 20)); e0.record()
     for _ in range(20): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
     e1.record(); torch.cuda.synchronize(); ms=e0.elapsed_time(e1)/20
-    n=C.c_int(); k=(C.c_float*2)(); check(lib.csrk_spmv_profile_end(h, C.byref(n), k))
-    st=(C.c_int64*12)(); check(lib.csrk_spmv_plan_stats(h, st, 12))
+    n=C.c_int(); k=(C.c_float*3)(); check(lib.csrk_spmv_profile_end(h, C.byref(n), k))
+    st=(C.c_int64*16)(); check(lib.csrk_spmv_plan_stats(h, st, 16))
     yy = y.clone()
     if ref is None: ref = yy
-    print(f'{name:26s} total {ms:.3f} ms  light {k[0]:.3f}  heavy {k[1]:.3f}  other {ms-k[0]-k[1]:.3f}  maxdiff {float((yy-ref).abs().max()):.2e} heavy_rows {st[2]} light_nnz {st[3]}', flush=True)
+    print(f'{name:22s} total {ms:.3f} ms light {k[0]:.3f} t0 {k[1]:.3f} t1 {k[2]:.3f} other {ms-k[0]-k[1]-k[2]:.3f} maxdiff {float((yy-ref).abs().max()):.1e} cut_rows {st[2]} light_nnz {st[3]} t1: rows {st[11]} pairs {st[12]} nnz {st[13]}', flush=True)
     check(lib.csrk_free(h))
-for mn in (1536, 2048, 3072, 4096, 8192, 16384):
-    run(f'panel min={mn}', CSRK_HEAVY_MIN=mn, CSRK_PANEL_TPW=8)
-run('panel min=2048 tpw=6', CSRK_HEAVY_MIN=2048, CSRK_PANEL_TPW=6)
-run('panel min=2048 tpw=12', CSRK_HEAVY_MIN=2048, CSRK_PANEL_TPW=12)
+run('tier1 off', CSRK_TIERB_MIN=0)
+for mn in (1024, 512, 256, 128, 64):
+    run(f'tier1 min={mn}', CSRK_TIERB_MIN=mn)
+run('tier1 min=256 tpw1=1', CSRK_TIERB_MIN=256, CSRK_PANEL_TPW1=1)
+run('tier1 min=256 tpw1=8', CSRK_TIERB_MIN=256, CSRK_PANEL_TPW1=8)
