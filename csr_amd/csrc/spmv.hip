@@ -97,6 +97,8 @@ struct SpmvPlan {
     DevBuf cut_cum;     // int64[n_heavy + 1]: cut entries before each cut row (shift table)
     DevBuf tile_cut;    // int32[n_tiles + 1]: cuts at or before each tile start
     DevBuf heavy_row;   // int32[n_heavy]
+    hipStream_t side[2] = {nullptr, nullptr};   // panel tiers run on forked streams (joined before y is final)
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS; [1] mid rows, 131072-column
                         // blocks, x window kept in L2 by block-major, XCD-aware scheduling
     // vector
@@ -112,6 +114,11 @@ struct SpmvPlan {
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        for (int q = 0; q < 2; q++) {
+            if (side[q]) (void)hipStreamDestroy(side[q]);
+            if (ev_join[q]) (void)hipEventDestroy(ev_join[q]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
 };
 
@@ -843,6 +850,23 @@ __global__ __launch_bounds__(256) void spmv_merge_fixup_kernel(const int32_t *__
     if (lane == 0) y[row] = acc + y[row];
 }
 
+// Thread-per-tile form of the fix-up, used when runs of equal carry_row are known to be short: with the
+// long-row split active no row on a tile path exceeds a few tiles (light rows < 2048 entries, panel
+// rows <= one column block), so a serial loop is cheaper than 64 lanes per tile (13 us -> 4 us).
+__global__ __launch_bounds__(256) void spmv_merge_fixup_short_kernel(const int32_t *__restrict__ carry_row,
+                                                                    const double *__restrict__ carry_val,
+                                                                    int64_t n_tiles, double *__restrict__ y)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int32_t row = carry_row[t];
+    if (row < 0) return;
+    if (t > 0 && carry_row[t - 1] == row) return;
+    double acc = carry_val[t];
+    for (int64_t u = t + 1; u < n_tiles && carry_row[u] == row; u++) acc += carry_val[u];
+    y[row] = acc + y[row];
+}
+
 // ---- vector: one wavefront per row segment ------------------------------------------------
 constexpr int VEC_SEG = 4096;
 
@@ -1099,6 +1123,17 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
 #undef BUILD
     p->n_heavy = n_cut;
     p->nnz_light = m->nnz - nnz_cut;
+    // Fork/join streams for the tiers: measured neutral on MI355X (1.231 vs 1.235 ms: the three kernels
+    // are each request/bandwidth-bound, so overlapping them only interleaves the same work); off unless
+    // CSRK_SPMV_STREAMS=1.
+    const char *ms = getenv("CSRK_SPMV_STREAMS");
+    if (ms && ms[0] == '1') {
+        CSRK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        for (int q = 0; q < 2; q++) {
+            CSRK_HIP(hipStreamCreateWithFlags(&p->side[q], hipStreamNonBlocking));
+            CSRK_HIP(hipEventCreateWithFlags(&p->ev_join[q], hipEventDisableTiming));
+        }
+    }
     return CSRK_OK;
 }
 
@@ -1176,46 +1211,65 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     if (algo == CSRK_SPMV_MERGE && m->nnz < 2) algo = CSRK_SPMV_SCALAR;   // the tile kernel's pair loads need >= 2 entries
     switch (algo) {
     case CSRK_SPMV_MERGE: {
-        KernelTimer kt(p, s);
-        if (p->n_heavy)
-            spmv_merge_kernel<P, VT, true><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
-                p->rp_light.as<P>(), m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows,
-                p->nnz_light, p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(),
-                p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>(), m->nnz);
-        else
-            spmv_merge_kernel<P, VT, false><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
-                rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
-                p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz);
-        kt.stop();
-        CSRK_LAUNCH_CHECK();
-        spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
-            p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
-        CSRK_LAUNCH_CHECK();
+        // Fork: the panel tiers are independent of the tile kernel until the final y writes, so they
+        // run on side streams and their tails / fix-up kernels overlap with it.  Join before the
+        // reduce2 kernels, which overwrite the zeros the tile kernel stored for the cut rows.
+        const bool fork = p->n_heavy && p->side[0];
+        if (fork) CSRK_HIP(hipEventRecord(p->ev_fork, s));
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on) continue;
-            KernelTimer kh(p, s, 1 + q);
+            hipStream_t sq = fork ? p->side[q] : s;
+            if (fork) CSRK_HIP(hipStreamWaitEvent(sq, p->ev_fork, 0));
+            KernelTimer kh(p, sq, 1 + q);
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
         pn->carry_val.as<double>(), pn->nnz
             const unsigned grid = (unsigned)pn->groups;
             if (q == 0) {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int32_t));
             } else {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, s>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int32_t));
             }
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
-            spmv_merge_fixup_kernel<<<(unsigned)ceil_div(pn->tiles * WAVE, 256), 256, 0, s>>>(
+            spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sq>>>(
                 pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
             CSRK_LAUNCH_CHECK();
-            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(pn->nrow, 256), PANEL_RCHUNKS), 256, 0, s>>>(
+            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(pn->nrow, 256), PANEL_RCHUNKS), 256, 0, sq>>>(
                 pn->y.as<double>(), pn->nrow, pn->nb, pn->tmp.as<double>());
             CSRK_LAUNCH_CHECK();
+            if (fork) CSRK_HIP(hipEventRecord(p->ev_join[q], sq));
+        }
+        {
+            KernelTimer kt(p, s);
+            if (p->n_heavy)
+                spmv_merge_kernel<P, VT, true><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
+                    p->rp_light.as<P>(), m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows,
+                    p->nnz_light, p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(),
+                    p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>(), m->nnz);
+            else
+                spmv_merge_kernel<P, VT, false><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
+                    rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
+                    p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz);
+            kt.stop();
+            CSRK_LAUNCH_CHECK();
+            if (p->n_heavy)
+                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(p->n_tiles, 256), 256, 0, s>>>(
+                    p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
+            else
+                spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
+                    p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
+            CSRK_LAUNCH_CHECK();
+        }
+        for (int q = 0; q < 2 && p->n_heavy; q++) {
+            Panel *pn = &p->tier[q];
+            if (!pn->on) continue;
+            if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[q], 0));
             panel_reduce2_kernel<<<(unsigned)ceil_div(pn->nrow, 256), 256, 0, s>>>(
                 pn->tmp.as<double>(), pn->nrow, pn->row_list.as<int32_t>(), d_y);
             CSRK_LAUNCH_CHECK();

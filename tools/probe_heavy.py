@@ -21,8 +21,7 @@ def run(name, **env):
     if ref is None: ref = yy
     print(f'{name:22s} total {ms:.3f} ms light {k[0]:.3f} t0 {k[1]:.3f} t1 {k[2]:.3f} other {ms-k[0]-k[1]-k[2]:.3f} maxdiff {float((yy-ref).abs().max()):.1e} cut_rows {st[2]} light_nnz {st[3]} t1: rows {st[11]} pairs {st[12]} nnz {st[13]}', flush=True)
     check(lib.csrk_free(h))
-run('tier1 off', CSRK_TIERB_MIN=0)
-for mn in (1024, 512, 256, 128, 64):
-    run(f'tier1 min={mn}', CSRK_TIERB_MIN=mn)
-run('tier1 min=256 tpw1=1', CSRK_TIERB_MIN=256, CSRK_PANEL_TPW1=1)
-run('tier1 min=256 tpw1=8', CSRK_TIERB_MIN=256, CSRK_PANEL_TPW1=8)
+run('streams off', CSRK_SPMV_STREAMS=0)
+run('streams on', CSRK_SPMV_STREAMS=1)
+run('streams off', CSRK_SPMV_STREAMS=0)
+run('streams on', CSRK_SPMV_STREAMS=1)
