@@ -51,6 +51,7 @@ SIGNATURES = {
     'csrk_device_count': (_int, [C.POINTER(_int)]),
     'csrk_set_device': (_int, [_int]),
     'csrk_synchronize': (_int, [_vp]),
+    'csrk_trim_cache': (_int, []),
     'csrk_create': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_create_device': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_free': (_int, [handle_t]),

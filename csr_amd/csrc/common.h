@@ -46,6 +46,17 @@ void set_error(const char *fmt, ...);
 // Check the launch that was just issued.
 #define CSRK_LAUNCH_CHECK() CSRK_HIP(hipGetLastError())
 
+// ---- caching device allocator (handle.hip) ---------------------------------------------------
+// hipMalloc / hipFree cost 50-100 us each and hipFree synchronises the device; a transpose or SpGEMM
+// call makes a dozen of each (half of a 2.8 ms transpose was allocator time).  Temporaries and
+// result arrays therefore come from a process-wide pool of previously freed blocks: a request is
+// served by the smallest cached block of [n, 1.5 n] bytes on the same device, freed blocks go back to
+// the pool, and the pool is trimmed above 16 GiB or by csrk_trim_cache().  All pooled memory is used
+// in stream order on the default stream, so a recycled block is never touched by an earlier kernel
+// that is still running.
+hipError_t pool_alloc(void **p, size_t n);
+void pool_free(void *p);
+
 // ---- device buffer with RAII -----------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
@@ -56,7 +67,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr;
         bytes = 0;
     }
@@ -64,7 +75,7 @@ struct DevBuf {
     int alloc(size_t n)
     {
         release();
-        CSRK_HIP(hipMalloc(&p, n ? n : 16));
+        CSRK_HIP(pool_alloc(&p, n ? n : 16));
         bytes = n;
         return CSRK_OK;
     }

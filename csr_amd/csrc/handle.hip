@@ -4,6 +4,8 @@
 // row_extent / row_nnzs (csr/_rows.py:9-13, csr/csr.py:432-441).
 #include "common.h"
 
+#include <map>
+#include <unordered_map>
 #include <unordered_set>
 
 namespace csrk {
@@ -24,6 +26,79 @@ static void register_matrix(const Matrix *m)
     live_set().insert(m);
 }
 
+// ---- caching device allocator -------------------------------------------------------------------
+namespace {
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::multimap<size_t, PoolBlock> g_pool_free;              // cached blocks by size
+std::unordered_map<void *, PoolBlock> g_pool_live;         // blocks handed out
+size_t g_pool_cached = 0;
+constexpr size_t POOL_CAP = 16ull << 30;
+
+void pool_trim_locked(size_t keep)
+{
+    while (g_pool_cached > keep && !g_pool_free.empty()) {
+        auto it = std::prev(g_pool_free.end());            // largest first
+        g_pool_cached -= it->second.bytes;
+        (void)hipFree(it->second.p);
+        g_pool_free.erase(it);
+    }
+}
+}  // namespace
+
+hipError_t pool_alloc(void **out, size_t n)
+{
+    n = (n + 255) & ~(size_t)255;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto it = g_pool_free.lower_bound(n); it != g_pool_free.end() && it->first <= n + n / 2; ++it) {
+            if (it->second.device != dev) continue;
+            PoolBlock b = it->second;
+            g_pool_free.erase(it);
+            g_pool_cached -= b.bytes;
+            g_pool_live[b.p] = b;
+            *out = b.p;
+            return hipSuccess;
+        }
+    }
+    void *q = nullptr;
+    e = hipMalloc(&q, n);
+    if (e != hipSuccess) {                                  // out of memory: give the cache back and retry
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+        e = hipMalloc(&q, n);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[q] = PoolBlock{q, n, dev};
+    *out = q;
+    return hipSuccess;
+}
+
+void pool_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) {                          // not ours (should not happen)
+        (void)hipFree(p);
+        return;
+    }
+    PoolBlock b = it->second;
+    g_pool_live.erase(it);
+    g_pool_free.emplace(b.bytes, b);
+    g_pool_cached += b.bytes;
+    if (g_pool_cached > POOL_CAP) pool_trim_locked(POOL_CAP / 2);
+}
+
 void set_error(const char *fmt, ...)
 {
     char buf[1024];
@@ -39,9 +114,9 @@ Matrix::~Matrix()
     if (spmv_plan) free_spmv_plan(spmv_plan);
     if (spmm_plan) free_spmm_plan(spmm_plan);
     if (owns) {
-        if (d_rowptrs) (void)hipFree(d_rowptrs);
-        if (d_colinds) (void)hipFree(d_colinds);
-        if (d_values) (void)hipFree(d_values);
+        pool_free(d_rowptrs);
+        pool_free(d_colinds);
+        pool_free(d_values);
     }
     magic = 0;
     std::lock_guard<std::mutex> lk(g_live_mu);
@@ -88,9 +163,9 @@ int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_typ
     size_t rp_bytes = (size_t)(nrows + 1) * m->ptr_bytes();
     size_t ci_bytes = (size_t)nnz * 4;
     size_t vs_bytes = (size_t)nnz * m->val_bytes();
-    e = hipMalloc(&m->d_rowptrs, rp_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_colinds, ci_bytes ? ci_bytes : 16);
-    if (e == hipSuccess && val_type != CSRK_VAL_NONE) e = hipMalloc(&m->d_values, vs_bytes ? vs_bytes : 16);
+    e = pool_alloc(&m->d_rowptrs, rp_bytes);
+    if (e == hipSuccess) e = pool_alloc((void **)&m->d_colinds, ci_bytes ? ci_bytes : 16);
+    if (e == hipSuccess && val_type != CSRK_VAL_NONE) e = pool_alloc(&m->d_values, vs_bytes ? vs_bytes : 16);
     if (e != hipSuccess) {
         set_error("hipMalloc failed for %lld-nnz matrix: %s", (long long)nnz, hipGetErrorString(e));
         delete m;
@@ -128,6 +203,14 @@ int csrk_device_count(int *count)
 int csrk_set_device(int device)
 {
     CSRK_HIP(hipSetDevice(device));
+    return CSRK_OK;
+}
+
+int csrk_trim_cache(void)
+{
+    CSRK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_trim_locked(0);
     return CSRK_OK;
 }
 

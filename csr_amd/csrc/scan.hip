@@ -88,7 +88,7 @@ static int scan_impl(const Tin *in, Tout *out, int64_t n, int64_t n_out, hipStre
     CSRK_TRY((scan_impl<Tout, Tout>(sums.as<Tout>(), sums.as<Tout>(), nb, nb, s)));
     add_chunk_offsets<Tout><<<(unsigned)nb, SCAN_THREADS, 0, s>>>(out, sums.as<Tout>(), n_out);
     CSRK_LAUNCH_CHECK();
-    // `sums` is freed on return: hipFree synchronises with outstanding work.
+    // `sums` goes back to the caching allocator on return; reuse is ordered on the default stream.
     return CSRK_OK;
 }
 

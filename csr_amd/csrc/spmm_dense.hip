@@ -140,7 +140,9 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
         if (!m->spmm_plan) {
             SpmmPlan *np = new (std::nothrow) SpmmPlan();
             CSRK_REQUIRE(np, "out of host memory");
-            int rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, s) : build_mm_plan<int32_t>(m, np, s);
+            // default stream + completion before use: see the caching allocator's contract (common.h)
+            int rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
+            if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
             if (rc != CSRK_OK) {
                 delete np;
                 return rc;

@@ -1191,7 +1191,14 @@ static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
         SpmvPlan *p = new (std::nothrow) SpmvPlan();
         CSRK_REQUIRE(p, "out of host memory");
         p->algo = m->spmv_algo == CSRK_SPMV_AUTO ? CSRK_SPMV_MERGE : m->spmv_algo;
-        int rc = m->ptr64 ? build_plan<int64_t>(m, p, s) : build_plan<int32_t>(m, p, s);
+        // Plans are built on the default stream and completed before use: their temporaries come from
+        // the caching allocator, whose recycling is safe only in default-stream order.
+        (void)s;
+        int rc = m->ptr64 ? build_plan<int64_t>(m, p, nullptr) : build_plan<int32_t>(m, p, nullptr);
+        if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) {
+            set_error("SpMV plan construction failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = CSRK_ERR_HIP;
+        }
         if (rc != CSRK_OK) {
             delete p;
             return rc;

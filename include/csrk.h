@@ -69,6 +69,9 @@ CSRK_API int csrk_device_count(int *count);
  * GPU normally passes LOCAL_RANK). */
 CSRK_API int csrk_set_device(int device);
 CSRK_API int csrk_synchronize(void *stream);
+/* Return the library's cached (free) device memory to the driver.  libcsrk keeps freed temporaries
+ * and released handles' arrays in a size-bucketed pool (at most 16 GiB) to avoid hipMalloc/hipFree. */
+CSRK_API int csrk_trim_cache(void);
 
 /* ---- handles: replaces to_handle / from_handle / release_handle ---------------------
  * csr/kernels/numba/__init__.py:16-44; csr/kernels/mkl/handle.py:61-70, 95-148;
