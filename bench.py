@@ -14,10 +14,12 @@ all-reduce north_star names).  The matrix is FIXED as N grows ("scaling": "stron
 One JSON line is printed by rank 0:
   value      whole-job GFLOP/s = 2 * nnz / (max-over-ranks wall time per step), inputs resident
              in HBM before the timed region;
-  roofline   the dominant kernel (spmv_merge_kernel): algorithmic bytes per launch
-             (12 B/nnz + 4 B/row pointer + 8 B/row of y + 8 B/col of x) divided by its
-             mean duration, measured live with hipEvent pairs recorded around that kernel on
-             its launch stream during the timed steps (csrk_spmv_profile_begin/end);
+  roofline   the slowest of the SpMV's streaming kernels (light merge-path kernel, panel tier 0,
+             panel tier 1: DESIGN.md section 4): that kernel's own algorithmic bytes per launch
+             (12 B per entry it processes + its row pointers / partials + x once) divided by its
+             mean duration, measured live with hipEvent pairs recorded around that kernel on its
+             launch stream during the timed steps (csrk_spmv_profile_begin/end); `all_kernels`
+             lists every kernel, `hbm_gbs_end_to_end` is 2.60 GB / step time;
              peak = 8000 GB/s (HBM3E spec); traffic = per-launch HBM bytes from the committed
              rocprofv3 PMC summary (profiles/), or null;
   cpu_baseline  the oracle's sequential restatement of the reference loop (oracle/csr_oracle.c,
@@ -63,8 +65,9 @@ def load_traffic(path, workload, kernel):
         try:
             with open(p) as f:
                 d = json.load(f)
-            if d.get('workload') == workload and kernel in d.get('hbm_bytes_per_launch', {}):
-                return float(d['hbm_bytes_per_launch'][kernel])
+            key = kernel.split(':')[0]           # 'spmv_panel_kernel<tier0: ...>' -> 'spmv_panel_kernel<tier0'
+            if d.get('workload') == workload and key in d.get('hbm_bytes_per_launch', {}):
+                return float(d['hbm_bytes_per_launch'][key])
         except (OSError, ValueError):
             continue
     return None

@@ -24,7 +24,10 @@ def pmc(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(f'{src}/{d}/*/*_counter_collection.csv'))):
         if 'csrk::spmv' in r['Kernel_Name'] or 'csrk::panel' in r['Kernel_Name']:
-            name = r['Kernel_Name'].split('csrk::')[1].split('(')[0].split('<')[0]
+            full = r['Kernel_Name'].split('csrk::')[1].split('(')[0]
+            name = full.split('<')[0]
+            if name == 'spmv_panel_kernel':      # two instantiations: tier 0 (LDS window), tier 1 (L2 window)
+                name += '<tier0' if ', true>' in full else '<tier1'
             agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 allc = {}
