@@ -93,12 +93,19 @@ def main():
         sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: no GPU is visible (the product has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    check(lib.csrk_set_device(local_rank))
+    # BENCH_TEST_SHARE_GPU=1 (plumbing test on a 1-GPU box only): all ranks use GPU 0 over gloo, because
+    # RCCL refuses two ranks on one device.  Never set by the driver.
+    share = os.environ.get('BENCH_TEST_SHARE_GPU') == '1'
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    check(lib.csrk_set_device(dev_index))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     nrows = ncols = int(round(10_000_000 * args.scale))
     nnz = int(round(200_000_000 * args.scale))
@@ -129,6 +136,7 @@ def main():
         op.step(x)
     barrier()
     check(lib.csrk_spmv_profile_begin(h, args.steps))
+    op.timing = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = op.step(x)
@@ -136,10 +144,11 @@ def main():
     elapsed = time.perf_counter() - t0
     n_rec, k_ms2 = C.c_int(0), (C.c_float * 3)(0.0, 0.0, 0.0)
     check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
+    compute_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, op.compute_ms()], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, compute_ms = float(t[0].item()), float(t[1].item())
 
     algo_name = lib.csrk_spmv_algo_name(h).decode()
     n_tiles, tile_items = C.c_int64(0), C.c_int32(0)
@@ -192,6 +201,11 @@ def main():
         'roofline': roofline,
         'gen_seconds': round(t_gen, 2),
     }
+    if compute_ms is not None:
+        # per step: the slowest rank's local SpMV (device events) and what the exchange adds on top
+        out['multi_gpu'] = {'local_spmv_ms_max_over_ranks': round(compute_ms, 4),
+                            'exchange_ms': round(ms_per_step - compute_ms, 4),
+                            'kernel_only_gflops': round(2.0 * nnz / (compute_ms * 1e-3) / 1e9, 1) if compute_ms > 0 else None}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O       # the checker / baseline, never the thing measured above

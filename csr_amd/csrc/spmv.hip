@@ -306,8 +306,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
         for (int u = 0; u < MERGE_PAIRS; u++) {
             const int k = 2 * (tid + u * MERGE_THREADS);
             load_pair_clamped<VT>(ci, vs, ja + k, ja, nn, nnz_total - 2, c0[u], c1[u], p0[u], p1[u]);
-            p0[u] = k < nn ? p0[u] : 0.0;
-            p1[u] = k + 1 < nn ? p1[u] : 0.0;
         }
     } else {
         // a heavy row was cut out somewhere inside this tile: per-entry shift (rare tiles)
@@ -347,8 +345,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     // entries that would hit in L1 are evicted between uses (measured: tools/probe notes in DESIGN.md).
 #pragma unroll
     for (int u = 0; u < MERGE_PAIRS; u++) {
-        p0[u] *= x[c0[u]];        // masked entries hold a valid column and a zero value
-        p1[u] *= x[c1[u]];
+        // Lanes past the tile's end hold a valid (neighbouring) entry; they are zeroed AFTER the
+        // multiply -- 0 * x[c] would be NaN for a non-finite x[c] -- with a select, not a branch.
+        const int k = 2 * (tid + u * MERGE_THREADS);
+        const double t0 = p0[u] * x[c0[u]], t1 = p1[u] * x[c1[u]];
+        p0[u] = k < nn ? t0 : 0.0;
+        p1[u] = k + 1 < nn ? t1 : 0.0;
         if ((u + 1) % MERGE_GATHER_PAIRS == 0 && u + 1 < MERGE_PAIRS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -685,8 +687,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
         {                                                                                             \
             const int k = 2 * (tid + u * MERGE_THREADS);                                              \
             load_pair_clamped<CSRK_VAL_F64>(pci, pvs, j0_ + k, j0_, nn_, pnnz - 2, c0[u], c1[u], p0[u], p1[u]); \
-            p0[u] = k < nn_ ? p0[u] : 0.0;                                                            \
-            p1[u] = k + 1 < nn_ ? p1[u] : 0.0;                                                        \
             if (WINDOW) {                                                                             \
                 c0[u] = k < nn_ ? c0[u] : w0;                                                         \
                 c1[u] = k + 1 < nn_ ? c1[u] : w0;                                                     \
@@ -714,8 +714,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
 #pragma unroll
         for (int u = 0; u < MERGE_PAIRS; u++) {
             const int k = 2 * (tid + u * MERGE_THREADS);
-            p0[u] *= WINDOW ? s_x[c0[u] - w0] : x[c0[u]];
-            p1[u] *= WINDOW ? s_x[c1[u] - w0] : x[c1[u]];
+            const double t0 = p0[u] * (WINDOW ? s_x[c0[u] - w0] : x[c0[u]]);
+            const double t1 = p1[u] * (WINDOW ? s_x[c1[u] - w0] : x[c1[u]]);
+            p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
+            p1[u] = k + 1 < nn ? t1 : 0.0;
         }
 
         if (nr == 0) {

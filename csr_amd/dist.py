@@ -38,18 +38,38 @@ class RowPartitionedSpMV:
         self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
         self.lens = [self.bounds[g + 1] - self.bounds[g] for g in range(world)]
         self.y = torch.zeros(self.nrows, dtype=torch.float64, device=device)
+        self.timing = False            # set True to record device events around the local product
+        self._ev = []
         if world > 1 and mode == 'allgather':
             self.maxlen = max(self.lens)
             self.loc = torch.zeros(self.maxlen, dtype=torch.float64, device=device)
             self.gath = torch.zeros(world * self.maxlen, dtype=torch.float64, device=device)
 
+    def _local(self, x, out):
+        if self.timing and out.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.local_spmv(x, out)
+            e1.record()
+            self._ev.append((e0, e1))
+        else:
+            self.local_spmv(x, out)
+
+    def compute_ms(self):
+        "mean device time of the local product over the steps timed so far (call after a synchronize)"
+        if not self._ev:
+            return 0.0
+        ms = sum(a.elapsed_time(b) for a, b in self._ev) / len(self._ev)
+        self._ev = []
+        return ms
+
     def step(self, x):
         "y = A x, complete on every rank; returns the (reused) y tensor"
         if self.world == 1:
-            self.local_spmv(x, self.y)
+            self._local(x, self.y)
             return self.y
         if self.mode == 'allgather':
-            self.local_spmv(x, self.loc[:self.r1 - self.r0])
+            self._local(x, self.loc[:self.r1 - self.r0])
             dist.all_gather_into_tensor(self.gath, self.loc, group=self.group)
             for g in range(self.world):
                 if self.lens[g]:
@@ -61,7 +81,7 @@ class RowPartitionedSpMV:
             self.y[:self.r0].zero_()
         if self.r1 < self.nrows:
             self.y[self.r1:].zero_()
-        self.local_spmv(x, self.y[self.r0:self.r1])
+        self._local(x, self.y[self.r0:self.r1])
         dist.all_reduce(self.y, op=dist.ReduceOp.SUM, group=self.group)
         return self.y
 

@@ -190,3 +190,55 @@ def test_spmv_sharded_caller(golden):
         assert hits > 5
     finally:
         K.max_nnz = save
+
+
+def test_spmv_nonfinite_propagation():
+    """
+    inf / NaN in x or in the values must reach exactly the rows the reference's loop lets them reach
+    (masked lanes of a tile must not turn 0 * inf into NaN for a neighbouring row).
+    """
+    from oracle import oracle as O
+    rng = np.random.default_rng(99)
+    lens = rng.integers(0, 12, size=6000)
+    lens[100] = 5000          # tier 0 row
+    lens[200] = 300           # tier 1 row
+    lens[-1] = 3              # last row: the final, partly filled tile
+    m = _random_csr(rng, 6000, 20000, lens, sort=True)
+    x = rng.uniform(-1, 1, size=m.ncols)
+    x[17] = np.inf
+    x[4000] = -np.inf
+    x[9000] = np.nan
+    x[int(m.colinds[-1])] = np.inf          # the matrix's very last entry gathers an inf
+    m.values[5] = np.nan
+    with np.errstate(all='ignore'):
+        ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+        for algo in ALGOS:
+            y = _mult_vec(m, x, algo)
+            assert np.array_equal(np.isnan(y), np.isnan(ref)), algo
+            assert np.array_equal(np.isposinf(y), np.isposinf(ref)) and np.array_equal(np.isneginf(y), np.isneginf(ref)), algo
+            fin = np.isfinite(ref)
+            assert np.allclose(y[fin], ref[fin], rtol=1e-9, atol=1e-12), algo
+
+
+def test_plan_stats_and_cache_trim():
+    "csrk_spmv_plan_stats reports the tiers; csrk_trim_cache returns the pool to the driver"
+    import ctypes as C
+    from csr_amd._lib import lib, check
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 10, size=4000)
+    lens[7] = 4000
+    lens[9] = 500
+    m = _random_csr(rng, 4000, 30000, lens, sort=True)
+    h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False))
+    try:
+        K.mult_vec(h, np.ones(m.ncols))
+        st = (C.c_int64 * 16)()
+        check(lib.csrk_spmv_plan_stats(h.H, st, 16))
+        assert st[2] == 2                      # two rows cut out of the tile path
+        assert st[10] == 4000 and st[13] == 500    # tier-0 / tier-1 entries
+        assert st[3] == m.nnz - 4500
+    finally:
+        K.release_handle(h)
+    check(lib.csrk_trim_cache())
