@@ -1008,7 +1008,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
             out.push_back(gq);
         }
     };
-    if (!xcd_streams) {
+    if (!xcd_streams || nb < 2 * HEAVY_STREAMS) {      // too few blocks to keep all 8 XCDs busy per stream
         for (int32_t b = 0; b < nb; b++) block_groups(b, groups);
     } else {
         std::vector<PanelGroup> st[HEAVY_STREAMS];
@@ -1054,6 +1054,10 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     const bool tier1 = allow_tier1 && TIERB_MIN > 0 && TIERB_MIN < HEAVY_MIN;
     const int cut_min = tier1 ? TIERB_MIN : HEAVY_MIN;
     if (m->nrows == 0 || m->nnz < cut_min) return CSRK_OK;
+    // The split pays for itself only when x does not fit in an XCD's 4 MiB L2: otherwise every gather
+    // is an L2 hit already and the panels only add (block, row) overhead (MovieLens-25M shape, x = 472 KB:
+    // 0.146 ms on the single merge path against 0.176-0.53 ms split; measured).  CSRK_SPMV_HEAVY_SPLIT=1 forces it.
+    if ((int64_t)m->ncols * 8 <= (4ll << 20) && !(env && env[0] == '1')) return CSRK_OK;
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nr = m->nrows;
     const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);

@@ -18,6 +18,20 @@ pytestmark = pytest.mark.gpu
 ALGOS = ['merge', 'vector', 'scalar']
 
 
+@pytest.fixture(autouse=True, params=['auto', 'forced_split'])
+def split_mode(request, monkeypatch):
+    """
+    Every test runs twice: with the library's own choice (small test matrices have an x that fits in
+    L2, so the long-row split stays off) and with the split forced on, so the panel tiers are
+    exercised on every shape.
+    """
+    if request.param == 'forced_split':
+        monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
+    else:
+        monkeypatch.delenv('CSRK_SPMV_HEAVY_SPLIT', raising=False)
+    return request.param
+
+
 def _abs_bound(m, x):
     from oracle import oracle as O
     vs = None if m.values is None else np.abs(m.values.astype(np.float64))
@@ -220,8 +234,10 @@ def test_spmv_nonfinite_propagation():
             assert np.allclose(y[fin], ref[fin], rtol=1e-9, atol=1e-12), algo
 
 
-def test_plan_stats_and_cache_trim():
+def test_plan_stats_and_cache_trim(split_mode):
     "csrk_spmv_plan_stats reports the tiers; csrk_trim_cache returns the pool to the driver"
+    if split_mode != 'forced_split':
+        pytest.skip('x of this small matrix fits in L2: no split unless forced')
     import ctypes as C
     from csr_amd._lib import lib, check
     from csr_amd.kernels import hip as K
