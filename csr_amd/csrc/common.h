@@ -113,8 +113,8 @@ struct Matrix {
     std::mutex mu;                 // serialises plan construction and host-API scratch use
     SpmvPlan *spmv_plan = nullptr;
     int spmv_algo = CSRK_SPMV_AUTO;
+    int spmv_calls = 0;            // SpMV launches on this handle (the long-row split is built on the 2nd)
     SpmmPlan *spmm_plan = nullptr;
-    DevBuf scratch_x, scratch_y;   // staging for the host-pointer entry points
 
     size_t ptr_bytes() const { return ptr64 ? 8 : 4; }
     size_t val_bytes() const { return val_type == CSRK_VAL_F64 ? 8 : (val_type == CSRK_VAL_F32 ? 4 : 0); }

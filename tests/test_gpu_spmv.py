@@ -258,3 +258,64 @@ def test_plan_stats_and_cache_trim(split_mode):
     finally:
         K.release_handle(h)
     check(lib.csrk_trim_cache())
+
+
+def test_lazy_split_on_second_call(split_mode):
+    """
+    Auto mode builds the long-row split on the SECOND launch on a handle (the reference's
+    CSR.mult_vec makes a handle per call and must not pay for the plan): first result from the single
+    merge path, later ones from the tiered kernels, all within tolerance of the oracle.
+    """
+    import ctypes as C
+    from oracle import oracle as O
+    from csr_amd._lib import lib, check
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(77)
+    lens = rng.integers(0, 9, size=5000)
+    lens[[3, 900, 4999]] = [6000, 2500, 700]
+    m = _random_csr(rng, 5000, 700000, lens, sort=True)       # x = 5.6 MB > L2: split eligible
+    x = rng.uniform(-1, 1, size=m.ncols)
+    ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+    bound = _abs_bound(m, x)
+    h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False))
+    try:
+        ys, cut = [], []
+        for _ in range(3):
+            ys.append(K.mult_vec(h, x))
+            st = (C.c_int64 * 16)()
+            check(lib.csrk_spmv_plan_stats(h.H, st, 16))
+            cut.append(int(st[2]))
+        for y in ys:
+            _check(y, ref, bound)
+        assert np.array_equal(ys[1], ys[2])
+        assert cut[1] == 3 and cut[2] == 3        # rows 3, 900, 4999 are in panels from the 2nd call on
+    finally:
+        K.release_handle(h)
+
+
+def test_concurrent_calls_on_one_handle():
+    "the reference's kernels are nogil: several Python threads may multiply with the same handle"
+    import threading
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(3)
+    m = _random_csr(rng, 20000, 5000, rng.integers(0, 30, size=20000))
+    h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False))
+    xs = [rng.uniform(-1, 1, size=m.ncols) for _ in range(8)]
+    refs = [O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x) for x in xs]
+    outs = [None] * 8
+    try:
+        K.mult_vec(h, xs[0])
+
+        def work(i):
+            for _ in range(5):
+                outs[i] = K.mult_vec(h, xs[i])
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    finally:
+        K.release_handle(h)
+    for y, r in zip(outs, refs):
+        assert np.allclose(y, r, rtol=1e-12, atol=1e-12)
