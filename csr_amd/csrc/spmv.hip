@@ -1193,9 +1193,9 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
 }
 
 // `launching`: the call is an SpMV launch (counts towards the lazy split), not a query.
-static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out, bool launching = false)
+// Caller holds m->mu.
+static int get_plan_locked(Matrix *m, hipStream_t s, SpmvPlan **out, bool launching)
 {
-    std::lock_guard<std::mutex> lk(m->mu);
     if (launching) m->spmv_calls++;
     // The long-row split costs ~25 ms and 2.4 GB on the headline matrix and pays back ~1.4 ms per
     // SpMV, so it is built on the SECOND launch on a handle: the reference's CSR.mult_vec makes a
@@ -1233,6 +1233,12 @@ static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out, bool launching = f
     }
     *out = m->spmv_plan;
     return CSRK_OK;
+}
+
+static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
+{
+    std::lock_guard<std::mutex> lk(m->mu);
+    return get_plan_locked(m, s, out, false);
 }
 
 template <class P, int VT>
@@ -1340,8 +1346,13 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 
 static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s)
 {
+    // One SpMV = several kernels that share the plan's carry / partial arrays.  The per-handle lock keeps
+    // the launch group together so that concurrent callers (the reference's kernels are nogil) are
+    // ordered by the stream instead of interleaving.  Calls on one handle with DIFFERENT streams must
+    // not overlap in time (same contract as any plan-owning library).
+    std::lock_guard<std::mutex> lk(m->mu);
     SpmvPlan *p = nullptr;
-    CSRK_TRY(get_plan(m, s, &p, true));
+    CSRK_TRY(get_plan_locked(m, s, &p, true));
 #define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
