@@ -6,13 +6,15 @@
 // The reference is a two-pass row-by-row algorithm with a dense marker/work row.  The GPU
 // version keeps the two passes (symbolic count -> exclusive scan -> numeric fill) but gives
 // every output row its own accumulator so rows run in parallel:
+//   * rows with <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or
+//     256-slot hash table in LDS, rank sort;
 //   * rows whose product count (sum over A_i of |B_j|) is <= 1024: one 256-thread workgroup
 //     per row, open-addressing hash table of 2048 slots in LDS (keys by atomicCAS, values by
 //     LDS float64 atomic add); the occupied slots are compacted and bitonic-sorted by column
 //     in LDS, so the output structure is deterministic and ascending;
 //   * heavier rows: a persistent grid of workgroups, each owning a dense float64 work row and
-//     marker row in HBM (the reference's `work` / `index` arrays, multiply.py:62,106), emitted
-//     in ascending column order by a compacting sweep.
+//     marker row in HBM (the reference's `work` / `index` arrays, multiply.py:62,106); touched
+//     columns are listed as they are first marked, the list is bitonic-sorted, the sums gathered.
 // Like the reference, entries that cancel to exactly 0.0 are KEPT (csr/csr.py:555 filters
 // them afterwards) and C's row pointers are int32 (multiply.py:28).
 // Column order inside a row is ascending here; the reference's order (reverse discovery) is
@@ -50,6 +52,7 @@ static MatView view_of(const Matrix *m)
 constexpr int SG_THREADS = 256;
 constexpr int SG_SLOTS = 2048;
 constexpr int SG_CAP = 1024;      // max products for the LDS hash path (load factor <= 0.5)
+constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take the wave-per-row kernels
 
 // products per output row: ub[i] = sum_{j in A_i} |B_j|
 __global__ void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub)
@@ -85,11 +88,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
     __shared__ int32_t s_n;
     const int i = blockIdx.x, tid = threadIdx.x;
     const int64_t u = ub[i];
-    if (u > SG_CAP) return;             // dense path
-    if (u == 0) {
-        if (!NUMERIC && tid == 0) cnt[i] = 0;
-        return;
-    }
+    if (u > SG_CAP || u <= SG_WAVE_CAP) return;   // dense path / wave-per-row path
     for (int s = tid; s < SG_SLOTS; s += SG_THREADS) {
         s_key[s] = -1;
         if (NUMERIC) s_val[s] = 0.0;
@@ -181,23 +180,138 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
     }
 }
 
-// Persistent workgroups for rows with ub > SG_CAP: dense work/marker rows in HBM.
+// One WAVEFRONT per output row for rows with lo < ub <= hi products (hi <= SLOTS / 2): a 256-thread
+// workgroup serves four rows, each with a private SLOTS-entry hash table in LDS.  A workgroup-per-row
+// launch with a 2048-slot table costs ~20 us of fixed work (clear, compact, sort) however few products
+// the row has; most rows of a sparse product have a handful.
+template <int SLOTS, bool NUMERIC>
+__global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub, int lo, int hi,
+                                                     int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
+                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+{
+    constexpr int WPB = 256 / WAVE;
+    __shared__ int32_t s_key[WPB][SLOTS];
+    __shared__ double s_val[NUMERIC ? WPB : 1][NUMERIC ? SLOTS : 1];
+    __shared__ int32_t s_ck[NUMERIC ? WPB : 1][NUMERIC ? SLOTS / 2 : 1];
+    __shared__ double s_cv[NUMERIC ? WPB : 1][NUMERIC ? SLOTS / 2 : 1];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int64_t i = (int64_t)blockIdx.x * WPB + w;
+    const int64_t u = i < a.nrows ? ub[i] : 0;
+    const bool mine = u > lo && u <= hi;          // wave-uniform; every wave still reaches the barriers
+    for (int sl = lane; sl < SLOTS; sl += WAVE) {
+        s_key[w][sl] = -1;
+        if (NUMERIC) s_val[w][sl] = 0.0;
+    }
+    __syncthreads();
+    int found = 0;
+    if (mine) {
+        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        for (int64_t jj = as; jj < ae; jj++) {
+            const int32_t j = a.ci[jj];
+            const double av = NUMERIC ? val_at(a, jj) : 0.0;
+            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
+            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
+                const int32_t k = b.ci[kk];
+                uint32_t slot = ((uint32_t)k * 2654435761u) & (SLOTS - 1);
+                for (;;) {
+                    int32_t old = atomicCAS(&s_key[w][slot], -1, k);
+                    if (old == -1 || old == k) {
+                        if (NUMERIC) atomicAdd(&s_val[w][slot], av * val_at(b, kk));
+                        else if (old == -1) found++;
+                        break;
+                    }
+                    slot = (slot + 1) & (SLOTS - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!NUMERIC) {
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) found += __shfl_down(found, off, WAVE);
+        if (mine && lane == 0) cnt[i] = found;
+        return;
+    }
+    // compact the occupied slots, then rank-sort by column (keys are unique)
+    int n = 0;
+    for (int s0 = 0; s0 < SLOTS; s0 += WAVE) {
+        const int32_t k = s_key[w][s0 + lane];
+        const bool occ = mine && k != -1;
+        const unsigned long long bal = __ballot(occ);
+        if (occ) {
+            const int o = n + __popcll(bal & ((1ull << lane) - 1ull));
+            s_ck[w][o] = k;
+            s_cv[w][o] = s_val[w][s0 + lane];
+        }
+        n += __popcll(bal);
+    }
+    __syncthreads();
+    if (mine) {
+        const int32_t o0 = c_rp[i];
+        for (int t = lane; t < n; t += WAVE) {
+            const int32_t kt = s_ck[w][t];
+            int rank = 0;
+            for (int q = 0; q < n; q++) rank += s_ck[w][q] < kt;
+            c_ci[o0 + rank] = kt;
+            c_vs[o0 + rank] = s_cv[w][t];
+        }
+    }
+}
+
+// Persistent workgroups for rows with ub > SG_CAP: dense work/marker rows in HBM (the reference's
+// `work` / `index` arrays).  The columns a row touches are appended to a list as they are first
+// marked; the list is sorted -- bitonic network, in LDS up to SG_LSORT entries, otherwise in a padded
+// global scratch buffer -- and the sums are gathered through it.  (A first version swept the whole
+// dense row instead: O(ncols) per row, 37 of the 45 ms of a 200k x 200k product.)
+constexpr int SG_LSORT = 8192;
+
+// ascending bitonic sort of p[0..np2) (np2 a power of two) by the whole workgroup
+__device__ inline void wg_bitonic(int32_t *p, int np2, int tid)
+{
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < np2 / 2; t += SG_THREADS) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int32_t kl = p[lo], kh = p[hi];
+                if ((kl > kh) == up && kl != kh) {
+                    p[lo] = kh;
+                    p[hi] = kl;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
 template <bool NUMERIC>
 __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                              int32_t n_large, double *__restrict__ work_all,
-                                                             int32_t *__restrict__ mark_all, int32_t *__restrict__ cnt,
+                                                             int32_t *__restrict__ mark_all, int32_t *__restrict__ scratch_all,
+                                                             int64_t scratch_len, int32_t *__restrict__ cnt,
                                                              const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
                                                              double *__restrict__ c_vs)
 {
     __shared__ int32_t s_n;
     __shared__ int32_t s_wsum[SG_THREADS / WAVE];
+    __shared__ int32_t s_sort[NUMERIC ? SG_LSORT : 1];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int32_t nc = b.ncols;
     double *work = work_all + (int64_t)blockIdx.x * nc;
     int32_t *mark = mark_all + (int64_t)blockIdx.x * nc;
+    int32_t *scratch = NUMERIC ? scratch_all + (int64_t)blockIdx.x * scratch_len : nullptr;
     for (int q = blockIdx.x; q < n_large; q += gridDim.x) {
         const int i = list[q];
         const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        const int32_t base = NUMERIC ? c_rp[i] : 0;
+        const int32_t n_out = NUMERIC ? c_rp[i + 1] - base : 0;
+        // where the touched-column list is collected and sorted
+        int32_t *lst = NUMERIC ? (n_out <= SG_LSORT ? s_sort : scratch) : nullptr;
+        // nearly full row: an ascending compaction sweep over the dense row costs O(ncols) ~ O(n) and
+        // beats list + sort (MovieLens-shaped A B^T blocks); sparse rows list and sort
+        const bool sweep = NUMERIC && (int64_t)n_out * 8 >= nc;
         if (tid == 0) s_n = 0;
         __syncthreads();
         for (int64_t jj = as + w; jj < ae; jj += SG_THREADS / WAVE) {
@@ -206,11 +320,12 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
             const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
             for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
                 const int32_t k = b.ci[kk];
-                if (NUMERIC) {
-                    atomicAdd(&work[k], av * val_at(b, kk));
-                    mark[k] = 1;
+                if (NUMERIC) atomicAdd(&work[k], av * val_at(b, kk));
+                if (NUMERIC && sweep) {
+                    mark[k] = 1;                       // the sweep only needs the marker
                 } else if (atomicExch(&mark[k], 1) == 0) {
-                    atomicAdd(&s_n, 1);
+                    const int o = atomicAdd(&s_n, 1);
+                    if (NUMERIC) lst[o] = k;
                 }
             }
         }
@@ -227,31 +342,49 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
             __syncthreads();
             continue;
         }
-        // ascending compaction sweep over the dense row; resets work/mark as it goes
-        int base = c_rp[i];
-        for (int32_t k0 = 0; k0 < nc; k0 += SG_THREADS) {
-            const int32_t k = k0 + tid;
-            // agent-scope loads: the sums were formed by L2 atomics, which do not update this CU's L1
-            const bool occ = k < nc && __hip_atomic_load(&mark[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            const unsigned long long bal = __ballot(occ);
-            const int below = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wsum[w] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, tot = 0;
+        if (sweep) {
+            int pos = base;
+            for (int32_t k0 = 0; k0 < nc; k0 += SG_THREADS) {
+                const int32_t k = k0 + tid;
+                const bool occ = k < nc && __hip_atomic_load(&mark[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                const unsigned long long bal = __ballot(occ);
+                const int below = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wsum[w] = __popcll(bal);
+                __syncthreads();
+                int woff = 0, tot = 0;
 #pragma unroll
-            for (int t = 0; t < SG_THREADS / WAVE; t++) {
-                if (t < w) woff += s_wsum[t];
-                tot += s_wsum[t];
+                for (int t = 0; t < SG_THREADS / WAVE; t++) {
+                    if (t < w) woff += s_wsum[t];
+                    tot += s_wsum[t];
+                }
+                if (occ) {
+                    c_ci[pos + woff + below] = k;
+                    c_vs[pos + woff + below] = __hip_atomic_load(&work[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    work[k] = 0.0;
+                    mark[k] = 0;
+                }
+                pos += tot;
+                __syncthreads();
             }
-            if (occ) {
-                c_ci[base + woff + below] = k;
-                c_vs[base + woff + below] = __hip_atomic_load(&work[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                work[k] = 0.0;
-                mark[k] = 0;
-            }
-            base += tot;
-            __syncthreads();
+            continue;
         }
+        const int n = s_n;                    // == n_out (same products as the symbolic pass)
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int t = n + tid; t < np2; t += SG_THREADS) lst[t] = 0x7fffffff;
+        __threadfence_block();
+        __syncthreads();
+        wg_bitonic(lst, np2, tid);
+        for (int t = tid; t < n; t += SG_THREADS) {
+            const int32_t k = lst[t];
+            c_ci[base + t] = k;
+            // agent-scope load: the sum was formed by L2 atomics, which do not update this CU's L1
+            c_vs[base + t] = __hip_atomic_load(&work[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            work[k] = 0.0;
+            mark[k] = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -262,7 +395,9 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
                  "mult_ab needs values on both operands (csr/kernels/numba/multiply.py:115,120)");
     const int32_t nr = a->nrows;
     MatView av = view_of(a), bv = view_of(b);
-    DevBuf ub, cnt, list, nl, work, mark;
+    DevBuf ub, cnt, list, nl, work, mark, scratch;
+    int64_t scratch_len = 1;
+    while (scratch_len < (int64_t)b->ncols) scratch_len <<= 1;     // padded length for the bitonic network
     CSRK_TRY(ub.alloc((size_t)(nr + 1) * 8));
     CSRK_TRY(cnt.alloc((size_t)(nr + 1) * 4));
     CSRK_TRY(list.alloc((size_t)(nr + 1) * 4));
@@ -279,22 +414,29 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipMemcpy(&n_large, nl.p, 4, hipMemcpyDeviceToHost));
         if (n_large > 0) {
-            const int64_t per = (int64_t)b->ncols * 12;
+            const int64_t per = (int64_t)b->ncols * 12 + scratch_len * 4;
             int64_t g_max = (4ll << 30) / (per > 0 ? per : 1);
             if (g_max < 1) g_max = 1;
             grid_dense = (int)(n_large < 256 ? n_large : 256);
             if (grid_dense > g_max) grid_dense = (int)g_max;
             CSRK_TRY(work.alloc((size_t)grid_dense * b->ncols * 8));
             CSRK_TRY(mark.alloc((size_t)grid_dense * b->ncols * 4));
+            CSRK_TRY(scratch.alloc((size_t)grid_dense * scratch_len * 4));
             CSRK_HIP(hipMemset(work.p, 0, work.bytes));
             CSRK_HIP(hipMemset(mark.p, 0, mark.bytes));
         }
-        // symbolic
+        // symbolic (rows with no products keep the zero count of the memset)
+        const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
+        sg_wave_kernel<64, false><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        CSRK_LAUNCH_CHECK();
+        sg_wave_kernel<256, false><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        CSRK_LAUNCH_CHECK();
         sg_hash_kernel<false><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
         if (n_large > 0) {
             sg_dense_kernel<false><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
-                                                              mark.as<int32_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+                                                              mark.as<int32_t>(), nullptr, 0, cnt.as<int32_t>(), nullptr,
+                                                              nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
         }
     }
@@ -313,12 +455,17 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
     CSRK_TRY(new_matrix(nr, b->ncols, c_nnz, 0, CSRK_VAL_F64, &c));
     int rc = exclusive_scan_i32(cnt.as<int32_t>(), (int32_t *)c->d_rowptrs, nr, nullptr);
     if (rc == CSRK_OK && nr > 0 && c_nnz > 0) {
+        const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
+        sg_wave_kernel<64, true><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
+                                              c->d_colinds, (double *)c->d_values);
+        sg_wave_kernel<256, true><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, nullptr,
+                                               (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
         sg_hash_kernel<true><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
                                                          c->d_colinds, (double *)c->d_values);
         if (n_large > 0)
             sg_dense_kernel<true><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
-                                                             mark.as<int32_t>(), nullptr, (const int32_t *)c->d_rowptrs,
-                                                             c->d_colinds, (double *)c->d_values);
+                                                             mark.as<int32_t>(), scratch.as<int32_t>(), scratch_len, nullptr,
+                                                             (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
     }
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipGetLastError();
