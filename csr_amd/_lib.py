@@ -71,6 +71,7 @@ SIGNATURES = {
     'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),
     'csrk_spmm_dense_device': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64, _vp]),
+    'csrk_from_coo': (_int, [_i32, _i32, _i64, _vp, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_transpose': (_int, [handle_t, _int, C.POINTER(handle_t)]),
     'csrk_row_nnzs': (_int, [handle_t, _vp]),
     'csrk_row_extent': (_int, [handle_t, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

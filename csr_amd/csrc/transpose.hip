@@ -77,9 +77,11 @@ __device__ __forceinline__ int32_t row_of(const P *__restrict__ rp, int64_t i, i
 }
 
 // ---- radix pass: stable scatter --------------------------------------------------------------
-// FIRST: records come from the CSR arrays (keys = colinds, row ids from rowptrs, values from
-//        the matrix, any dtype).  VT = value type of the INPUT of this pass (CSRK_VAL_NONE =
-//        structure only).  keys_out may be NULL.
+// MODE 1: first pass of a transpose -- records come from the CSR arrays (keys = colinds, row ids
+//         recovered from rowptrs, values from the matrix in dtype VT).
+// MODE 2: first pass of a COO ingest -- keys, payload and values (dtype VT) are given arrays.
+// MODE 0: later pass -- keys, payload, float64 values from the previous pass.
+// VT = CSRK_VAL_NONE: structure only.  keys_out may be NULL.
 //
 // A record's slot inside its chunk's output is  loff[digit] + (records of that digit placed by
 // earlier rounds / earlier wavefronts / lower lanes)  -- stable by construction.  The chunk is first
@@ -87,7 +89,7 @@ __device__ __forceinline__ int32_t row_of(const P *__restrict__ rp, int64_t i, i
 // addresses: a direct scatter issues one 4-8-byte write request per record and array and runs at the
 // chip's request rate (~24 ps per record measured), whereas runs of equal digits (16 records on
 // average) coalesce into full-line writes.
-template <class P, int VT, bool FIRST>
+template <class P, int VT, int MODE>
 __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     const int32_t *__restrict__ keys_in, const int32_t *__restrict__ rows_in, const void *__restrict__ vals_in,
     const P *__restrict__ rp, int32_t nrows, int64_t n, int shift, int64_t n_chunks,
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     double *__restrict__ vals_out)
 {
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
+    constexpr bool FIRST = MODE == 1;
     __shared__ int64_t s_goff[256];               // global offset of this chunk's run per digit
     __shared__ int32_t s_loff[256];               // offset of the digit's run inside the chunk
     __shared__ int32_t s_run[256];                // records of each digit already placed
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
             else val[r] = 0.0;
         } else {
             row[r] = rows_in[i];
-            val[r] = HAS_V ? ((const double *)vals_in)[i] : 0.0;
+            if (MODE == 2 && VT == CSRK_VAL_F32) val[r] = (double)((const float *)vals_in)[i];
+            else val[r] = HAS_V ? ((const double *)vals_in)[i] : 0.0;
         }
     }
     __syncthreads();                                  // FIRST: everyone has read its rows out of s_row
@@ -245,69 +249,75 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     }
 }
 
-template <class P, int VT>
-static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
+// Stable sort of n records by a key in [0, key_range): payload (int32) -> out_payload, values (widened
+// to float64) -> out_vals, and the run starts of every key -> out_ptr[0..key_range].  FROM_CSR: the records
+// are the entries of a CSR matrix (keys = its colinds, payload = the entry's row, from `rp`); otherwise
+// keys / payload / values are the given device arrays (COO ingest).
+template <class P, int VT, bool FROM_CSR>
+static int sort_records(const int32_t *keys, const int32_t *payload, const void *vals, const P *rp, int32_t rp_rows,
+                        int64_t n, int32_t key_range, P *out_ptr, int32_t *out_payload, double *out_vals, hipStream_t s)
 {
-    const P *rp = (const P *)a->d_rowptrs;
-    const int64_t nnz = a->nnz;
-    const int32_t ncols = a->ncols;
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
-
-    if (nnz == 0) {
-        CSRK_HIP(hipMemsetAsync(t->d_rowptrs, 0, (size_t)(ncols + 1) * sizeof(P), s));
+    if (n == 0) {
+        CSRK_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(key_range + 1) * sizeof(P), s));
         CSRK_HIP(hipStreamSynchronize(s));
         return CSRK_OK;
     }
-
     int bits = 0;
-    while (bits < 31 && (1ll << bits) < (int64_t)ncols) bits++;
+    while (bits < 31 && (1ll << bits) < (int64_t)key_range) bits++;
     int passes = bits <= 8 ? 1 : (bits + 7) / 8;
-    const int64_t n_chunks = ceil_div(nnz, RX_CHUNK);
+    const int64_t n_chunks = ceil_div(n, RX_CHUNK);
 
     DevBuf table, keyA, keyB, rowA, rowB, valA, valB, keyL;
     CSRK_TRY(table.alloc((size_t)(256 * n_chunks + 1) * 8));
-    CSRK_TRY(keyL.alloc((size_t)nnz * 4));        // sorted keys of the last pass -> output row pointers
+    CSRK_TRY(keyL.alloc((size_t)n * 4));          // sorted keys of the last pass -> run starts
     if (passes > 1) {
-        CSRK_TRY(keyA.alloc((size_t)nnz * 4));
-        CSRK_TRY(rowA.alloc((size_t)nnz * 4));
-        if (HAS_V) CSRK_TRY(valA.alloc((size_t)nnz * 8));
+        CSRK_TRY(keyA.alloc((size_t)n * 4));
+        CSRK_TRY(rowA.alloc((size_t)n * 4));
+        if (HAS_V) CSRK_TRY(valA.alloc((size_t)n * 8));
     }
     if (passes > 2) {
-        CSRK_TRY(keyB.alloc((size_t)nnz * 4));
-        CSRK_TRY(rowB.alloc((size_t)nnz * 4));
-        if (HAS_V) CSRK_TRY(valB.alloc((size_t)nnz * 8));
+        CSRK_TRY(keyB.alloc((size_t)n * 4));
+        CSRK_TRY(rowB.alloc((size_t)n * 4));
+        if (HAS_V) CSRK_TRY(valB.alloc((size_t)n * 8));
     }
 
-    const int32_t *k_in = a->d_colinds;
-    const int32_t *r_in = nullptr;
-    const void *v_in = a->d_values;
+    const int32_t *k_in = keys;
+    const int32_t *r_in = payload;
+    const void *v_in = vals;
     for (int p = 0; p < passes; p++) {
         const bool first = p == 0, last = p == passes - 1;
         const int shift = 8 * p;
         int32_t *k_out = last ? keyL.as<int32_t>() : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
-        int32_t *r_out = last ? t->d_colinds : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
-        double *v_out = !HAS_V ? nullptr : (last ? (double *)t->d_values : ((p & 1) ? valB.as<double>() : valA.as<double>()));
-        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, nnz, shift, n_chunks, table.as<int64_t>());
+        int32_t *r_out = last ? out_payload : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
+        double *v_out = !HAS_V ? nullptr : (last ? out_vals : ((p & 1) ? valB.as<double>() : valA.as<double>()));
+        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>());
         CSRK_LAUNCH_CHECK();
         CSRK_TRY(exclusive_scan_i64(table.as<int64_t>(), table.as<int64_t>(), 256 * n_chunks, s));
         const unsigned grid = (unsigned)n_chunks;
         constexpr int VMID = HAS_V ? CSRK_VAL_F64 : CSRK_VAL_NONE;   // intermediates are float64
-#define RX_ARGS k_in, r_in, v_in, rp, a->nrows, nnz, shift, n_chunks, table.as<int64_t>(), k_out, r_out, v_out
+#define RX_ARGS k_in, r_in, v_in, rp, rp_rows, n, shift, n_chunks, table.as<int64_t>(), k_out, r_out, v_out
         if (first)
-            rx_scatter_kernel<P, VT, true><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+            rx_scatter_kernel<P, VT, FROM_CSR ? 1 : 2><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
         else
-            rx_scatter_kernel<P, VMID, false><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
+            rx_scatter_kernel<P, VMID, 0><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
 #undef RX_ARGS
         CSRK_LAUNCH_CHECK();
         k_in = k_out;
         r_in = r_out;
         v_in = v_out;
     }
-    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(nnz + 1, 256), 256, 0, s>>>(keyL.as<int32_t>(), nnz, ncols,
-                                                                              (P *)t->d_rowptrs);
+    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(n + 1, 256), 256, 0, s>>>(keyL.as<int32_t>(), n, key_range, out_ptr);
     CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipStreamSynchronize(s));   // temporaries are released on return
+    CSRK_HIP(hipStreamSynchronize(s));   // temporaries go back to the pool on return
     return CSRK_OK;
+}
+
+template <class P, int VT>
+static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
+{
+    return sort_records<P, VT, true>(a->d_colinds, nullptr, a->d_values, (const P *)a->d_rowptrs, a->nrows, a->nnz,
+                                     a->ncols, (P *)t->d_rowptrs, t->d_colinds, (double *)t->d_values, s);
 }
 
 // Transpose `a` into a new matrix.  Exposed to the other translation units (spgemm_abt,
@@ -339,6 +349,78 @@ int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s)
 }  // namespace csrk
 
 using namespace csrk;
+
+__global__ void coo_cast_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];       // exact: the doubles are widened floats
+}
+
+// COO -> CSR: a stable sort of the entries by row is exactly the reference's counting sort
+// (csr/structure.py:11-58: entries of a row keep their input order).
+extern "C" int csrk_from_coo(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t *rows, const int32_t *cols,
+                             const void *values, int val_type, csrk_handle_t *out)
+{
+    CSRK_REQUIRE(out, "out is NULL");
+    *out = 0;
+    CSRK_REQUIRE(nrows >= 0 && ncols >= 0 && nnz >= 0, "negative dimension");
+    CSRK_REQUIRE(nnz == 0 || (rows && cols), "rows / cols is NULL");
+    CSRK_REQUIRE(val_type == CSRK_VAL_NONE || val_type == CSRK_VAL_F32 || val_type == CSRK_VAL_F64, "unknown val_type %d", val_type);
+    CSRK_REQUIRE(val_type == CSRK_VAL_NONE || nnz == 0 || values, "values is NULL but val_type=%d", val_type);
+    const int ptr64 = nnz > INT32_MAX;
+    Matrix *m = nullptr;
+    CSRK_TRY(new_matrix(nrows, ncols, nnz, ptr64, val_type, &m));
+    DevBuf d_rows, d_cols, d_vals, d_v64;
+    int rc = CSRK_OK;
+    const size_t vb = val_type == CSRK_VAL_F64 ? 8 : 4;
+    do {
+        if ((rc = d_rows.alloc((size_t)nnz * 4)) != CSRK_OK) break;
+        if ((rc = d_cols.alloc((size_t)nnz * 4)) != CSRK_OK) break;
+        hipError_t e = hipSuccess;
+        if (nnz) e = hipMemcpy(d_rows.p, rows, (size_t)nnz * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz) e = hipMemcpy(d_cols.p, cols, (size_t)nnz * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && val_type != CSRK_VAL_NONE) {
+            if ((rc = d_vals.alloc((size_t)nnz * vb)) != CSRK_OK) break;
+            if (nnz) e = hipMemcpy(d_vals.p, values, (size_t)nnz * vb, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            set_error("host-to-device copy failed: %s", hipGetErrorString(e));
+            rc = CSRK_ERR_HIP;
+            break;
+        }
+        double *v_out = (double *)m->d_values;
+        if (val_type == CSRK_VAL_F32) {
+            if ((rc = d_v64.alloc((size_t)nnz * 8)) != CSRK_OK) break;
+            v_out = d_v64.as<double>();
+        }
+#define GO(P, VT)                                                                                                    \
+    rc = sort_records<P, VT, false>(d_rows.as<int32_t>(), d_cols.as<int32_t>(), d_vals.p, (const P *)nullptr, 0, nnz,   \
+                                    nrows, (P *)m->d_rowptrs, m->d_colinds, v_out, nullptr)
+        if (ptr64) {
+            if (val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
+            else if (val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
+            else GO(int64_t, CSRK_VAL_NONE);
+        } else {
+            if (val_type == CSRK_VAL_F64) GO(int32_t, CSRK_VAL_F64);
+            else if (val_type == CSRK_VAL_F32) GO(int32_t, CSRK_VAL_F32);
+            else GO(int32_t, CSRK_VAL_NONE);
+        }
+#undef GO
+        if (rc == CSRK_OK && val_type == CSRK_VAL_F32 && nnz) {
+            coo_cast_f64_to_f32<<<(unsigned)ceil_div(nnz, 256), 256>>>(d_v64.as<double>(), (float *)m->d_values, nnz);
+            if (hipDeviceSynchronize() != hipSuccess) {
+                set_error("from_coo value cast failed");
+                rc = CSRK_ERR_HIP;
+            }
+        }
+    } while (0);
+    if (rc != CSRK_OK) {
+        delete m;
+        return rc;
+    }
+    *out = to_handle(m);
+    return CSRK_OK;
+}
 
 extern "C" int csrk_transpose(csrk_handle_t h, int with_values, csrk_handle_t *out)
 {

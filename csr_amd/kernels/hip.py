@@ -149,6 +149,29 @@ def transpose(h, include_values=True):
     return _wrap(out.value)
 
 
+def from_coo(rows, cols, vals, shape):
+    """
+    csr/structure.py:11-67 on the device: COO arrays -> a NEW handle (entries of a row keep their
+    input order, like the reference's counting sort).  `vals` may be None (structure only).
+    """
+    nrows, ncols = (int(v) for v in shape)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    nnz = len(rows)
+    if len(cols) != nnz or (vals is not None and len(vals) != nnz):
+        raise ValueError('rows, cols and vals must have the same length')
+    if nnz and (rows.min() < 0 or rows.max() >= max(nrows, 1) or cols.min() < 0 or cols.max() >= max(ncols, 1)):
+        raise ValueError('COO coordinates out of range')
+    if vals is not None:
+        vals = np.ascontiguousarray(vals)
+        if vals.dtype not in (np.dtype('f4'), np.dtype('f8')):
+            vals = vals.astype(np.float64)
+    out = handle_t(0)
+    check(lib.csrk_from_coo(nrows, ncols, nnz, ptr(rows), ptr(cols), ptr(vals),
+                            _VAL_CODES[None if vals is None else vals.dtype], C.byref(out)))
+    return _wrap(out.value)
+
+
 def row_nnzs(h):
     "csr/csr.py:432-441"
     _, _, _, p64, _ = _info(_live(h))

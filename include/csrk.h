@@ -157,6 +157,14 @@ CSRK_API int csrk_spmm_dense_device(csrk_handle_t a, const double *d_B, int32_t 
  * structure-only input, gives a structure-only result (:241-242).                      */
 CSRK_API int csrk_transpose(csrk_handle_t h, int with_values, csrk_handle_t *out);
 
+/* ---- COO ingest -----------------------------------------------------------------------------
+ * csr/structure.py:11-67 (_from_coo_structure / _from_coo_values / from_coo), the ingest behind
+ * CSR.from_coo (csr/csr.py:138-169).  Host COO arrays -> a NEW device handle.  Entries of a row
+ * keep their input order (the reference's stable counting sort); values keep their dtype; row
+ * pointers are int32 unless nnz > INT32_MAX.  rows[] must lie in [0, nrows), cols[] in [0, ncols). */
+CSRK_API int csrk_from_coo(int32_t nrows, int32_t ncols, int64_t nnz, const int32_t *rows,
+                           const int32_t *cols, const void *values, int val_type, csrk_handle_t *out);
+
 /* ---- row extents / counts ---------------------------------------------------------------
  * csr/_rows.py:9-13 (extent), csr/csr.py:432-441 (row_nnzs = diff(rowptrs)).
  * `out` has nrows entries of the handle's pointer width (int32 or int64).              */

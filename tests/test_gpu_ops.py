@@ -374,3 +374,40 @@ def test_spmm_dense(k):
     assert Cm.shape == ref.shape
     assert np.all(np.abs(Cm - ref) <= 1e-6 * bound + 1e-300)
     assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
+
+
+# ---- COO ingest on the device ----------------------------------------------------------------------------
+
+def test_from_coo_device(golden):
+    "csr/structure.py:11-67: stable by row (entries keep input order), dtype kept; vs the host ingest and the KAT"
+    from csr_amd import CSR
+    from csr_amd.kernels import hip as K
+    g = golden('kat')
+    a = Mat(g, 'a_')
+    h = K.from_coo(np.array([0, 0, 1, 3]), np.array([1, 2, 0, 1]), np.arange(4.0), (4, 3))
+    try:
+        c = K.from_handle(h)
+    finally:
+        K.release_handle(h)
+    assert np.array_equal(c.rowptrs, a.rowptrs) and np.array_equal(c.colinds, a.colinds)
+    assert np.array_equal(c.values, a.values)
+    rng = np.random.default_rng(12)
+    for nrows, ncols, nnz, dt in ((300, 200, 5000, np.float64), (70000, 1000, 200000, np.float32),
+                                  (5, 5, 0, np.float64), (100000, 70000, 300000, None)):
+        rows = rng.integers(0, nrows, size=nnz).astype(np.int32)      # duplicates allowed, unsorted
+        cols = rng.integers(0, ncols, size=nnz).astype(np.int32)
+        vals = None if dt is None else rng.uniform(-1, 1, size=nnz).astype(dt)
+        ref = CSR.from_coo(rows, cols, vals, (nrows, ncols))           # host: stable numpy argsort by row
+        h = K.from_coo(rows, cols, vals, (nrows, ncols))
+        try:
+            c = K.from_handle(h)
+        finally:
+            K.release_handle(h)
+        assert (c.nrows, c.ncols, c.nnz) == (nrows, ncols, nnz)
+        assert np.array_equal(c.rowptrs, ref.rowptrs) and np.array_equal(c.colinds, ref.colinds)
+        if dt is None:
+            assert c.values is None
+        else:
+            assert c.values.dtype == dt and np.array_equal(c.values, ref.values)
+    with pytest.raises(ValueError):
+        K.from_coo(np.array([5]), np.array([0]), None, (3, 3))
