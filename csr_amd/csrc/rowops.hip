@@ -34,18 +34,25 @@ __device__ __forceinline__ double wmax_nan(double v, bool nan)
     return __any(nan) ? __builtin_nan("") : v;   // np.max propagates NaN (transform.py:52)
 }
 
+constexpr int ROW_LONG = 8192;     // rows longer than this get a whole workgroup
+
 template <class T> struct FInfo;
 template <> struct FInfo<double> { static constexpr int maxexp = 1024, minexp = -1022; };
 template <> struct FInfo<float> { static constexpr int maxexp = 128, minexp = -126; };
 
 template <class P, class T>
 __global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
-                                                       T *__restrict__ norms, int32_t nrows)
+                                                       T *__restrict__ norms, int32_t nrows,
+                                                       int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
 {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     if (r >= nrows) return;
     const int64_t sp = rp[r], ep = rp[r + 1];
+    if (ep - sp > ROW_LONG) {             // left to the workgroup-per-row kernel
+        if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
+        return;
+    }
     if (sp == ep) {                       // empty row: norm 0 (transform.py:36-38)
         if (lane == 0) norms[r] = (T)0;
         return;
@@ -80,12 +87,17 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp
 
 template <class P, class T>
 __global__ __launch_bounds__(256) void center_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
-                                                         T *__restrict__ means, int32_t nrows)
+                                                         T *__restrict__ means, int32_t nrows,
+                                                         int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
 {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     if (r >= nrows) return;
     const int64_t sp = rp[r], ep = rp[r + 1];
+    if (ep - sp > ROW_LONG) {
+        if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
+        return;
+    }
     if (sp == ep) {
         if (lane == 0) means[r] = (T)0;
         return;
@@ -97,6 +109,86 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const P *__restrict__ 
     for (int64_t k = sp + lane; k < ep; k += WAVE) vs[k] = vs[k] - m;
 }
 
+// Rows longer than ROW_LONG entries: one 1024-thread workgroup per row (a single wavefront would need
+// ~10^4 serial iterations for the 10^6-entry rows of a power-law matrix).  Block-wide reductions =
+// wavefront shuffles + one LDS stage, in a fixed order: deterministic.
+constexpr int ROW_LONG_THREADS = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double *s_red)
+{
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    __syncthreads();
+    if (lane == 0) s_red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < ROW_LONG_THREADS / WAVE; k++) t += s_red[k];
+    return t;
+}
+
+template <class P, class T, bool UNIT>
+__global__ __launch_bounds__(ROW_LONG_THREADS) void row_stat_long_kernel(const P *__restrict__ rp, T *__restrict__ vs,
+                                                                        T *__restrict__ out,
+                                                                        const int32_t *__restrict__ long_rows)
+{
+    __shared__ double s_red[ROW_LONG_THREADS / WAVE];
+    __shared__ int s_nan;
+    const int32_t r = long_rows[blockIdx.x];
+    const int64_t sp = rp[r], ep = rp[r + 1];
+    const int tid = threadIdx.x;
+    if (!UNIT) {
+        double s = 0.0;
+        for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) s += (double)vs[k];
+        const T m = (T)(block_sum(s, s_red) / (double)(ep - sp));
+        if (tid == 0) out[r] = m;
+        for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) vs[k] = vs[k] - m;
+        return;
+    }
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    double vmax = 0.0;
+    bool nan = false;
+    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
+        double a = fabs((double)vs[k]);
+        nan |= a != a;
+        vmax = a > vmax ? a : vmax;
+    }
+    if (nan) s_nan = 1;
+    // block maximum through the same LDS stage (max is order independent)
+    {
+        const int lane = tid & (WAVE - 1), w = tid / WAVE;
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) {
+            double o = __shfl_down(vmax, off, WAVE);
+            vmax = o > vmax ? o : vmax;
+        }
+        __syncthreads();
+        if (lane == 0) s_red[w] = vmax;
+        __syncthreads();
+        vmax = 0.0;
+        for (int k = 0; k < ROW_LONG_THREADS / WAVE; k++) vmax = s_red[k] > vmax ? s_red[k] : vmax;
+        if (s_nan) vmax = __builtin_nan("");
+    }
+    int ve = 0;
+    if (vmax == vmax && !isinf(vmax)) (void)frexp(vmax, &ve);
+    int pnexp = -ve;
+    pnexp = pnexp > FInfo<T>::maxexp - 1 ? FInfo<T>::maxexp - 1 : pnexp;
+    pnexp = pnexp < FInfo<T>::minexp ? FInfo<T>::minexp : pnexp;
+    const T prenorm = (T)ldexp(1.0, pnexp);
+    double ss = 0.0;
+    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
+        T v = vs[k] * prenorm;
+        ss += (double)v * (double)v;
+    }
+    const T inorm = (T)sqrt(block_sum(ss, s_red));
+    if (tid == 0) out[r] = inorm / prenorm;
+    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
+        T v = vs[k] * prenorm;
+        vs[k] = v / inorm;
+    }
+}
+
 template <bool UNIT>
 static int row_stat(Matrix *m, void *out_host)
 {
@@ -104,15 +196,27 @@ static int row_stat(Matrix *m, void *out_host)
     CSRK_REQUIRE(out_host || m->nrows == 0, "output is NULL");
     if (m->nrows == 0) return CSRK_OK;
     std::lock_guard<std::mutex> lk(m->mu);
-    DevBuf d;
+    DevBuf d, longs, nl;
     CSRK_TRY(d.alloc((size_t)m->nrows * m->val_bytes()));
+    const int64_t max_long = m->nnz / ROW_LONG + 1;           // at most this many rows can be that long
+    CSRK_TRY(longs.alloc((size_t)max_long * 4));
+    CSRK_TRY(nl.alloc(4));
+    CSRK_HIP(hipMemset(nl.p, 0, 4));
     unsigned grid = (unsigned)ceil_div((int64_t)m->nrows * WAVE, 256);
 #define GO(P, T)                                                                                          \
     do {                                                                                                  \
         if (UNIT)                                                                                         \
-            unit_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows);   \
+            unit_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows,     \
+                                                  longs.as<int32_t>(), nl.as<int32_t>());                 \
         else                                                                                              \
-            center_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows); \
+            center_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows,   \
+                                                    longs.as<int32_t>(), nl.as<int32_t>());               \
+        CSRK_LAUNCH_CHECK();                                                                              \
+        int32_t n_long = 0;                                                                               \
+        CSRK_HIP(hipMemcpy(&n_long, nl.p, 4, hipMemcpyDeviceToHost));                                     \
+        if (n_long > 0)                                                                                   \
+            row_stat_long_kernel<P, T, UNIT><<<(unsigned)n_long, ROW_LONG_THREADS>>>(                     \
+                (const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), longs.as<int32_t>());               \
     } while (0)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, double); else GO(int64_t, float);

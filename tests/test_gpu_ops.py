@@ -411,3 +411,31 @@ def test_from_coo_device(golden):
             assert c.values.dtype == dt and np.array_equal(c.values, ref.values)
     with pytest.raises(ValueError):
         K.from_coo(np.array([5]), np.array([0]), None, (3, 3))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_unit_center_long_rows_vs_oracle(dtype):
+    "rows longer than 8192 entries take the workgroup-per-row kernels; NaN row and zero row included"
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    lens = rng.integers(0, 20, size=400)
+    lens[[5, 77, 200, 399]] = [9000, 30000, 8193, 12000]
+    m = _rand(rng, 400, 3000, lens, dtype=dtype)
+    s200 = int(m.rowptrs[200])
+    m.values[s200:s200 + 8193] = 0                      # an all-zero long row -> norm 0, NaN values
+    m.values[int(m.rowptrs[399]) + 17] = np.nan         # NaN in a long row propagates
+    rel = 1e-5 if dtype == np.float32 else 1e-9
+    u, ur = m.copy(), m.values.copy()
+    with np.errstate(all='ignore'):
+        norms = u.normalize_rows('unit')
+        rn = O.unit_rows(m.nrows, m.rowptrs, ur)
+    assert norms == pytest.approx(rn, rel=rel, abs=0, nan_ok=True)
+    assert np.array_equal(np.isnan(u.values), np.isnan(ur))
+    assert u.values == pytest.approx(ur, rel=rel, abs=1e-300, nan_ok=True)
+    m.values[int(m.rowptrs[399]) + 17] = 0.5
+    c, cr = m.copy(), m.values.copy()
+    means = c.normalize_rows('center')
+    rm = O.center_rows(m.nrows, m.rowptrs, cr)
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    assert means == pytest.approx(rm, rel=rel, abs=tol)
+    assert c.values == pytest.approx(cr, rel=rel, abs=tol)
