@@ -1367,6 +1367,28 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     return CSRK_ERR_INVALID;   // not reached
 }
 
+int spmv_tier0_view(Matrix *m, Tier0View *out)
+{
+    *out = Tier0View();
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));              // a query: builds the split eagerly
+    if (p->algo != CSRK_SPMV_MERGE || !p->n_heavy || !p->tier[0].on) return CSRK_OK;
+    const Panel &t = p->tier[0];
+    out->on = true;
+    out->p64 = t.p64;
+    out->n_rows = t.nrow;
+    out->n_blocks = t.nb;
+    out->block_cols = t.cb;
+    out->min_entries = HEAVY_MIN;
+    out->pairs = t.rows;
+    out->nnz = t.nnz;
+    out->rp = t.rp.p;
+    out->ci = t.ci.as<int32_t>();
+    out->vs = t.vs.as<double>();
+    out->row_list = t.row_list.as<int32_t>();
+    return CSRK_OK;
+}
+
 }  // namespace csrk
 
 using namespace csrk;

@@ -439,3 +439,28 @@ def test_unit_center_long_rows_vs_oracle(dtype):
     tol = 1e-6 if dtype == np.float32 else 1e-12
     assert means == pytest.approx(rm, rel=rel, abs=tol)
     assert c.values == pytest.approx(cr, rel=rel, abs=tol)
+
+
+@pytest.mark.parametrize('k', [64, 20])
+def test_spmm_dense_heavy_rows_blocked(k, monkeypatch):
+    "heavy rows served from the SpMV plan's column-block-major panel (forced on for this small matrix)"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
+    monkeypatch.setenv('CSRK_SPMM_HEAVY', '1')
+    rng = np.random.default_rng(40 + k)
+    lens = rng.integers(0, 30, size=3000)
+    lens[[0, 10, 1500, 2999]] = [5000, 2048, 9000, 3000]        # tier-0 rows
+    lens[[20, 30]] = [1000, 300]                                # split light rows (> 256 entries)
+    A = _rand(rng, 3000, 40000, lens, sort=True)
+    B = rng.uniform(-1, 1, (A.ncols, k))
+    h = K.to_handle(A)
+    try:
+        Cm = K.mult_dense(h, B)
+        C2 = K.mult_dense(h, B)
+    finally:
+        K.release_handle(h)
+    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, A.values, B)
+    bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
+    assert np.array_equal(Cm, C2)
+    assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
