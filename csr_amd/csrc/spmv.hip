@@ -1430,8 +1430,13 @@ int csrk_set_spmv_algo(csrk_handle_t h, int algo)
         CSRK_HIP(hipDeviceSynchronize());
         free_spmv_plan(m->spmv_plan);
         m->spmv_plan = nullptr;
+        if (m->spmm_plan) {               // it may hold a view of the SpMV plan's tier-0 panel
+            free_spmm_plan(m->spmm_plan);
+            m->spmm_plan = nullptr;
+        }
     }
     m->spmv_algo = algo;
+    m->spmv_calls = 0;
     return CSRK_OK;
 }
 

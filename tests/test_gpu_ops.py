@@ -464,3 +464,30 @@ def test_spmm_dense_heavy_rows_blocked(k, monkeypatch):
     bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
     assert np.array_equal(Cm, C2)
     assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
+
+
+def test_spmm_survives_spmv_algo_change(monkeypatch):
+    "the SpMM plan borrows the SpMV plan's panel: changing the SpMV algorithm must not leave it dangling"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
+    monkeypatch.setenv('CSRK_SPMM_HEAVY', '1')
+    rng = np.random.default_rng(4)
+    lens = rng.integers(0, 10, size=1000)
+    lens[[1, 500]] = [4000, 2500]
+    A = _rand(rng, 1000, 30000, lens, sort=True)
+    B = rng.uniform(-1, 1, (A.ncols, 8))
+    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, A.values, B)
+    h = K.to_handle(A)
+    try:
+        c1 = K.mult_dense(h, B)
+        K.set_spmv_algo(h, 'vector')
+        y = K.mult_vec(h, B[:, 0].copy())
+        c2 = K.mult_dense(h, B)
+        K.set_spmv_algo(h, 'auto')
+        c3 = K.mult_dense(h, B)
+    finally:
+        K.release_handle(h)
+    for c in (c1, c2, c3):
+        assert np.allclose(c, ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(y, ref[:, 0], rtol=1e-10, atol=1e-12)
