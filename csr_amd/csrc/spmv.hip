@@ -537,6 +537,12 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
 //     L2 holds the window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.
 constexpr int PANEL_CB0 = 4096;
 constexpr int PANEL_CB1 = 131072;
+#ifndef PANEL_T0
+#define PANEL_T0 512      // threads per workgroup, tier 0: same LDS as 256 threads, twice the wavefronts per CU
+#endif
+#ifndef PANEL_T1
+#define PANEL_T1 256
+#endif
 
 template <class P>
 __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
@@ -637,8 +643,8 @@ struct PanelGroup {
 };
 constexpr int PANEL_TPW = 8;     // tiles per workgroup: the x window is copied once per group
 
-template <class PP, int CB, bool WINDOW>
-__global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
+template <class PP, int CB, bool WINDOW, int PT>
+__global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
@@ -648,8 +654,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
     __shared__ double s_buf[MERGE_ITEMS + 1];
     __shared__ int32_t s_long[MERGE_MAXLONG];
     __shared__ int32_t s_nlong;
-    __shared__ double s_wpart[MERGE_THREADS / WAVE];
+    __shared__ double s_wpart[PT / WAVE];
 
+    constexpr int PPAIRS = MERGE_ITEMS / PT / 2;      // consecutive pairs per lane
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wv = tid / WAVE;
     const PanelGroup grp = groups[blockIdx.x];
@@ -660,33 +667,33 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
     if (WINDOW) {
         const int wlen = ncols - w0 < CB ? ncols - w0 : CB;
         const f64x2_t *src = (const f64x2_t *)(x + w0);
-        constexpr int WL = WINDOW ? CB / 2 / MERGE_THREADS : 1;
+        constexpr int WL = WINDOW ? CB / 2 / PT : 1;
         if (wlen == CB) {
             f64x2_t v[WL];
 #pragma unroll
-            for (int u = 0; u < WL; u++) v[u] = src[tid + u * MERGE_THREADS];
+            for (int u = 0; u < WL; u++) v[u] = src[tid + u * PT];
 #pragma unroll
-            for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * MERGE_THREADS] = v[u];
+            for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * PT] = v[u];
         } else {
-            for (int k = tid; k < wlen; k += MERGE_THREADS) s_x[k] = x[w0 + k];
+            for (int k = tid; k < wlen; k += PT) s_x[k] = x[w0 + k];
         }
     }
 
     // Software pipeline over the group's tiles: the entries (and row ends) of tile it+1 are loaded
     // into registers while tile it is reduced out of LDS, so one global-load latency is exposed per
     // group instead of two per tile.
-    constexpr int RPT = MERGE_ITEMS / MERGE_THREADS;     // row ends a lane may have to fetch
-    int32_t c0[MERGE_PAIRS], c1[MERGE_PAIRS], rv[RPT];
-    double p0[MERGE_PAIRS], p1[MERGE_PAIRS];
+    constexpr int RPT = MERGE_ITEMS / PT;     // row ends a lane may have to fetch
+    int32_t c0[PPAIRS], c1[PPAIRS], rv[RPT];
+    double p0[PPAIRS], p1[PPAIRS];
     PanelTile pt = tiles[grp.t0];
 
 #define PANEL_LOAD_TILE(T)                                                                            \
     {                                                                                                 \
         const int64_t j0_ = (T).j0;                                                                   \
         const int nn_ = (T).nn, nr_ = (T).i1 - (T).i0;                                                \
-        _Pragma("unroll") for (int u = 0; u < MERGE_PAIRS; u++)                                       \
+        _Pragma("unroll") for (int u = 0; u < PPAIRS; u++)                                       \
         {                                                                                             \
-            const int k = 2 * (tid + u * MERGE_THREADS);                                              \
+            const int k = 2 * (tid + u * PT);                                              \
             load_pair_clamped<CSRK_VAL_F64>(pci, pvs, j0_ + k, j0_, nn_, pnnz - 2, c0[u], c1[u], p0[u], p1[u]); \
             if (WINDOW) {                                                                             \
                 c0[u] = k < nn_ ? c0[u] : w0;                                                         \
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
         }                                                                                             \
         _Pragma("unroll") for (int u = 0; u < RPT; u++)                                               \
         {                                                                                             \
-            const int r = tid + u * MERGE_THREADS;                                                    \
+            const int r = tid + u * PT;                                                    \
             const int rc = r < nr_ ? r : (nr_ > 0 ? nr_ - 1 : 0);                                     \
             rv[u] = (int32_t)((int64_t)prp[(T).i0 + rc + 1] - j0_);                                   \
         }                                                                                             \
@@ -713,8 +720,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
 
         __syncthreads();      // window visible (first pass); previous tile's LDS reads finished
 #pragma unroll
-        for (int u = 0; u < MERGE_PAIRS; u++) {
-            const int k = 2 * (tid + u * MERGE_THREADS);
+        for (int u = 0; u < PPAIRS; u++) {
+            const int k = 2 * (tid + u * PT);
             const double t0 = p0[u] * (WINDOW ? s_x[c0[u] - w0] : x[c0[u]]);
             const double t1 = p1[u] * (WINDOW ? s_x[c1[u] - w0] : x[c1[u]]);
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
         if (nr == 0) {
             double acc = 0.0;
 #pragma unroll
-            for (int u = 0; u < MERGE_PAIRS; u++) acc += p0[u] + p1[u];
+            for (int u = 0; u < PPAIRS; u++) acc += p0[u] + p1[u];
             if (more) PANEL_LOAD_TILE(nx);
             acc = wave_sum(acc);
             if (lane == 0) s_wpart[wv] = acc;
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
             if (tid == 0) {
                 double tot = s_wpart[0];
 #pragma unroll
-                for (int w = 1; w < MERGE_THREADS / WAVE; w++) tot += s_wpart[w];
+                for (int w = 1; w < PT / WAVE; w++) tot += s_wpart[w];
                 carry_row[t] = i1 < n_prows ? i1 : -1;
                 carry_val[t] = tot;
             }
@@ -744,21 +751,21 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
         int32_t *s_rend = (int32_t *)(s_buf + nn);
         if (tid == 0) s_nlong = 0;
 #pragma unroll
-        for (int u = 0; u < MERGE_PAIRS; u++) {
-            const int k = 2 * (tid + u * MERGE_THREADS);
+        for (int u = 0; u < PPAIRS; u++) {
+            const int k = 2 * (tid + u * PT);
             if (k < nn) s_prod[k] = p0[u];
             if (k + 1 < nn) s_prod[k + 1] = p1[u];
         }
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
-            const int r = tid + u * MERGE_THREADS;
+            const int r = tid + u * PT;
             if (r < nr) s_rend[r] = rv[u];
         }
         if (tid == 0) s_rend[nr] = nn;
         if (more) PANEL_LOAD_TILE(nx);       // registers are free again: next tile's loads in flight
         __syncthreads();
 
-        for (int r = tid; r <= nr; r += MERGE_THREADS) {
+        for (int r = tid; r <= nr; r += PT) {
             int s = r ? s_rend[r - 1] : 0;
             int e = s_rend[r];
             if (e - s >= MERGE_LONG) {
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_panel_kernel(
         }
         __syncthreads();
         const int nlong = s_nlong;
-        for (int q = wv; q < nlong; q += MERGE_THREADS / WAVE) {
+        for (int q = wv; q < nlong; q += PT / WAVE) {
             int r = s_long[q];
             int s = r ? s_rend[r - 1] : 0;
             int e = s_rend[r];
@@ -1267,11 +1274,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         pn->carry_val.as<double>(), pn->nnz
             const unsigned grid = (unsigned)pn->groups;
             if (q == 0) {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB0, true><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, sq>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, sq>>>(PANEL_ARGS(int32_t));
             } else {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB1, false><<<grid, MERGE_THREADS, 0, sq>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, sq>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, sq>>>(PANEL_ARGS(int32_t));
             }
 #undef PANEL_ARGS
             kh.stop();
