@@ -156,8 +156,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 16)()
-    check(lib.csrk_spmv_plan_stats(h, st, 16))
+    st = (C.c_int64 * 20)()
+    check(lib.csrk_spmv_plan_stats(h, st, 20))
     n_heavy, nnz_path = int(st[2]), int(st[3])
     # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
     # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer and
@@ -195,6 +195,7 @@ def main():
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
                    'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9])},
                    'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
+                   'hot_column_cache': {'columns': int(st[16]), 'entry_share_sampled': round(int(st[17]) / 1e6, 4), 'slots': int(st[19])},
                    'parallelism': f'row-partition x{world}',
                    'collective': args.collective if world > 1 else 'none'},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),

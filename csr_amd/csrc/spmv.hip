@@ -98,6 +98,14 @@ struct SpmvPlan {
     DevBuf cut_cum;     // int64[n_heavy + 1]: cut entries before each cut row (shift table)
     DevBuf tile_cut;    // int32[n_tiles + 1]: cuts at or before each tile start
     DevBuf heavy_row;   // int32[n_heavy]
+    // merge, hot-column pack: the HOT_SLOTS most referenced columns are renumbered to -1 - slot in a
+    // copy of colinds; their x values are packed into xh before every tile-kernel launch
+    int32_t n_hot = 0;            // 0: no pack
+    int32_t hot_slots = 0;
+    double hot_cover = 0.0;       // sampled fraction of the tile kernel's entries on packed columns
+    DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered
+    DevBuf hot_cols;    // int32[n_hot]: column of each slot
+    DevBuf xh;          // double[n_hot]
     hipStream_t side[2] = {nullptr, nullptr};   // panel tiers run on forked streams (joined before y is final)
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS; [1] mid rows, 131072-column
@@ -255,13 +263,20 @@ constexpr int MERGE_PAIRS = MERGE_IPT / 2;
 
 // HEAVY: the path runs over the light view (rp = rp_light, nnz = nnz_light); a light entry index
 // jl maps to the actual entry jl + cut_cum[#cuts with cut_pos <= jl].
-template <class P, int VT, bool HEAVY>
+//
+// HOT: hot-column pack.  `ci` is the plan's renumbered copy of colinds (a popular column reads
+// -1 - slot) and `xh` holds x[hot_cols[slot]], packed by hot_pack_kernel before this launch.  What
+// bounds this kernel on a power-law matrix is the x gathers that miss L2 (one 128-B line from the
+// Infinity Cache or HBM per 8-B value): with the columns in arbitrary order a
+// popular column shares its line with 15 unpopular ones, so the 4 MiB L2 holds ~30k popular columns;
+// packed, every cached line is 16 popular columns.
+template <class P, int VT, bool HEAVY, bool HOT>
 __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
     int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
     const int32_t *__restrict__ tile_cut, const int64_t *__restrict__ cut_pos,
-    const int64_t *__restrict__ cut_cum, int64_t nnz_total)
+    const int64_t *__restrict__ cut_cum, int64_t nnz_total, const double *__restrict__ xh)
 {
     // One LDS buffer: nn products (8 B each) followed by nr + 1 tile-relative row ends (4 B each);
     // nn + nr <= MERGE_ITEMS, so MERGE_ITEMS * 8 + 8 bytes always suffice (16.4 KB -> 8 tiles per CU).
@@ -344,12 +359,17 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     // x gathers, MERGE_GATHER_PAIRS pairs (2 gathers each) in flight per lane at a time: with all 8
     // in flight a wavefront has 512 lines outstanding, twice the 256-line L1, and the popular x
     // entries that would hit in L1 are evicted between uses (measured: tools/probe notes in DESIGN.md).
+    // Lanes past the tile's end hold a valid (neighbouring) entry; they are zeroed AFTER the
+    // multiply -- 0 * x[c] would be NaN for a non-finite x[c] -- with a select, not a branch.
 #pragma unroll
     for (int u = 0; u < MERGE_PAIRS; u++) {
-        // Lanes past the tile's end hold a valid (neighbouring) entry; they are zeroed AFTER the
-        // multiply -- 0 * x[c] would be NaN for a non-finite x[c] -- with a select, not a branch.
         const int k = 2 * (tid + u * MERGE_THREADS);
-        const double t0 = p0[u] * x[c0[u]], t1 = p1[u] * x[c1[u]];
+        const double *a0 = x + c0[u], *a1 = x + c1[u];
+        if (HOT) {
+            a0 = c0[u] < 0 ? xh + ~c0[u] : a0;
+            a1 = c1[u] < 0 ? xh + ~c1[u] : a1;
+        }
+        const double t0 = p0[u] * *a0, t1 = p1[u] * *a1;
         p0[u] = k < nn ? t0 : 0.0;
         p1[u] = k + 1 < nn ? t1 : 0.0;
         if ((u + 1) % MERGE_GATHER_PAIRS == 0 && u + 1 < MERGE_PAIRS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -429,6 +449,79 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
             }
         }
     }
+}
+
+// ---- hot-column cache: plan-time kernels ------------------------------------------------------------
+// Column reference counts over the rows the tile kernel serves, from every `row_stride`-th row and at
+// most 128 entries of it (a sample is enough to rank popularity); total[0] = entries counted.
+template <class P>
+__global__ __launch_bounds__(256) void hot_count_kernel(const P *__restrict__ rp, const P *__restrict__ rp_light,
+                                                       const int32_t *__restrict__ ci, int32_t nrows, int64_t row_stride,
+                                                       int32_t *__restrict__ cnt, unsigned long long *__restrict__ total)
+{
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * row_stride;
+    unsigned long long n = 0;
+    if (r < nrows && !(rp_light && rp_light[r + 1] == rp_light[r])) {   // not a row cut out to the panels
+        const int64_t s = rp[r];
+        int64_t e = rp[r + 1];
+        e = e - s > 128 ? s + 128 : e;
+        for (int64_t k = s; k < e; k++) atomicAdd(&cnt[ci[k]], 1);
+        n = (unsigned long long)(e - s);
+    }
+    for (int off = WAVE / 2; off; off >>= 1) n += __shfl_down(n, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && n) atomicAdd(total, n);
+}
+
+__global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__restrict__ hot_cols, int32_t n_hot,
+                                double *__restrict__ xh)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_hot) xh[i] = x[hot_cols[i]];
+}
+
+// out[0] = #columns with count >= thr, out[1] = sum of their counts
+__global__ __launch_bounds__(256) void hot_census_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr,
+                                                        unsigned long long *__restrict__ out)
+{
+    unsigned long long n = 0, sum = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * 256) {
+        const int32_t v = cnt[c];
+        if (v >= thr) {
+            n++;
+            sum += (unsigned long long)v;
+        }
+    }
+    for (int off = WAVE / 2; off; off >>= 1) {
+        n += __shfl_down(n, off, WAVE);
+        sum += __shfl_down(sum, off, WAVE);
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && n) {
+        atomicAdd(&out[0], n);
+        atomicAdd(&out[1], sum);
+    }
+}
+
+__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr, int32_t *__restrict__ flag)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= thr) ? 1 : 0;
+}
+
+// slot[c] = exclusive scan of the flags; cnt[c] >= thr marks the cached columns
+__global__ void hot_list_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ slot, int32_t ncols,
+                                int32_t thr, int32_t *__restrict__ hot_cols)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncols && cnt[c] >= thr) hot_cols[slot[c]] = (int32_t)c;
+}
+
+__global__ void hot_remap_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ cnt,
+                                 const int32_t *__restrict__ slot, int32_t thr, int32_t *__restrict__ ci_hot)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int32_t c = ci[k];
+    ci_hot[k] = cnt[c] >= thr ? ~slot[c] : c;
 }
 
 // ---- long rows: cut out of the merge path ------------------------------------------------------
@@ -1151,6 +1244,87 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     return CSRK_OK;
 }
 
+// Pick the (at most HOT_SLOTS) most referenced columns and renumber them in a copy of colinds.  Built
+// with the lazy plan (second launch on a handle).  Skipped when x is small enough to live in L1/L2
+// next to the streams anyway, when the matrix is small, or when the cached columns would carry less
+// than a fifth of the entries (no popularity skew: nothing to gain, and the persistent grid has fewer
+// wavefronts in flight than the plain one).  CSRK_SPMV_HOT=0 disables, =1 forces.
+template <class P>
+static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    p->n_hot = 0;
+    const char *env = getenv("CSRK_SPMV_HOT");
+    if (env && env[0] == '0') return CSRK_OK;
+    const bool force = env && env[0] == '1';
+    if (m->nnz < 2 || m->ncols < 1) return CSRK_OK;
+    int64_t HOT_SLOTS = 65536;    // 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
+                                  // 256k 0.430, 1M 0.439, 4M 0.460 ms for the tile kernel; none 0.481)
+    if (const char *e = getenv("CSRK_HOT_SLOTS")) HOT_SLOTS = atoll(e) > 0 ? atoll(e) : HOT_SLOTS;
+    p->hot_slots = (int32_t)HOT_SLOTS;
+    // x that fits in L2 whole needs no packing
+    if (!force && (m->nnz < (1 << 20) || (int64_t)m->ncols * 8 <= (4ll << 20))) return CSRK_OK;
+    const int32_t nc = m->ncols;
+    DevBuf cnt, slot, census;
+    CSRK_TRY(cnt.alloc((size_t)(nc + 1) * 4));
+    CSRK_TRY(slot.alloc((size_t)(nc + 2) * 4));
+    CSRK_TRY(census.alloc(16));
+    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * 4, s));
+    CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
+    const int64_t row_stride = p->nnz_light > (1ll << 25) ? p->nnz_light >> 25 : 1;
+    hot_count_kernel<P><<<(unsigned)ceil_div(ceil_div(m->nrows, row_stride), 256), 256, 0, s>>>(
+        (const P *)m->d_rowptrs, p->n_heavy ? p->rp_light.as<P>() : (const P *)nullptr, m->d_colinds, m->nrows,
+        row_stride, cnt.as<int32_t>(), census.as<unsigned long long>());
+    CSRK_LAUNCH_CHECK();
+    unsigned long long n_samples_u = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_samples_u, census.p, 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    const int64_t n_samples = (int64_t)n_samples_u;
+    if (n_samples == 0) return CSRK_OK;
+    // smallest threshold (>= 2 references in the sample) that leaves at most HOT_SLOTS columns
+    auto census_at = [&](int32_t thr, unsigned long long out[2]) -> int {
+        CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
+        hot_census_kernel<<<1024, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, census.as<unsigned long long>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipMemcpyAsync(out, census.p, 16, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        return CSRK_OK;
+    };
+    unsigned long long c[2];
+    int64_t lo = 2, hi = n_samples + 1;     // invariant: census(hi).n <= HOT_SLOTS
+    CSRK_TRY(census_at((int32_t)lo, c));
+    if (c[0] > (unsigned long long)HOT_SLOTS) {
+        while (lo + 1 < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            CSRK_TRY(census_at((int32_t)(mid > INT32_MAX ? INT32_MAX : mid), c));
+            if (c[0] <= (unsigned long long)HOT_SLOTS)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        CSRK_TRY(census_at((int32_t)(hi > INT32_MAX ? INT32_MAX : hi), c));
+        lo = hi;
+    }
+    const int32_t thr = (int32_t)(lo > INT32_MAX ? INT32_MAX : lo);
+    const int32_t n_hot = (int32_t)c[0];
+    p->hot_cover = n_samples ? (double)c[1] / (double)n_samples : 0.0;
+    if (n_hot == 0 || (!force && p->hot_cover < 0.2)) return CSRK_OK;
+
+    const unsigned gc = (unsigned)ceil_div((int64_t)nc + 1, 256);
+    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, slot.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(slot.as<int32_t>(), slot.as<int32_t>(), nc, s));
+    CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
+    CSRK_TRY(p->xh.alloc((size_t)n_hot * 8));
+    CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
+    hot_list_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot.as<int32_t>(), nc, thr, p->hot_cols.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, cnt.as<int32_t>(),
+                                                                    slot.as<int32_t>(), thr, p->ci_hot.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    p->n_hot = n_hot;
+    return CSRK_OK;
+}
+
 template <class P>
 static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
 {
@@ -1177,6 +1351,7 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
                 p->tile_cut.as<int32_t>());
             CSRK_LAUNCH_CHECK();
         }
+        if (allow_split) CSRK_TRY(build_hot_cache<P>(m, p, s));
     } else if (p->algo == CSRK_SPMV_VECTOR) {
         CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
         if (m->nrows > 0) {
@@ -1208,8 +1383,8 @@ static int get_plan_locked(Matrix *m, hipStream_t s, SpmvPlan **out, bool launch
     // SpMV, so it is built on the SECOND launch on a handle: the reference's CSR.mult_vec makes a
     // handle per call (csr/csr.py:582) and must not pay for a plan it uses once.  Forcing the split
     // (CSRK_SPMV_HEAVY_SPLIT=1) or profiling builds it at once.
-    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
-    const bool eager = (env && env[0] == '1') || !launching;
+    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT"), *env_hot = getenv("CSRK_SPMV_HOT");
+    const bool eager = (env && env[0] == '1') || (env_hot && env_hot[0] == '1') || !launching;
     const bool want_split = eager || m->spmv_calls >= 2;
     if (m->spmv_plan && !m->spmv_plan->split_considered && want_split && m->spmv_plan->algo == CSRK_SPMV_MERGE &&
         !m->spmv_plan->profiling) {
@@ -1292,16 +1467,31 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             if (fork) CSRK_HIP(hipEventRecord(p->ev_join[q], sq));
         }
         {
+#define MERGE_ARGS_LIGHT(CI)                                                                                        \
+    p->rp_light.as<P>(), CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, p->nnz_light,                \
+        p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(), p->cut_pos.as<int64_t>(),  \
+        p->cut_cum.as<int64_t>(), m->nnz, p->xh.as<double>()
+#define MERGE_ARGS_FULL(CI)                                                                                         \
+    rp, CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz, p->carry_row.as<int32_t>(),          \
+        p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz, p->xh.as<double>()
+            const unsigned grid = (unsigned)p->n_tiles;
+            if (p->n_hot) {
+                hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
+                                                                                p->xh.as<double>());
+                CSRK_LAUNCH_CHECK();
+            }
             KernelTimer kt(p, s);
-            if (p->n_heavy)
-                spmv_merge_kernel<P, VT, true><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
-                    p->rp_light.as<P>(), m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows,
-                    p->nnz_light, p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(),
-                    p->cut_pos.as<int64_t>(), p->cut_cum.as<int64_t>(), m->nnz);
+            if (p->n_hot) {
+                if (p->n_heavy)
+                    spmv_merge_kernel<P, VT, true, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(p->ci_hot.as<int32_t>()));
+                else
+                    spmv_merge_kernel<P, VT, false, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(p->ci_hot.as<int32_t>()));
+            } else if (p->n_heavy)
+                spmv_merge_kernel<P, VT, true, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
             else
-                spmv_merge_kernel<P, VT, false><<<(unsigned)p->n_tiles, MERGE_THREADS, 0, s>>>(
-                    rp, m->d_colinds, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz,
-                    p->carry_row.as<int32_t>(), p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz);
+                spmv_merge_kernel<P, VT, false, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
+#undef MERGE_ARGS_LIGHT
+#undef MERGE_ARGS_FULL
             kt.stop();
             CSRK_LAUNCH_CHECK();
             if (p->n_heavy)
@@ -1514,12 +1704,13 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
     const Panel &t0 = p->tier[0], &t1 = p->tier[1];
-    const int64_t v[16] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    const int64_t v[20] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            t0.tiles, t0.nb, HEAVY_MIN, t0.cb, p->n_heavy ? 2 : 0, t0.rows, t0.nnz,
-                           t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb};
-    for (int i = 0; i < n && i < 16; i++) out[i] = v[i];
+                           t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
+                           p->n_hot, (int64_t)(p->hot_cover * 1e6), 0, p->hot_slots};
+    for (int i = 0; i < n && i < 20; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

@@ -56,6 +56,11 @@ def test_spmv_config2_full_size():
         _spmv(h, x, y3)
         torch.cuda.synchronize()
         assert torch.equal(y2, y3)       # bitwise reproducible
+        import ctypes as C
+        st = (C.c_int64 * 20)()
+        check(lib.csrk_spmv_plan_stats(h, st, 20))
+        assert st[2] > 0 and st[10] > 0 and st[13] > 0     # both panel tiers are in use at this size ...
+        assert st[16] > 0                                  # ... and so is the hot-column pack
         # error scale: sum_j |a_ij| |x_j| through the same kernels on |A|, |x|
         absv = m['values'].abs()
         mabs = dict(m, values=absv)

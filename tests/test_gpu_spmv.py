@@ -18,17 +18,22 @@ pytestmark = pytest.mark.gpu
 ALGOS = ['merge', 'vector', 'scalar']
 
 
-@pytest.fixture(autouse=True, params=['auto', 'forced_split'])
+@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'hot', 'forced_split_hot'])
 def split_mode(request, monkeypatch):
     """
-    Every test runs twice: with the library's own choice (small test matrices have an x that fits in
-    L2, so the long-row split stays off) and with the split forced on, so the panel tiers are
-    exercised on every shape.
+    Every test runs four times: with the library's own choice (small test matrices have an x that fits
+    in L2, so the long-row split and the hot-column pack stay off), with the split forced on (the panel
+    tiers are exercised on every shape), with the hot-column pack forced on (renumbered colinds + packed
+    x in the tile kernel), and with both.
     """
-    if request.param == 'forced_split':
+    if 'forced_split' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
     else:
         monkeypatch.delenv('CSRK_SPMV_HEAVY_SPLIT', raising=False)
+    if 'hot' in request.param:
+        monkeypatch.setenv('CSRK_SPMV_HOT', '1')
+    else:
+        monkeypatch.delenv('CSRK_SPMV_HOT', raising=False)
     return request.param
 
 
@@ -236,7 +241,7 @@ def test_spmv_nonfinite_propagation():
 
 def test_plan_stats_and_cache_trim(split_mode):
     "csrk_spmv_plan_stats reports the tiers; csrk_trim_cache returns the pool to the driver"
-    if split_mode != 'forced_split':
+    if 'forced_split' not in split_mode:
         pytest.skip('x of this small matrix fits in L2: no split unless forced')
     import ctypes as C
     from csr_amd._lib import lib, check
@@ -250,11 +255,16 @@ def test_plan_stats_and_cache_trim(split_mode):
     h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False))
     try:
         K.mult_vec(h, np.ones(m.ncols))
-        st = (C.c_int64 * 16)()
-        check(lib.csrk_spmv_plan_stats(h.H, st, 16))
+        st = (C.c_int64 * 20)()
+        check(lib.csrk_spmv_plan_stats(h.H, st, 20))
         assert st[2] == 2                      # two rows cut out of the tile path
         assert st[10] == 4000 and st[13] == 500    # tier-0 / tier-1 entries
         assert st[3] == m.nnz - 4500
+        if 'hot' in split_mode:
+            # columns referenced at least twice by the tile path's rows are packed
+            assert 0 < st[16] <= st[19] and 0 < st[17] <= 1_000_000
+        else:
+            assert st[16] == 0
     finally:
         K.release_handle(h)
     check(lib.csrk_trim_cache())
@@ -319,3 +329,32 @@ def test_concurrent_calls_on_one_handle():
         K.release_handle(h)
     for y, r in zip(outs, refs):
         assert np.allclose(y, r, rtol=1e-12, atol=1e-12)
+
+
+def test_hot_pack_is_bit_identical(monkeypatch):
+    """
+    The hot-column pack only changes WHERE an x value is read from (a packed copy instead of x itself):
+    products and summation order are those of the plain tile kernel, so y is bit-identical.
+    """
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(4242)
+    lens = rng.integers(0, 40, size=3000)
+    lens[11] = 3000
+    nc = 9000
+    # Zipf-like column popularity so that some columns are referenced by many rows
+    pop = 1.0 / np.arange(1, nc + 1)
+    pop /= pop.sum()
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(nc, size=int(n), replace=False, p=pop)) for n in lens]).astype(np.int32)
+    vs = rng.uniform(-1, 1, size=ci.size)
+    x = rng.uniform(-1, 1, size=nc)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('CSRK_SPMV_HOT', mode)
+        h = K.to_handle(CSR(3000, nc, int(ci.size), rp, ci, vs, _cast=False))
+        try:
+            out[mode] = K.mult_vec(h, x)
+        finally:
+            K.release_handle(h)
+    assert np.array_equal(out['0'], out['1'])
