@@ -80,6 +80,14 @@ struct Panel {
     DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y, tmp;
 };
 
+// Tier 0 in accumulator form: one group of <= ACC_MAXROWS heavy rows (see "long rows, accumulator form")
+struct AccPanel {
+    int32_t nrow = 0, nb = 0, n_wg = 0;
+    int64_t tiles = 0, nnz = 0, n_segs = 0;
+    size_t lds = 0;
+    DevBuf row_list, vals, idx, segs, wg_seg, partial;
+};
+
 struct SpmvPlan {
     int algo = CSRK_SPMV_MERGE;
     // merge
@@ -108,8 +116,12 @@ struct SpmvPlan {
     DevBuf xh;          // double[n_hot]
     hipStream_t side[2] = {nullptr, nullptr};   // panel tiers run on forked streams (joined before y is final)
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS; [1] mid rows, 131072-column
-                        // blocks, x window kept in L2 by block-major, XCD-aware scheduling
+    Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
+                        // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
+                        // 131072-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
+    std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
+    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their entries: source of either form
+    int64_t t0_nnz = 0;
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -128,6 +140,7 @@ struct SpmvPlan {
             if (ev_join[q]) (void)hipEventDestroy(ev_join[q]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (AccPanel *a : acc) delete a;
     }
 };
 
@@ -930,6 +943,290 @@ __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t 
     if (b <= n_blocks) out[b] = off[(int64_t)b * n_heavy];
 }
 
+// ---- long rows, accumulator form (tier 0, default) ---------------------------------------------------
+// The pair form above spends a quarter of the tier-0 traffic on bookkeeping: a row pointer and a partial
+// per (column block, row) pair (avg. 7.8 entries), the partials re-read by the reduce, plus four
+// workgroup barriers per 2048-item tile.  The heavy rows are FEW (thousands), so one accumulator per heavy
+// row fits in LDS next to the x window: 8192 rows * 8 B = 64 KiB + 32 KiB.  The accumulator form is a pure
+// stream:
+//   * Heavy rows are taken in groups of <= ACC_MAXROWS.  A group's entries are stored column-block-major
+//     (block = ACC_CB columns), inside a block by heavy row, as (float64 value, packed uint32
+//     {column - block start : 13 bits, heavy-row index : 13 bits}) = 12 B per entry, nothing else.
+//   * A block's entries are padded to whole TILES of 512 = 64 lanes x 8 entries; a tile is stored lane-
+//     interleaved so that one wavefront reads it with 16-B-per-lane coalesced loads and every lane
+//     receives 8 CONSECUTIVE entries (a run of one row is then mostly inside one lane).
+//   * A persistent workgroup (one per CU, 16 wavefronts) owns a contiguous range of tiles, cut into
+//     SEGMENTS (tiles of one column block, <= 256).  Per segment: the block's x window -> LDS; each
+//     wavefront walks tiles: lane-local ordered sums per row, a segmented scan over the lanes (__shfl_up)
+//     joins the runs that cross lanes, and the finished row sums are added to the LDS accumulators.
+//   * Determinism: within a segment a row's run is owned by the tile it starts in; the leading run of a
+//     tile (which may belong to the previous tile's last row) is parked in a per-tile head slot instead and
+//     the heads are folded in, in tile order, by one wavefront after the segment's barrier.  So every
+//     accumulator sees its addends in a fixed order whichever wavefront took which tile: results are
+//     bitwise reproducible, although ds_add_f64 is used for the adds.
+//   * At the end the workgroup stores its accumulators (H * 8 B) and acc_reduce_kernel sums the
+//     workgroups' partials in workgroup order into y.
+// HBM traffic: 12 B per entry + one 32 KiB window per segment + n_wg * H * 8 B of partials (14 MB on the
+// headline matrix) -- against 12 B + 20 B per pair + windows for the pair form.
+constexpr int ACC_CB = 4096;
+constexpr int ACC_K = 8;                      // consecutive entries per lane
+constexpr int ACC_TILE = WAVE * ACC_K;        // 512
+constexpr int ACC_MAXROWS = 8192;             // heavy rows per group (13-bit row field)
+constexpr int ACC_SEG_TILES = 256;            // head slots per segment
+constexpr int ACC_THREADS = 1024;
+constexpr int ACC_ROW_SHIFT = 13;
+constexpr uint32_t ACC_COL_MASK = (1u << ACC_ROW_SHIFT) - 1;
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+struct AccSeg {
+    int64_t tile0;    // first tile of the segment
+    int32_t ntiles;   // <= ACC_SEG_TILES, all in one column block
+    int32_t blk;
+};
+
+// physical slot of logical entry e (0..511) of a tile: lane = e / 8, j = e % 8
+__host__ __device__ __forceinline__ int acc_val_slot(int e)
+{
+    const int lane = e >> 3, j = e & 7;
+    return (j >> 1) * (2 * WAVE) + lane * 2 + (j & 1);        // four 16-B loads per lane
+}
+__host__ __device__ __forceinline__ int acc_idx_slot(int e)
+{
+    const int lane = e >> 3, j = e & 7;
+    return (j >> 2) * (4 * WAVE) + lane * 4 + (j & 3);        // two 16-B loads per lane
+}
+
+// one thread per (block, heavy row) pair: copies the pair's entries into the tiled stream
+template <class P, int VT>
+__global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks, int32_t cb,
+                                const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
+                                double *__restrict__ pvals, uint32_t *__restrict__ pidx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_heavy * n_blocks) return;
+    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
+    const int64_t n = off[i + 1] - off[i];
+    if (n == 0) return;
+    const int32_t r = heavy_row[c];
+    const int64_t s = rp[r], e = rp[r + 1];
+    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
+    int64_t L = blk_tile0[b] * ACC_TILE + (off[i] - off[(int64_t)b * n_heavy]);      // logical position
+    for (int64_t k = lo; k < lo + n; k++, L++) {
+        const int64_t t = L / ACC_TILE;
+        const int el = (int)(L % ACC_TILE);
+        pvals[t * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
+        pidx[t * ACC_TILE + acc_idx_slot(el)] = (uint32_t)(ci[k] - b * cb) | ((uint32_t)c << ACC_ROW_SHIFT);
+    }
+}
+
+// one workgroup per block: pads the block's last tile with (0.0, column slot ACC_CB (a zero in LDS),
+// the last heavy row) -- a padding entry adds 0.0 * 0.0 to an accumulator
+__global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
+                                                     const int64_t *__restrict__ blk_tile0, double *__restrict__ pvals,
+                                                     uint32_t *__restrict__ pidx)
+{
+    const int32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const int64_t cnt = off[(int64_t)(b + 1) * n_heavy] - off[(int64_t)b * n_heavy];
+    const int64_t L0 = blk_tile0[b] * ACC_TILE + cnt, L1 = blk_tile0[b + 1] * ACC_TILE;
+    for (int64_t L = L0 + threadIdx.x; L < L1; L += blockDim.x) {
+        const int64_t t = L / ACC_TILE;
+        const int el = (int)(L % ACC_TILE);
+        pvals[t * ACC_TILE + acc_val_slot(el)] = 0.0;
+        pidx[t * ACC_TILE + acc_idx_slot(el)] = (uint32_t)ACC_CB | ((uint32_t)(n_heavy - 1) << ACC_ROW_SHIFT);
+    }
+}
+
+// Inclusive segmented sum over the lanes of a wavefront: a lane with `reset` set does not take the
+// running sum of the lanes below it.
+__device__ __forceinline__ double wave_segscan(double v, bool reset, int lane)
+{
+    int f = reset ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const double vp = __shfl_up(v, d, WAVE);
+        const int fp = __shfl_up(f, d, WAVE);
+        if (lane >= d && !f) {
+            v += vp;
+            f = fp;
+        }
+    }
+    return v;
+}
+
+template <int CB, int PT>
+__global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__ pvals, const uint32_t *__restrict__ pidx,
+                                                     const double *__restrict__ x, int32_t ncols,
+                                                     const AccSeg *__restrict__ segs, const int32_t *__restrict__ wg_seg,
+                                                     int32_t H, double *__restrict__ partial)
+{
+    extern __shared__ __align__(16) unsigned char acc_smem[];
+    double *s_x = (double *)acc_smem;                     // CB + 2 (slot CB = 0.0 for padding entries)
+    double *s_acc = s_x + CB + 2;                         // Hpad
+    const int Hpad = (H + 1) & ~1;
+    double *s_hval = s_acc + Hpad;                        // ACC_SEG_TILES
+    int32_t *s_hrow = (int32_t *)(s_hval + ACC_SEG_TILES);
+    constexpr int NW = PT / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+
+    for (int h = tid; h < Hpad; h += PT) s_acc[h] = 0.0;
+    if (tid < 2) s_x[CB + tid] = 0.0;
+    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;      // lanes < lane
+    const unsigned long long upto = below | (1ull << lane);                       // lanes <= lane
+
+    int cur_blk = -1;
+    const int sb = wg_seg[blockIdx.x], se = wg_seg[blockIdx.x + 1];
+    for (int si = sb; si < se; si++) {
+        const AccSeg sg = segs[si];
+        if (sg.blk != cur_blk) {
+            // every wavefront is past barrier B of the previous segment: nobody reads s_x any more
+            cur_blk = sg.blk;
+            const int32_t w0 = sg.blk * CB;
+            const int wlen = ncols - w0 < CB ? ncols - w0 : CB;
+            if (wlen == CB) {
+                constexpr int WL = CB / 2 / PT;
+                f64x2_t v[WL];
+#pragma unroll
+                for (int u = 0; u < WL; u++) v[u] = *((const F64x2 *)(x + w0) + tid + u * PT);
+#pragma unroll
+                for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * PT] = v[u];
+            } else {
+                for (int k = tid; k < wlen; k += PT) s_x[k] = x[w0 + k];
+            }
+        }
+        __syncthreads();      // A: window stored; heads of the previous segment folded in; accumulators zeroed
+
+        const int nt = sg.ntiles;
+        f64x2_t v[4], vn[4];
+        u32x4_t ix[2], ixn[2];
+        int t = wv;
+        if (t < nt) {
+            const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.tile0 + t) * ACC_TILE);
+            const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.tile0 + t) * ACC_TILE);
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+#pragma unroll
+            for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        }
+        for (; t < nt; t += NW) {
+            const bool more = t + NW < nt;
+            if (more) {      // next tile's loads are in flight while this one is reduced
+                const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.tile0 + t + NW) * ACC_TILE);
+                const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.tile0 + t + NW) * ACC_TILE);
+#pragma unroll
+                for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+#pragma unroll
+                for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+            }
+            const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
+            const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+            double xv[ACC_K];
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) xv[j] = s_x[e[j] & ACC_COL_MASK];
+            // lane-local: ordered sum per row; the first run is the lane's head, the last its tail, runs in
+            // between start and end inside this lane and go straight to their accumulators
+            const int hr = (int)(e[0] >> ACC_ROW_SHIFT);
+            int cur = hr;
+            double acc = 0.0, hs = 0.0;
+            bool nb = false;
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const int r = (int)(e[j] >> ACC_ROW_SHIFT);
+                if (r != cur) {
+                    if (!nb) {
+                        hs = acc;
+                        nb = true;
+                    } else {
+                        atomicAdd(&s_acc[cur], acc);
+                    }
+                    acc = 0.0;
+                    cur = r;
+                }
+                acc += a[j] * xv[j];
+            }
+            const int tr = cur;
+            const double ts = acc;
+            if (!nb) hs = acc;
+            // join the runs that cross lanes
+            const int tr_prev = __shfl_up(tr, 1, WAVE);
+            const bool ne = lane > 0 && tr_prev != hr;           // a run ends between lane - 1 and this lane
+            const double T = wave_segscan(ts, nb || ne, lane);    // running sum of this lane's tail run
+            const double T_prev = __shfl_up(T, 1, WAVE);
+            const double X = (lane > 0 && !ne) ? T_prev : 0.0;    // what earlier lanes carry into this lane's head
+            const unsigned long long m_nb = __ballot(nb), m_ne = __ballot(ne);
+            const bool before = ((m_nb & below) | (m_ne & upto)) != 0;   // some run ended before this lane's head
+            const int ne_next = __shfl_down((int)ne, 1, WAVE);
+            const bool tail_done = lane == WAVE - 1 || ne_next != 0;
+            if (nb) {                                            // the head run ends inside this lane
+                const double hv = hs + X;
+                if (before) {
+                    atomicAdd(&s_acc[hr], hv);
+                } else {                                         // it is the tile's leading run
+                    s_hrow[t] = hr;
+                    s_hval[t] = hv;
+                }
+            }
+            if (tail_done) {
+                if (nb || before) {
+                    atomicAdd(&s_acc[tr], T);
+                } else {                                         // the whole tile up to here is one run
+                    s_hrow[t] = tr;
+                    s_hval[t] = T;
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = vn[q];
+#pragma unroll
+                for (int q = 0; q < 2; q++) ix[q] = ixn[q];
+            }
+        }
+        __syncthreads();      // B: every tile's accumulator adds and head slot are in LDS
+        if (wv == 0) {
+            // fold the heads in, in tile order (rows ascend inside a block, so equal rows are adjacent)
+            for (int base = 0; base < nt; base += WAVE) {
+                const int i = base + lane;
+                const bool ok = i < nt;
+                const int row = ok ? s_hrow[i] : -1 - lane;
+                const double val = ok ? s_hval[i] : 0.0;
+                const int row_prev = __shfl_up(row, 1, WAVE);
+                const double S = wave_segscan(val, lane == 0 || row_prev != row, lane);
+                const int row_next = __shfl_down(row, 1, WAVE);
+                if (ok && (lane == WAVE - 1 || row_next != row)) atomicAdd(&s_acc[row], S);
+            }
+        }
+    }
+    __syncthreads();
+    for (int h = tid; h < H; h += PT) partial[(int64_t)blockIdx.x * H + h] = s_acc[h];
+}
+
+// y[row_list[h]] = sum over workgroups of partial[w][h], in workgroup order.  64 heavy rows per
+// workgroup, 16 lanes-groups each summing a contiguous range of workgroups, joined in order through LDS.
+__global__ __launch_bounds__(1024) void acc_reduce_kernel(const double *__restrict__ partial, int32_t H, int32_t n_wg,
+                                                         const int32_t *__restrict__ row_list, double *__restrict__ y)
+{
+    __shared__ double s_p[16][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), g = threadIdx.x / WAVE;
+    const int h = blockIdx.x * WAVE + lane;
+    const int per = (n_wg + 15) / 16;
+    const int w0 = g * per, w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    double acc = 0.0;
+    if (h < H) {
+#pragma unroll 8
+        for (int w = w0; w < w1; w++) acc += partial[(int64_t)w * H + h];
+    }
+    s_p[g][lane] = acc;
+    __syncthreads();
+    if (g == 0 && h < H) {
+        double tot = s_p[0][lane];
+#pragma unroll
+        for (int q = 1; q < 16; q++) tot += s_p[q][lane];
+        y[row_list[h]] = tot;
+    }
+}
+
 // One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
 // in tile order, onto the y entry written by the tile that completed the row.
 __global__ __launch_bounds__(256) void spmv_merge_fixup_kernel(const int32_t *__restrict__ carry_row,
@@ -1042,8 +1339,6 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-static int g_heavy_split = 1;   // CSRK_SPMV_HEAVY_SPLIT=0 disables the heavy-row path (A/B runs)
-
 constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (speed assumption only)
 
 // Build one panel tier: M' (column-block-major copy of the listed rows, float64 values), its tiles and
@@ -1143,6 +1438,86 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     return CSRK_OK;
 }
 
+// Build one accumulator-form group: the listed heavy rows (<= ACC_MAXROWS, ascending) as a tiled,
+// column-block-major (value, packed index) stream plus the persistent workgroups' segment lists.
+template <class P, int VT>
+static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, int32_t n, int64_t nnz_rows, hipStream_t s)
+{
+    const P *rp = (const P *)m->d_rowptrs;
+    const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
+    const int64_t pairs = (int64_t)n * nb;
+    CSRK_TRY(ap->row_list.alloc((size_t)n * 4));
+    CSRK_HIP(hipMemcpyAsync(ap->row_list.p, rows, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    DevBuf off, bends;
+    CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
+    const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
+    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
+    CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
+    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
+    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    t0[0] = 0;
+    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div(be[b + 1] - be[b], ACC_TILE);
+    const int64_t n_tiles = t0[nb];
+    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(ap->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
+    CSRK_TRY(ap->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
+    acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
+        rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
+        ap->vals.as<double>(), ap->idx.as<uint32_t>());
+    CSRK_LAUNCH_CHECK();
+    acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
+                                               ap->idx.as<uint32_t>());
+    CSRK_LAUNCH_CHECK();
+
+    // persistent workgroups: one per CU, equal shares of the tiles, cut into one-block segments
+    int cus = 0;
+    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    int64_t n_wg = cus > 0 ? cus : 256;
+    if (const char *e = getenv("CSRK_ACC_WGS")) n_wg = atoll(e) > 0 ? atoll(e) : n_wg;
+    if (n_wg > n_tiles) n_wg = n_tiles;
+    std::vector<AccSeg> segs;
+    std::vector<int32_t> wg_seg((size_t)n_wg + 1);
+    int32_t b = 0;
+    for (int64_t w = 0; w < n_wg; w++) {
+        wg_seg[(size_t)w] = (int32_t)segs.size();
+        int64_t t = n_tiles * w / n_wg;
+        const int64_t t_end = n_tiles * (w + 1) / n_wg;
+        while (t < t_end) {
+            while (t0[b + 1] <= t) b++;
+            int64_t e = t_end < t0[b + 1] ? t_end : t0[b + 1];
+            if (e - t > ACC_SEG_TILES) e = t + ACC_SEG_TILES;
+            AccSeg sg;
+            sg.tile0 = t;
+            sg.ntiles = (int32_t)(e - t);
+            sg.blk = b;
+            segs.push_back(sg);
+            t = e;
+        }
+    }
+    wg_seg[(size_t)n_wg] = (int32_t)segs.size();
+    CSRK_TRY(ap->segs.alloc(segs.size() * sizeof(AccSeg)));
+    CSRK_TRY(ap->wg_seg.alloc(wg_seg.size() * 4));
+    CSRK_HIP(hipMemcpyAsync(ap->segs.p, segs.data(), segs.size() * sizeof(AccSeg), hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(ap->wg_seg.p, wg_seg.data(), wg_seg.size() * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(ap->partial.alloc((size_t)n_wg * n * 8));
+    ap->lds = (size_t)(ACC_CB + 2) * 8 + (size_t)((n + 1) & ~1) * 8 + (size_t)ACC_SEG_TILES * 12;
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    CSRK_HIP(hipStreamSynchronize(s));     // `segs`, `wg_seg`, `t0` are host temporaries of async copies
+    ap->nrow = n;
+    ap->nb = nb;
+    ap->n_wg = (int32_t)n_wg;
+    ap->tiles = n_tiles;
+    ap->nnz = nnz_rows;
+    ap->n_segs = (int64_t)segs.size();
+    return CSRK_OK;
+}
+
 // Cut the long rows out of the merge path and build their panel tiers.
 template <class P>
 static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_tier1 = true)
@@ -1150,6 +1525,8 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->n_heavy = 0;
     const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
     if (env && env[0] == '0') return CSRK_OK;
+    HEAVY_MIN = 2048;
+    TIERB_MIN = 128;
     if (const char *e = getenv("CSRK_HEAVY_MIN")) HEAVY_MIN = atoi(e) > 64 ? atoi(e) : 64;
     if (const char *e = getenv("CSRK_TIERB_MIN")) TIERB_MIN = atoi(e) >= 0 ? atoi(e) : 0;
     const bool tier1 = allow_tier1 && TIERB_MIN > 0 && TIERB_MIN < HEAVY_MIN;
@@ -1200,10 +1577,12 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
 
     std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
+    std::vector<int64_t> len0;
     int64_t nnz0 = 0, nnz1 = 0;
     for (int32_t c = 0; c < n_cut; c++) {
         if (lens[c] >= HEAVY_MIN) {
             r0.push_back(rows[c]);
+            len0.push_back(lens[c]);
             nnz0 += lens[c];
         } else {
             r1.push_back(rows[c]);
@@ -1219,9 +1598,22 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     int tpw0 = 8, tpw1 = 1;
     if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
     if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
+    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows) unless CSRK_SPMV_TIER0=pairs
+    const char *t0env = getenv("CSRK_SPMV_TIER0");
+    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
 #define BUILD(VT)                                                                                                  \
     do {                                                                                                           \
-        if (!r0.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[0], r0, nnz0, PANEL_CB0, true, tpw0, false, s))); \
+        if (!r0.empty() && !acc_form)                                                                              \
+            CSRK_TRY((build_panel<P, VT>(m, &p->tier[0], r0, nnz0, PANEL_CB0, true, tpw0, false, s)));              \
+        for (size_t g0 = 0; acc_form && g0 < r0.size(); g0 += ACC_MAXROWS) {                                       \
+            const size_t g1 = g0 + ACC_MAXROWS < r0.size() ? g0 + ACC_MAXROWS : r0.size();                         \
+            int64_t gn = 0;                                                                                        \
+            for (size_t c = g0; c < g1; c++) gn += len0[c];                                                        \
+            AccPanel *ap = new (std::nothrow) AccPanel();                                                          \
+            CSRK_REQUIRE(ap, "out of host memory");                                                                \
+            p->acc.push_back(ap);                                                                                  \
+            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, (int32_t)(g1 - g0), gn, s)));                  \
+        }                                                                                                          \
         if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
     } while (0)
     if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
@@ -1230,6 +1622,8 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
 #undef BUILD
     p->n_heavy = n_cut;
     p->nnz_light = m->nnz - nnz_cut;
+    p->t0_rows = r0;
+    p->t0_nnz = nnz0;
     // Fork/join streams for the tiers: measured neutral on MI355X (1.231 vs 1.235 ms: the three kernels
     // are each request/bandwidth-bound, so overlapping them only interleaves the same work); off unless
     // CSRK_SPMV_STREAMS=1.
@@ -1437,9 +1831,22 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         // reduce2 kernels, which overwrite the zeros the tile kernel stored for the cut rows.
         const bool fork = p->n_heavy && p->side[0];
         if (fork) CSRK_HIP(hipEventRecord(p->ev_fork, s));
+        if (p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
+            hipStream_t sq = fork ? p->side[0] : s;
+            if (fork) CSRK_HIP(hipStreamWaitEvent(sq, p->ev_fork, 0));
+            KernelTimer kh(p, sq, 1);
+            for (AccPanel *ap : p->acc) {
+                spmv_acc_kernel<ACC_CB, ACC_THREADS><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, sq>>>(
+                    ap->vals.as<double>(), ap->idx.as<uint32_t>(), d_x, m->ncols, ap->segs.as<AccSeg>(),
+                    ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
+                CSRK_LAUNCH_CHECK();
+            }
+            kh.stop();
+            if (fork) CSRK_HIP(hipEventRecord(p->ev_join[0], sq));
+        }
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
-            if (!pn->on) continue;
+            if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             hipStream_t sq = fork ? p->side[q] : s;
             if (fork) CSRK_HIP(hipStreamWaitEvent(sq, p->ev_fork, 0));
             KernelTimer kh(p, sq, 1 + q);
@@ -1502,9 +1909,17 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                     p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
             CSRK_LAUNCH_CHECK();
         }
+        if (p->n_heavy && !p->acc.empty()) {
+            if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[0], 0));
+            for (AccPanel *ap : p->acc) {
+                acc_reduce_kernel<<<(unsigned)ceil_div(ap->nrow, WAVE), 1024, 0, s>>>(
+                    ap->partial.as<double>(), ap->nrow, ap->n_wg, ap->row_list.as<int32_t>(), d_y);
+                CSRK_LAUNCH_CHECK();
+            }
+        }
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
-            if (!pn->on) continue;
+            if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[q], 0));
             panel_reduce2_kernel<<<(unsigned)ceil_div(pn->nrow, 256), 256, 0, s>>>(
                 pn->tmp.as<double>(), pn->nrow, pn->row_list.as<int32_t>(), d_y);
@@ -1569,7 +1984,29 @@ int spmv_tier0_view(Matrix *m, Tier0View *out)
     *out = Tier0View();
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));              // a query: builds the split eagerly
-    if (p->algo != CSRK_SPMV_MERGE || !p->n_heavy || !p->tier[0].on) return CSRK_OK;
+    if (p->algo != CSRK_SPMV_MERGE || !p->n_heavy) return CSRK_OK;
+    if (!p->tier[0].on && !p->t0_rows.empty()) {
+        // SpMV itself runs tier 0 in accumulator form; the dense-panel SpMM wants the pair form
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!p->tier[0].on) {
+            int rc;
+#define BUILD0(PT_, VT)                                                                                            \
+    rc = build_panel<PT_, VT>(m, &p->tier[0], p->t0_rows, p->t0_nnz, PANEL_CB0, true, PANEL_TPW, false, nullptr)
+            if (m->ptr64) {
+                if (m->val_type == CSRK_VAL_F64) BUILD0(int64_t, CSRK_VAL_F64);
+                else if (m->val_type == CSRK_VAL_F32) BUILD0(int64_t, CSRK_VAL_F32);
+                else BUILD0(int64_t, CSRK_VAL_NONE);
+            } else {
+                if (m->val_type == CSRK_VAL_F64) BUILD0(int32_t, CSRK_VAL_F64);
+                else if (m->val_type == CSRK_VAL_F32) BUILD0(int32_t, CSRK_VAL_F32);
+                else BUILD0(int32_t, CSRK_VAL_NONE);
+            }
+#undef BUILD0
+            CSRK_TRY(rc);
+            CSRK_HIP(hipDeviceSynchronize());
+        }
+    }
+    if (!p->tier[0].on) return CSRK_OK;
     const Panel &t = p->tier[0];
     out->on = true;
     out->p64 = t.p64;
@@ -1704,12 +2141,23 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
     const Panel &t0 = p->tier[0], &t1 = p->tier[1];
+    // tier 0: [4] tiles, [5] column blocks, [7] block width, [9] (block,row) pairs in pair form / rows in
+    // accumulator form, [10] entries, [18] form (0 pairs, 1 accumulator)
+    int64_t a_tiles = 0, a_rows = 0, a_nnz = 0, a_nb = 0;
+    for (const AccPanel *ap : p->acc) {
+        a_tiles += ap->tiles;
+        a_rows += ap->nrow;
+        a_nnz += ap->nnz;
+        a_nb = ap->nb;
+    }
+    const bool af = !p->acc.empty();
     const int64_t v[20] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
-                           t0.tiles, t0.nb, HEAVY_MIN, t0.cb, p->n_heavy ? 2 : 0, t0.rows, t0.nnz,
+                           af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, HEAVY_MIN, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
+                           af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
-                           p->n_hot, (int64_t)(p->hot_cover * 1e6), 0, p->hot_slots};
+                           p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots};
     for (int i = 0; i < n && i < 20; i++) out[i] = v[i];
     return CSRK_OK;
 }

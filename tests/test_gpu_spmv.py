@@ -18,18 +18,23 @@ pytestmark = pytest.mark.gpu
 ALGOS = ['merge', 'vector', 'scalar']
 
 
-@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'hot', 'forced_split_hot'])
+@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'forced_split_pairs', 'hot', 'forced_split_hot'])
 def split_mode(request, monkeypatch):
     """
-    Every test runs four times: with the library's own choice (small test matrices have an x that fits
+    Every test runs five times: with the library's own choice (small test matrices have an x that fits
     in L2, so the long-row split and the hot-column pack stay off), with the split forced on (the panel
-    tiers are exercised on every shape), with the hot-column pack forced on (renumbered colinds + packed
-    x in the tile kernel), and with both.
+    tiers are exercised on every shape; tier 0 in its default accumulator form), with the split forced on
+    and tier 0 in its (block, row)-pair form, with the hot-column pack forced on (renumbered colinds +
+    packed x in the tile kernel), and with split and pack both.
     """
     if 'forced_split' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
     else:
         monkeypatch.delenv('CSRK_SPMV_HEAVY_SPLIT', raising=False)
+    if 'pairs' in request.param:
+        monkeypatch.setenv('CSRK_SPMV_TIER0', 'pairs')
+    else:
+        monkeypatch.delenv('CSRK_SPMV_TIER0', raising=False)
     if 'hot' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HOT', '1')
     else:
@@ -175,6 +180,37 @@ def test_spmv_shapes(algo, shape):
         m = _random_csr(rng, 20000, 3000, lens, dtype=np.float32, ptr64=True)
     x = rng.uniform(-1, 1, size=m.ncols)
     y = _mult_vec(m, x, algo)
+    ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+    _check(y, ref, _abs_bound(m, x))
+
+
+def test_spmv_many_heavy_rows(monkeypatch, split_mode):
+    """
+    More long rows than one accumulator group holds (8192): tier 0 runs as several groups.  The
+    threshold is lowered so that a small matrix has that many "heavy" rows; rows of every length
+    around a lane's 8 entries and a tile's 512, dense runs inside one column block, a last block
+    narrower than 4096 columns.
+    """
+    from oracle import oracle as O
+    if 'forced_split' not in split_mode:
+        pytest.skip('needs the split')
+    monkeypatch.setenv('CSRK_HEAVY_MIN', '64')
+    monkeypatch.setenv('CSRK_TIERB_MIN', '0')
+    rng = np.random.default_rng(2026)
+    nrows = 9500
+    lens = rng.integers(64, 130, size=nrows)
+    lens[::7] = 3                       # light rows in between
+    lens[5] = 30000                     # > one column block's worth per block
+    lens[9000] = 511
+    lens[9001] = 512
+    lens[9002] = 513
+    m = _random_csr(rng, nrows, 4096 * 9 + 100, lens, sort=True)
+    # a dense run: one row with every column of block 2
+    s, e = int(m.rowptrs[5]), int(m.rowptrs[5]) + 4096
+    m.colinds[s:e] = np.arange(2 * 4096, 3 * 4096, dtype=np.int32)
+    m.colinds[int(m.rowptrs[5]):int(m.rowptrs[6])].sort()
+    x = rng.uniform(-1, 1, size=m.ncols)
+    y = _mult_vec(m, x, 'merge')
     ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
     _check(y, ref, _abs_bound(m, x))
 
