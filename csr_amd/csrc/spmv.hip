@@ -29,6 +29,7 @@
 // csr/csr.py:254-262).
 #include "common.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace csrk {
@@ -100,6 +101,7 @@ struct SpmvPlan {
     // and served by one or two column-blocked panels
     bool split_considered = false; // false: built without looking at the long-row split (first call)
     int32_t n_heavy = 0;          // rows cut out
+    int32_t heavy_min = 0;        // tier 0 holds the cut rows with at least this many entries
     int64_t nnz_light = 0;
     DevBuf rp_light;    // P[nrows + 1]: row pointers with the cut rows collapsed to length 0
     DevBuf cut_pos;     // int64[n_heavy]: light-index position of each cut row
@@ -109,6 +111,7 @@ struct SpmvPlan {
     // merge, hot-column pack: the HOT_SLOTS most referenced columns are renumbered to -1 - slot in a
     // copy of colinds; their x values are packed into xh before every tile-kernel launch
     int32_t n_hot = 0;            // 0: no pack
+    int32_t n_hot_lds = 0;        // slots [0, n_hot_lds) hold the most referenced columns (kept in LDS by the light stream)
     int32_t hot_slots = 0;
     double hot_cover = 0.0;       // sampled fraction of the tile kernel's entries on packed columns
     DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered
@@ -119,9 +122,18 @@ struct SpmvPlan {
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
                         // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
                         // 131072-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
+    // the light stream: private tiled copy of the rows that stay on the row-major path
+    struct {
+        bool on = false;
+        int64_t n_view = 0, n_tiles = 0;
+        int32_t n_runs = 0;
+        unsigned grid = 0;
+        DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
+    } ls;
     std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
-    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their entries: source of either form
-    int64_t t0_nnz = 0;
+    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths: source of either form
+    std::vector<int64_t> t0_lens;
+    int32_t view_min = 0;                 // row-length threshold of the pair-form panel handed to the SpMM
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -514,10 +526,24 @@ __global__ __launch_bounds__(256) void hot_census_kernel(const int32_t *__restri
     }
 }
 
-__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr, int32_t *__restrict__ flag)
+// flag[c] = lo <= cnt[c] < hi
+__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t lo, int64_t hi,
+                                int32_t *__restrict__ flag)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= thr) ? 1 : 0;
+    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= lo && (int64_t)cnt[c] < hi) ? 1 : 0;
+}
+
+// Slots in two classes: the columns with cnt >= thr2 first (slots [0, n_top): the light stream keeps their
+// x values in LDS), then those with thr <= cnt < thr2; column order inside a class.
+__global__ void hot_slot_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ slot_top,
+                                const int32_t *__restrict__ slot_rest, int32_t ncols, int32_t thr, int32_t thr2,
+                                int32_t n_top, int32_t *__restrict__ slot)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    const int32_t v = cnt[c];
+    slot[c] = v >= thr2 ? slot_top[c] : (v >= thr ? n_top + slot_rest[c] : -1);
 }
 
 // slot[c] = exclusive scan of the flags; cnt[c] >= thr marks the cached columns
@@ -971,7 +997,8 @@ __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t 
 constexpr int ACC_CB = 4096;
 constexpr int ACC_K = 8;                      // consecutive entries per lane
 constexpr int ACC_TILE = WAVE * ACC_K;        // 512
-constexpr int ACC_MAXROWS = 8192;             // heavy rows per group (13-bit row field)
+constexpr int ACC_MAXROWS = 15360;            // heavy rows per group: 120 KiB of accumulators + 32 KiB window + heads <= 160 KiB
+constexpr int ACC_FLOOR = 512;                // tier 0 is never extended to rows shorter than this
 constexpr int ACC_SEG_TILES = 256;            // head slots per segment
 constexpr int ACC_THREADS = 1024;
 constexpr int ACC_ROW_SHIFT = 13;
@@ -1224,6 +1251,255 @@ __global__ __launch_bounds__(1024) void acc_reduce_kernel(const double *__restri
 #pragma unroll
         for (int q = 1; q < 16; q++) tot += s_p[q][lane];
         y[row_list[h]] = tot;
+    }
+}
+
+// ---- short rows: the light stream ---------------------------------------------------------------------
+// The merge-path tile kernel spends ~600 vector instructions per wavefront-tile on index arithmetic (clamped
+// 64-bit addresses, merge coordinates, the cut table) and four dependent memory round trips per 2048-item
+// tile; with every x gather served from L1 it still took 0.25-0.28 ms on the headline matrix against
+// 0.09 ms for its 0.61 GB at streaming rate (measured: SQ counters, gather ablation).  The light stream is
+// the same idea as the accumulator form, for the rows that stay on the row-major path: at plan time their
+// entries are copied into a private stream of (float64 value, uint32 index) tiles of 512 = 64 lanes x 8
+// consecutive entries, lane-interleaved for 16-B coalesced loads, with
+//     index bit 31  hot column (low bits = slot in the packed xh), else low bits = column
+//     index bit 30  first entry of its row
+// plus rowids[k] = k-th non-empty row of the view and tile_base[t] (run numbering, below).  One wavefront
+// per tile, no LDS, no workgroup barrier:
+//   * every lane sums its 8 entries run by run in storage order; a run that starts and ends inside the lane
+//     is stored to y at once;
+//   * a segmented scan over the lanes joins runs that cross lanes (fixed tree order: deterministic);
+//   * the tile's leading run, when it continues a row of the previous tile, goes to carry[] and the
+//     existing fix-up kernel adds it to y in tile order.
+// y is zeroed first (rows with no entries, rows served by the tiers until their reduce overwrites them).
+// Run numbering: run(e) = tile_base[t] - 1 + #{row starts in the tile up to and including e}, with
+// tile_base[t] = index of the row holding the tile's first entry among the non-empty rows, + 1 if that entry
+// is not the row's first.  Needs ncols < 2^30 (two flag bits); otherwise the tile kernel stays in charge.
+constexpr int LS_THREADS = 1024;            // one persistent workgroup per CU
+constexpr int LS_HOT_LDS = 8192;            // packed columns kept in LDS (64 KiB)
+constexpr int LS_SEQ = 3;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
+constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
+
+// smallest r in [0, nrows) with rpv[r + 1] > L (the row holding view entry L); L < rpv[nrows]
+template <class P>
+__device__ __forceinline__ int32_t ls_row_of(const P *__restrict__ rpv, int32_t nrows, int64_t L)
+{
+    int32_t lo = 0, hi = nrows - 1;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)rpv[mid + 1] > L)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+template <class P>
+__global__ void ls_rowflag_kernel(const P *__restrict__ rpv, int32_t nrows, int32_t *__restrict__ flag)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= nrows) flag[r] = (r < nrows && rpv[r + 1] > rpv[r]) ? 1 : 0;
+}
+
+template <class P>
+__global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
+                                 int32_t *__restrict__ rowids)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows && rpv[r + 1] > rpv[r]) rowids[ridx[r]] = (int32_t)r;
+}
+
+// one thread per stream slot: view entry L of row r is the actual entry rp[r] + (L - rpv[r]) (rows of the
+// view are whole rows of the matrix or empty); slots past the view's end are padding
+template <class P, int VT>
+__global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ rp, const P *__restrict__ rpv, int32_t nrows,
+                                                     const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                     int64_t n_view, int64_t n_slots, double *__restrict__ svals,
+                                                     uint32_t *__restrict__ sidx)
+{
+    const int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= n_slots) return;
+    const int64_t t = L / ACC_TILE;
+    const int el = (int)(L % ACC_TILE);
+    double v = 0.0;
+    uint32_t ix = 0;
+    if (L < n_view) {
+        const int32_t r = ls_row_of(rpv, nrows, L);
+        const int64_t first = (int64_t)rpv[r];
+        const int64_t a = (int64_t)rp[r] + (L - first);
+        v = ValLoad<VT>::at(vs, a);
+        const int32_t c = ci[a];
+        ix = c < 0 ? (LS_HOT_BIT | (uint32_t)~c) : (uint32_t)c;
+        if (L == first) ix |= LS_START_BIT;
+    }
+    svals[t * ACC_TILE + acc_val_slot(el)] = v;
+    sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
+}
+
+template <class P>
+__global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
+                                   int64_t n_tiles, int32_t *__restrict__ tile_base)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t e0 = t * ACC_TILE;
+    const int32_t r = ls_row_of(rpv, nrows, e0);
+    tile_base[t] = ridx[r] + ((int64_t)rpv[r] == e0 ? 0 : 1);
+}
+
+__device__ __forceinline__ int wave_exscan_i32(int v, int lane)
+{
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int up = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += up;
+    }
+    return inc - v;
+}
+
+// LDS: [0, LS_HOT_LDS) the x values of the most popular packed columns (slots below n_lds are read from
+// here instead of gathered), then one staging buffer of ACC_TILE + 2 run sums per wavefront.
+__global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
+    const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
+    const int32_t *__restrict__ tile_base, const double *__restrict__ x, const double *__restrict__ xh, int32_t n_lds,
+    int64_t n_view, int64_t n_tiles, double *__restrict__ y, int32_t *__restrict__ carry_row,
+    double *__restrict__ carry_val)
+{
+    extern __shared__ __align__(16) unsigned char ls_smem[];
+    double *s_hot = (double *)ls_smem;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    double *s_out = s_hot + LS_HOT_LDS + wv * (ACC_TILE + 2);
+    for (int i = threadIdx.x; i < n_lds; i += LS_THREADS) s_hot[i] = xh[i];
+    __syncthreads();
+
+    const int64_t wave0 = (int64_t)blockIdx.x * (LS_THREADS / WAVE) + wv;
+    const int64_t n_waves = (int64_t)gridDim.x * (LS_THREADS / WAVE);
+    f64x2_t v[4], vn[4];
+    u32x4_t ix[2], ixn[2];
+    int32_t tb = 0, tbn = 0;
+    int64_t t = wave0;
+    if (t < n_tiles) {
+        const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
+        const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+#pragma unroll
+        for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        tb = tile_base[t];
+    }
+    for (; t < n_tiles; t += n_waves) {
+        const bool more = t + n_waves < n_tiles;
+        if (more) {      // next tile's stream loads are in flight while this one is gathered and reduced
+            const f64x2_t *vp = (const f64x2_t *)(svals + (t + n_waves) * ACC_TILE);
+            const u32x4_t *ip = (const u32x4_t *)(sidx + (t + n_waves) * ACC_TILE);
+#pragma unroll
+            for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+#pragma unroll
+            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+            tbn = tile_base[t + n_waves];
+        }
+        const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
+        const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+        // x values: the most popular packed columns from LDS, the others gathered (lanes served from LDS
+        // are masked out of the gather, which is what the texture path charges for); all eight in flight
+        double gv[ACC_K], lv[ACC_K];
+        bool inl[ACC_K];
+#pragma unroll
+        for (int j = 0; j < ACC_K; j++) {
+            const uint32_t c = e[j] & LS_COL_MASK;
+            const bool hot = (e[j] & LS_HOT_BIT) != 0;
+            inl[j] = hot && (int32_t)c < n_lds;
+            const double *g = hot ? xh + c : x + c;
+            gv[j] = 0.0;
+            if (!inl[j]) gv[j] = *g;
+            lv[j] = s_hot[inl[j] ? c : 0];
+        }
+        // row starts: bit j of st = entry j opens a row
+        uint32_t st = 0;
+#pragma unroll
+        for (int j = 0; j < ACC_K; j++) st |= ((e[j] >> 30) & 1u) << j;
+        const int cnt = __popc(st);
+        const int S = wave_exscan_i32(cnt, lane);          // row starts in the lanes below
+        const int total = __shfl(S + cnt, WAVE - 1, WAVE);   // row starts in the tile
+        const bool tail_tile = t == n_tiles - 1;
+        const int64_t e_first = t * ACC_TILE + lane * ACC_K;
+        // products, rounded on their own like the reference's `v * x` (no FMA contraction: short rows are
+        // to come out bit-identical to the sequential loop)
+        double pr[ACC_K];
+#pragma unroll
+        for (int j = 0; j < ACC_K; j++) {
+            pr[j] = __dmul_rn(a[j], inl[j] ? lv[j] : gv[j]);
+            if (tail_tile) pr[j] = e_first + j < n_view ? pr[j] : 0.0;     // padding: masked after the multiply
+        }
+        // Run sums go to the wavefront's staging buffer: slot 0 = the tile's leading run (the part of a row
+        // begun in an earlier tile; 0.0 if the tile opens a row), slot k = the run opened by the tile's k-th
+        // row start.  Lane-local pass: runs that start and end inside the lane.
+        double acc = 0.0, hs = 0.0;
+        bool started = false;
+#pragma unroll
+        for (int j = 0; j < ACC_K; j++) {
+            if ((st >> j) & 1u) {
+                if (started) {
+                    s_out[S + __popc(st & ((1u << j) - 1))] = acc;      // the run opened by the previous start
+                } else {
+                    hs = acc;
+                    started = true;
+                }
+                acc = 0.0;
+            }
+            acc = __dadd_rn(acc, pr[j]);
+        }
+        const bool has_start = st != 0;
+        if (!has_start) hs = acc;
+        const double ts = acc;                                   // the lane's last run so far
+        // runs that cross lanes, tree order (any length)
+        const double T = wave_segscan(ts, has_start, lane);
+        const double T_prev = __shfl_up(T, 1, WAVE);
+        const double X = lane > 0 ? T_prev : 0.0;               // what the lanes below carry into this lane's head
+        // ... and in the reference's own order for runs over at most LS_SEQ + 1 lanes: round k hands the
+        // exact running sum of the lane below to a lane that has not got its carry yet, which then re-adds
+        // its head entries one by one on top of it
+        const int first = has_start ? __ffs(st) - 1 : ACC_K;    // entries before the lane's first row start
+        double Tq = ts, Hq = hs;
+        bool okq = has_start || lane == 0, hok = lane == 0;
+#pragma unroll
+        for (int it = 0; it < LS_SEQ; it++) {
+            const double Xq = __shfl_up(Tq, 1, WAVE);
+            const int xok = __shfl_up((int)okq, 1, WAVE);
+            const bool take = lane > 0 && xok && !hok;
+            double sum = Xq;
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) sum = __dadd_rn(sum, j < first ? pr[j] : -0.0);
+            Hq = take ? sum : Hq;
+            hok = hok || take;
+            if (!has_start) {
+                Tq = take ? sum : Tq;
+                okq = okq || take;
+            }
+        }
+        if (has_start) s_out[S] = hok ? Hq : hs + X;             // the head run ends in this lane
+        if (lane == WAVE - 1) s_out[S + cnt] = okq ? Tq : T;     // the tile's last run (continued by the next tile's slot 0)
+        // out: slot k -> the row of run tile_base - 1 + k; consecutive lanes write ascending (mostly
+        // consecutive) rows.  LDS operations of one wavefront complete in order: no barrier needed.
+        for (int k = lane; k <= total; k += WAVE) {
+            const double val = s_out[k];
+            if (k == 0) {
+                const bool opens = (st & 1u) != 0;               // lane 0: the tile's first entry opens a row
+                carry_val[t] = val;
+                carry_row[t] = opens ? -1 : rowids[tb > 0 ? tb - 1 : 0];
+            } else {
+                y[rowids[tb - 1 + k]] = val;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = vn[q];
+#pragma unroll
+            for (int q = 0; q < 2; q++) ix[q] = ixn[q];
+            tb = tbn;
+        }
     }
 }
 
@@ -1576,6 +1852,30 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     CSRK_HIP(hipStreamSynchronize(s));
     if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
 
+    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows) unless CSRK_SPMV_TIER0=pairs
+    const char *t0env = getenv("CSRK_SPMV_TIER0");
+    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
+    // The accumulator form costs 1.8 ps per entry against 4.8 for tier 1 (measured, headline matrix), and
+    // one group holds up to ACC_MAXROWS rows at no extra window traffic: when fewer rows than that reach
+    // HEAVY_MIN, tier 0 is extended downwards to the ACC_MAXROWS longest rows (not below ACC_FLOOR).
+    const int base_heavy_min = HEAVY_MIN;
+    if (acc_form && tier1 && !getenv("CSRK_HEAVY_MIN")) {
+        int64_t n_min = 0;
+        for (int32_t c = 0; c < n_cut; c++) n_min += lens[c] >= HEAVY_MIN;
+        if (n_min < ACC_MAXROWS && n_cut > n_min) {
+            std::vector<int64_t> sl(lens);
+            const size_t kth = (size_t)(n_cut < ACC_MAXROWS ? n_cut : ACC_MAXROWS) - 1;
+            std::nth_element(sl.begin(), sl.begin() + kth, sl.end(), [](int64_t a, int64_t b) { return a > b; });
+            int64_t thr = sl[kth];
+            // rows tied with the kth must not push the group over its capacity
+            int64_t n_ge = 0;
+            for (int32_t c = 0; c < n_cut; c++) n_ge += lens[c] >= thr;
+            if (n_ge > ACC_MAXROWS) thr++;
+            thr = thr < ACC_FLOOR ? ACC_FLOOR : thr;
+            if (thr < HEAVY_MIN) HEAVY_MIN = (int)thr;
+        }
+    }
+    p->heavy_min = HEAVY_MIN;
     std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
     std::vector<int64_t> len0;
     int64_t nnz0 = 0, nnz1 = 0;
@@ -1598,9 +1898,6 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     int tpw0 = 8, tpw1 = 1;
     if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
     if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
-    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows) unless CSRK_SPMV_TIER0=pairs
-    const char *t0env = getenv("CSRK_SPMV_TIER0");
-    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
 #define BUILD(VT)                                                                                                  \
     do {                                                                                                           \
         if (!r0.empty() && !acc_form)                                                                              \
@@ -1623,7 +1920,8 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->n_heavy = n_cut;
     p->nnz_light = m->nnz - nnz_cut;
     p->t0_rows = r0;
-    p->t0_nnz = nnz0;
+    p->t0_lens = len0;
+    p->view_min = acc_form ? (base_heavy_min > p->heavy_min ? base_heavy_min : p->heavy_min) : p->heavy_min;
     // Fork/join streams for the tiers: measured neutral on MI355X (1.231 vs 1.235 ms: the three kernels
     // are each request/bandwidth-bound, so overlapping them only interleaves the same work); off unless
     // CSRK_SPMV_STREAMS=1.
@@ -1703,10 +2001,37 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     p->hot_cover = n_samples ? (double)c[1] / (double)n_samples : 0.0;
     if (n_hot == 0 || (!force && p->hot_cover < 0.2)) return CSRK_OK;
 
+    // second threshold: the (at most LS_HOT_LDS) most referenced of the packed columns get the first slots
+    unsigned long long c2[2] = {c[0], c[1]};
+    int64_t lo2 = thr, hi2 = n_samples + 1;           // invariant: census(hi2).n <= LS_HOT_LDS
+    if (c2[0] > (unsigned long long)LS_HOT_LDS) {
+        while (lo2 + 1 < hi2) {
+            const int64_t mid = lo2 + (hi2 - lo2) / 2;
+            CSRK_TRY(census_at((int32_t)(mid > INT32_MAX ? INT32_MAX : mid), c2));
+            if (c2[0] <= (unsigned long long)LS_HOT_LDS)
+                hi2 = mid;
+            else
+                lo2 = mid;
+        }
+        CSRK_TRY(census_at((int32_t)(hi2 > INT32_MAX ? INT32_MAX : hi2), c2));
+        lo2 = hi2;
+    }
+    const int32_t thr2 = (int32_t)(lo2 > INT32_MAX ? INT32_MAX : lo2);
+    const int32_t n_top = (int32_t)c2[0];
+
     const unsigned gc = (unsigned)ceil_div((int64_t)nc + 1, 256);
-    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, slot.as<int32_t>());
+    DevBuf slot_top, slot_rest;
+    CSRK_TRY(slot_top.alloc((size_t)(nc + 2) * 4));
+    CSRK_TRY(slot_rest.alloc((size_t)(nc + 2) * 4));
+    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr2, (int64_t)1 << 40, slot_top.as<int32_t>());
     CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(slot.as<int32_t>(), slot.as<int32_t>(), nc, s));
+    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, (int64_t)thr2, slot_rest.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(slot_top.as<int32_t>(), slot_top.as<int32_t>(), nc, s));
+    CSRK_TRY(exclusive_scan_i32(slot_rest.as<int32_t>(), slot_rest.as<int32_t>(), nc, s));
+    hot_slot_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot_top.as<int32_t>(), slot_rest.as<int32_t>(), nc, thr, thr2,
+                                      n_top, slot.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
     CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
     CSRK_TRY(p->xh.alloc((size_t)n_hot * 8));
     CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
@@ -1716,6 +2041,68 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
                                                                     slot.as<int32_t>(), thr, p->ci_hot.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     p->n_hot = n_hot;
+    p->n_hot_lds = n_top;
+    CSRK_HIP(hipStreamSynchronize(s));     // slot_top / slot_rest are freed on return
+    return CSRK_OK;
+}
+
+// Copy the rows of the row-major path (the light view, or the whole matrix when nothing was cut out) into
+// the light stream.  Built with the lazy plan.  Skipped (the tile kernel stays in charge) when ncols needs
+// the two flag bits, when the copy does not fit in device memory, or with CSRK_SPMV_STREAM=0.
+template <class P, int VT>
+static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    p->ls.on = false;
+    const char *env = getenv("CSRK_SPMV_STREAM");
+    if (env && env[0] == '0') return CSRK_OK;
+    const int64_t n_view = p->n_heavy ? p->nnz_light : m->nnz;
+    if (m->nrows == 0 || n_view < 1 || (int64_t)m->ncols > (int64_t)LS_COL_MASK) return CSRK_OK;
+    const P *rp = (const P *)m->d_rowptrs;
+    const P *rpv = p->n_heavy ? p->rp_light.as<P>() : rp;
+    const int32_t *ci = p->n_hot ? p->ci_hot.as<int32_t>() : m->d_colinds;
+    const int64_t n_tiles = ceil_div(n_view, ACC_TILE);
+    size_t mfree = 0, mtotal = 0;
+    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if ((size_t)n_tiles * ACC_TILE * 12 + ((size_t)m->nrows + n_tiles) * 8 + (64u << 20) > mfree && !(env && env[0] == '1'))
+        return CSRK_OK;
+    DevBuf ridx;
+    CSRK_TRY(ridx.alloc((size_t)(m->nrows + 2) * 4));
+    const unsigned gr = (unsigned)ceil_div((int64_t)m->nrows + 1, 256);
+    ls_rowflag_kernel<P><<<gr, 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(ridx.as<int32_t>(), ridx.as<int32_t>(), m->nrows, s));
+    int32_t n_runs = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + m->nrows, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    if (n_runs < 1) return CSRK_OK;
+    CSRK_TRY(p->ls.rowids.alloc((size_t)n_runs * 4));
+    ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>(), p->ls.rowids.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(p->ls.vals.alloc((size_t)n_tiles * ACC_TILE * 8));
+    CSRK_TRY(p->ls.idx.alloc((size_t)n_tiles * ACC_TILE * 4));
+    ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
+        rp, rpv, m->nrows, ci, m->d_values, n_view, n_tiles * ACC_TILE, p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(p->ls.tile_base.alloc((size_t)n_tiles * 4));
+    ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>(), n_tiles,
+                                                                         p->ls.tile_base.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(p->ls.carry_row.alloc((size_t)n_tiles * 4));
+    CSRK_TRY(p->ls.carry_val.alloc((size_t)n_tiles * 8));
+    int cus = 0;
+    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
+    const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
+    p->ls.grid = (unsigned)(wgs < need ? wgs : need);
+    p->ls.n_view = n_view;
+    p->ls.n_tiles = n_tiles;
+    p->ls.n_runs = n_runs;
+    CSRK_HIP(hipStreamSynchronize(s));      // ridx is freed on return
+    p->ls.on = true;
+    p->ci_hot.release();                    // the stream carries the renumbered columns
     return CSRK_OK;
 }
 
@@ -1745,7 +2132,12 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
                 p->tile_cut.as<int32_t>());
             CSRK_LAUNCH_CHECK();
         }
-        if (allow_split) CSRK_TRY(build_hot_cache<P>(m, p, s));
+        if (allow_split) {
+            CSRK_TRY(build_hot_cache<P>(m, p, s));
+            if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
+            else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
+            else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
+        }
     } else if (p->algo == CSRK_SPMV_VECTOR) {
         CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
         if (m->nrows > 0) {
@@ -1777,8 +2169,8 @@ static int get_plan_locked(Matrix *m, hipStream_t s, SpmvPlan **out, bool launch
     // SpMV, so it is built on the SECOND launch on a handle: the reference's CSR.mult_vec makes a
     // handle per call (csr/csr.py:582) and must not pay for a plan it uses once.  Forcing the split
     // (CSRK_SPMV_HEAVY_SPLIT=1) or profiling builds it at once.
-    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT"), *env_hot = getenv("CSRK_SPMV_HOT");
-    const bool eager = (env && env[0] == '1') || (env_hot && env_hot[0] == '1') || !launching;
+    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT"), *env_hot = getenv("CSRK_SPMV_HOT"), *env_ls = getenv("CSRK_SPMV_STREAM");
+    const bool eager = (env && env[0] == '1') || (env_hot && env_hot[0] == '1') || (env_ls && env_ls[0] == '1') || !launching;
     const bool want_split = eager || m->spmv_calls >= 2;
     if (m->spmv_plan && !m->spmv_plan->split_considered && want_split && m->spmv_plan->algo == CSRK_SPMV_MERGE &&
         !m->spmv_plan->profiling) {
@@ -1887,6 +2279,24 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                                                                                 p->xh.as<double>());
                 CSRK_LAUNCH_CHECK();
             }
+            if (p->ls.on) {
+                CSRK_HIP(hipMemsetAsync(d_y, 0, (size_t)m->nrows * 8, s));
+                KernelTimer kl(p, s);
+                constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
+                spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
+                    p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
+                    p->ls.tile_base.as<int32_t>(), d_x, p->xh.as<double>(), p->n_hot_lds, p->ls.n_view, p->ls.n_tiles, d_y,
+                    p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
+                kl.stop();
+                CSRK_LAUNCH_CHECK();
+                if (p->n_heavy)
+                    spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(p->ls.n_tiles, 256), 256, 0, s>>>(
+                        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y);
+                else
+                    spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->ls.n_tiles * WAVE, 256), 256, 0, s>>>(
+                        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y);
+                CSRK_LAUNCH_CHECK();
+            } else {
             KernelTimer kt(p, s);
             if (p->n_hot) {
                 if (p->n_heavy)
@@ -1908,6 +2318,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
                     p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
             CSRK_LAUNCH_CHECK();
+            }
         }
         if (p->n_heavy && !p->acc.empty()) {
             if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[0], 0));
@@ -1987,11 +2398,20 @@ int spmv_tier0_view(Matrix *m, Tier0View *out)
     if (p->algo != CSRK_SPMV_MERGE || !p->n_heavy) return CSRK_OK;
     if (!p->tier[0].on && !p->t0_rows.empty()) {
         // SpMV itself runs tier 0 in accumulator form; the dense-panel SpMM wants the pair form
+        // (of the rows that reach the pair form's own threshold: the accumulator form may have extended
+        // tier 0 to shorter rows, which would only add thin pairs there)
         std::lock_guard<std::mutex> lk(m->mu);
-        if (!p->tier[0].on) {
+        std::vector<int32_t> vr;
+        int64_t vn = 0;
+        for (size_t c = 0; c < p->t0_rows.size(); c++)
+            if (p->t0_lens[c] >= p->view_min) {
+                vr.push_back(p->t0_rows[c]);
+                vn += p->t0_lens[c];
+            }
+        if (!p->tier[0].on && !vr.empty()) {
             int rc;
 #define BUILD0(PT_, VT)                                                                                            \
-    rc = build_panel<PT_, VT>(m, &p->tier[0], p->t0_rows, p->t0_nnz, PANEL_CB0, true, PANEL_TPW, false, nullptr)
+    rc = build_panel<PT_, VT>(m, &p->tier[0], vr, vn, PANEL_CB0, true, PANEL_TPW, false, nullptr)
             if (m->ptr64) {
                 if (m->val_type == CSRK_VAL_F64) BUILD0(int64_t, CSRK_VAL_F64);
                 else if (m->val_type == CSRK_VAL_F32) BUILD0(int64_t, CSRK_VAL_F32);
@@ -2013,7 +2433,7 @@ int spmv_tier0_view(Matrix *m, Tier0View *out)
     out->n_rows = t.nrow;
     out->n_blocks = t.nb;
     out->block_cols = t.cb;
-    out->min_entries = HEAVY_MIN;
+    out->min_entries = p->acc.empty() ? p->heavy_min : p->view_min;
     out->pairs = t.rows;
     out->nnz = t.nnz;
     out->rp = t.rp.p;
@@ -2151,14 +2571,15 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
         a_nb = ap->nb;
     }
     const bool af = !p->acc.empty();
-    const int64_t v[20] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    const int64_t v[24] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
-                           af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, HEAVY_MIN, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
+                           af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
                            af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
-                           p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots};
-    for (int i = 0; i < n && i < 20; i++) out[i] = v[i];
+                           p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
+                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid};
+    for (int i = 0; i < n && i < 24; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

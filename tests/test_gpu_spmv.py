@@ -18,10 +18,12 @@ pytestmark = pytest.mark.gpu
 ALGOS = ['merge', 'vector', 'scalar']
 
 
-@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'forced_split_pairs', 'hot', 'forced_split_hot'])
+@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'forced_split_pairs', 'hot', 'forced_split_hot',
+                                      'forced_split_hot_nostream'])
 def split_mode(request, monkeypatch):
     """
-    Every test runs five times: with the library's own choice (small test matrices have an x that fits
+    Every test runs six times (the last one: split + pack with the light stream off, i.e. the merge-path
+    tile kernel in its cut-table + packed-column form): with the library's own choice (small test matrices have an x that fits
     in L2, so the long-row split and the hot-column pack stay off), with the split forced on (the panel
     tiers are exercised on every shape; tier 0 in its default accumulator form), with the split forced on
     and tier 0 in its (block, row)-pair form, with the hot-column pack forced on (renumbered colinds +
@@ -31,6 +33,10 @@ def split_mode(request, monkeypatch):
         monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
     else:
         monkeypatch.delenv('CSRK_SPMV_HEAVY_SPLIT', raising=False)
+    if 'nostream' in request.param:      # the merge-path tile kernel instead of the light stream
+        monkeypatch.setenv('CSRK_SPMV_STREAM', '0')
+    else:
+        monkeypatch.delenv('CSRK_SPMV_STREAM', raising=False)
     if 'pairs' in request.param:
         monkeypatch.setenv('CSRK_SPMV_TIER0', 'pairs')
     else:
@@ -91,8 +97,11 @@ def test_spmv_cfg1(golden, algo):
     y = _mult_vec(a, g['x'], algo)
     _check(y, g['y'], _abs_bound(a, g['x']))
     if algo == 'merge':
-        # rows not cut by a tile boundary are summed in storage order: bit-identical
-        assert np.sum(y != g['y']) <= (a.nrows + a.nnz) // 2048 + 1
+        # rows not cut by a tile boundary (2048-item merge tiles, 512-entry stream tiles) are summed in
+        # storage order, products rounded on their own: bit-identical.  (The stream hands carries over in
+        # order across up to 4 lanes = rows of up to 25 entries wherever they lie.)
+        lens = np.diff(a.rowptrs)
+        assert np.sum(y != g['y']) <= a.nnz // 512 + 1 + int(np.sum(lens > 25))
 
 
 def test_kat_and_protocol(golden):
@@ -367,11 +376,13 @@ def test_concurrent_calls_on_one_handle():
         assert np.allclose(y, r, rtol=1e-12, atol=1e-12)
 
 
-def test_hot_pack_is_bit_identical(monkeypatch):
+def test_hot_pack_is_bit_identical(monkeypatch, split_mode):
     """
     The hot-column pack only changes WHERE an x value is read from (a packed copy instead of x itself):
-    products and summation order are those of the plain tile kernel, so y is bit-identical.
+    products and summation order are those of the same kernel without the pack, so y is bit-identical.
     """
+    if 'nostream' not in split_mode:
+        monkeypatch.setenv('CSRK_SPMV_STREAM', '1')      # both runs on the light stream (eager plan)
     from csr_amd.kernels import hip as K
     from csr_amd import CSR
     rng = np.random.default_rng(4242)
