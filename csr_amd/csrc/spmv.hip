@@ -526,32 +526,28 @@ __global__ __launch_bounds__(256) void hot_census_kernel(const int32_t *__restri
     }
 }
 
-// flag[c] = lo <= cnt[c] < hi
-__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t lo, int64_t hi,
-                                int32_t *__restrict__ flag)
+__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr, int32_t *__restrict__ flag)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= lo && (int64_t)cnt[c] < hi) ? 1 : 0;
+    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= thr) ? 1 : 0;
 }
 
-// Slots in two classes: the columns with cnt >= thr2 first (slots [0, n_top): the light stream keeps their
-// x values in LDS), then those with thr <= cnt < thr2; column order inside a class.
-__global__ void hot_slot_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ slot_top,
-                                const int32_t *__restrict__ slot_rest, int32_t ncols, int32_t thr, int32_t thr2,
-                                int32_t n_top, int32_t *__restrict__ slot)
+// pos[c] = exclusive scan of the flags: the packed columns in column order, with their counts
+__global__ void hot_list_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ pos, int32_t ncols,
+                                int32_t thr, int32_t *__restrict__ hot_cols, int32_t *__restrict__ hot_cnt)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
-    const int32_t v = cnt[c];
-    slot[c] = v >= thr2 ? slot_top[c] : (v >= thr ? n_top + slot_rest[c] : -1);
+    if (c < ncols && cnt[c] >= thr) {
+        hot_cols[pos[c]] = (int32_t)c;
+        hot_cnt[pos[c]] = cnt[c];
+    }
 }
 
-// slot[c] = exclusive scan of the flags; cnt[c] >= thr marks the cached columns
-__global__ void hot_list_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ slot, int32_t ncols,
-                                int32_t thr, int32_t *__restrict__ hot_cols)
+// slot[hot_cols[k]] = k (hot_cols in its final, popularity order)
+__global__ void hot_slot_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t *__restrict__ slot)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncols && cnt[c] >= thr) hot_cols[slot[c]] = (int32_t)c;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_hot) slot[hot_cols[k]] = k;
 }
 
 __global__ void hot_remap_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ cnt,
@@ -1411,8 +1407,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             const uint32_t c = e[j] & LS_COL_MASK;
             const bool hot = (e[j] & LS_HOT_BIT) != 0;
             inl[j] = hot && (int32_t)c < n_lds;
-            const double *g = hot ? xh + c : x + c;
             gv[j] = 0.0;
+            const double *g = hot ? xh + c : x + c;
             if (!inl[j]) gv[j] = *g;
             lv[j] = s_hot[inl[j] ? c : 0];
         }
@@ -1949,7 +1945,9 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     if (env && env[0] == '0') return CSRK_OK;
     const bool force = env && env[0] == '1';
     if (m->nnz < 2 || m->ncols < 1) return CSRK_OK;
-    int64_t HOT_SLOTS = 65536;    // 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
+    int64_t HOT_SLOTS = 524288;   // 4 MiB of packed x, most popular first (light stream, LDS for the first 8192: 64k 0.340,
+                                  // 256k 0.308, 512k 0.302, 1M 0.297, 2M 0.297 ms, but the per-call pack costs more than that gains past 512k)
+                                  // earlier sweep, tile kernel, 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
                                   // 256k 0.430, 1M 0.439, 4M 0.460 ms for the tile kernel; none 0.481)
     if (const char *e = getenv("CSRK_HOT_SLOTS")) HOT_SLOTS = atoll(e) > 0 ? atoll(e) : HOT_SLOTS;
     p->hot_slots = (int32_t)HOT_SLOTS;
@@ -2001,48 +1999,41 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     p->hot_cover = n_samples ? (double)c[1] / (double)n_samples : 0.0;
     if (n_hot == 0 || (!force && p->hot_cover < 0.2)) return CSRK_OK;
 
-    // second threshold: the (at most LS_HOT_LDS) most referenced of the packed columns get the first slots
-    unsigned long long c2[2] = {c[0], c[1]};
-    int64_t lo2 = thr, hi2 = n_samples + 1;           // invariant: census(hi2).n <= LS_HOT_LDS
-    if (c2[0] > (unsigned long long)LS_HOT_LDS) {
-        while (lo2 + 1 < hi2) {
-            const int64_t mid = lo2 + (hi2 - lo2) / 2;
-            CSRK_TRY(census_at((int32_t)(mid > INT32_MAX ? INT32_MAX : mid), c2));
-            if (c2[0] <= (unsigned long long)LS_HOT_LDS)
-                hi2 = mid;
-            else
-                lo2 = mid;
-        }
-        CSRK_TRY(census_at((int32_t)(hi2 > INT32_MAX ? INT32_MAX : hi2), c2));
-        lo2 = hi2;
-    }
-    const int32_t thr2 = (int32_t)(lo2 > INT32_MAX ? INT32_MAX : lo2);
-    const int32_t n_top = (int32_t)c2[0];
-
+    // Slots in order of popularity (count descending, column ascending among equals): the first
+    // LS_HOT_LDS slots are the ones the light stream keeps in LDS, and the packed lines that follow
+    // are referenced less and less often, so what L2 fails to retain is the pack's tail.
     const unsigned gc = (unsigned)ceil_div((int64_t)nc + 1, 256);
-    DevBuf slot_top, slot_rest;
-    CSRK_TRY(slot_top.alloc((size_t)(nc + 2) * 4));
-    CSRK_TRY(slot_rest.alloc((size_t)(nc + 2) * 4));
-    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr2, (int64_t)1 << 40, slot_top.as<int32_t>());
+    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, slot.as<int32_t>());
     CSRK_LAUNCH_CHECK();
-    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, (int64_t)thr2, slot_rest.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(slot_top.as<int32_t>(), slot_top.as<int32_t>(), nc, s));
-    CSRK_TRY(exclusive_scan_i32(slot_rest.as<int32_t>(), slot_rest.as<int32_t>(), nc, s));
-    hot_slot_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot_top.as<int32_t>(), slot_rest.as<int32_t>(), nc, thr, thr2,
-                                      n_top, slot.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(slot.as<int32_t>(), slot.as<int32_t>(), nc, s));
     CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
+    DevBuf hcnt;
+    CSRK_TRY(hcnt.alloc((size_t)n_hot * 4));
+    hot_list_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot.as<int32_t>(), nc, thr, p->hot_cols.as<int32_t>(),
+                                      hcnt.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    {
+        std::vector<int32_t> hc((size_t)n_hot), hn((size_t)n_hot), ord((size_t)n_hot), sorted((size_t)n_hot);
+        CSRK_HIP(hipMemcpyAsync(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipMemcpyAsync(hn.data(), hcnt.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        for (int32_t i = 0; i < n_hot; i++) ord[(size_t)i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return hn[(size_t)a] > hn[(size_t)b]; });
+        for (int32_t i = 0; i < n_hot; i++) sorted[(size_t)i] = hc[(size_t)ord[(size_t)i]];
+        CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, s));
+        CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
+    }
+    hot_slot_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(p->hot_cols.as<int32_t>(), n_hot, slot.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
     CSRK_TRY(p->xh.alloc((size_t)n_hot * 8));
     CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
-    hot_list_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot.as<int32_t>(), nc, thr, p->hot_cols.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
     hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, cnt.as<int32_t>(),
                                                                     slot.as<int32_t>(), thr, p->ci_hot.as<int32_t>());
     CSRK_LAUNCH_CHECK();
+    const int32_t n_top = n_hot < LS_HOT_LDS ? n_hot : LS_HOT_LDS;
     p->n_hot = n_hot;
     p->n_hot_lds = n_top;
-    CSRK_HIP(hipStreamSynchronize(s));     // slot_top / slot_rest are freed on return
+    CSRK_HIP(hipStreamSynchronize(s));     // hcnt is freed on return
     return CSRK_OK;
 }
 
@@ -2283,7 +2274,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 CSRK_HIP(hipMemsetAsync(d_y, 0, (size_t)m->nrows * 8, s));
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-                spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
+spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
                     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
                     p->ls.tile_base.as<int32_t>(), d_x, p->xh.as<double>(), p->n_hot_lds, p->ls.n_view, p->ls.n_tiles, d_y,
                     p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
