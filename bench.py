@@ -65,7 +65,7 @@ def load_traffic(path, workload, kernel):
         try:
             with open(p) as f:
                 d = json.load(f)
-            key = kernel.split(':')[0]           # 'spmv_panel_kernel<tier0: ...>' -> 'spmv_panel_kernel<tier0'
+            key = kernel
             if d.get('workload') == workload and key in d.get('hbm_bytes_per_launch', {}):
                 return float(d['hbm_bytes_per_launch'][key])
         except (OSError, ValueError):
@@ -156,32 +156,48 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 20)()
-    check(lib.csrk_spmv_plan_stats(h, st, 20))
+    st = (C.c_int64 * 24)()
+    check(lib.csrk_spmv_plan_stats(h, st, 24))
     n_heavy, nnz_path = int(st[2]), int(st[3])
     # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
     # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer and
     # writes one y entry per row; a panel kernel reads one 4-B row pointer and writes one 8-B partial per
     # (column block, row) pair of its tier; each kernel reads x once.
-    kernels = [{'kernel': f'spmv_{algo_name}_kernel', 'ms': k_ms2[0], 'entries': nnz_path,
-                'algorithmic_bytes': nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8}]
+    # st[20]: the short rows run as the light stream (else the merge-path tile kernel); st[18]: tier 0 in
+    # accumulator form (st[9] = its rows; one row pointer + one y entry each) or in pair form (st[9] = pairs).
+    light = {'kernel': 'spmv_lstream_kernel', 'role': 'short rows: one wavefront per 512-entry tile of the light stream'} \
+        if int(st[20]) else {'kernel': f'spmv_{algo_name}_kernel', 'role': 'merge-path tiles'}
+    kernels = [dict(light, ms=k_ms2[0], entries=nnz_path,
+                    algorithmic_bytes=nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8)]
     if int(st[10]):
-        kernels.append({'kernel': 'spmv_panel_kernel<tier0: x window in LDS>', 'ms': k_ms2[1], 'entries': int(st[10]),
-                        'algorithmic_bytes': int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8})
+        t0 = {'kernel': 'spmv_acc_kernel', 'role': 'tier 0 (longest rows): x window + one accumulator per row in LDS'} \
+            if int(st[18]) else {'kernel': 'spmv_panel_kernel<tier0>', 'role': 'tier 0, (block, row) pair form: x window in LDS'}
+        kernels.append(dict(t0, ms=k_ms2[1], entries=int(st[10]),
+                            algorithmic_bytes=int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8))
     if int(st[13]):
-        kernels.append({'kernel': 'spmv_panel_kernel<tier1: x window in L2>', 'ms': k_ms2[2], 'entries': int(st[13]),
+        kernels.append({'kernel': 'spmv_panel_kernel<tier1>', 'role': 'tier 1 (mid rows): (block, row) pairs, x window in L2',
+                        'ms': k_ms2[2], 'entries': int(st[13]),
                         'algorithmic_bytes': int(st[13]) * 12 + int(st[12]) * 12 + ncols * 8})
     for k in kernels:
         k['achieved_gbs'] = round(k['algorithmic_bytes'] / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
         k['ms'] = round(k['ms'], 4)
     dom = max(kernels, key=lambda k: k['ms'])
+    k_sum_ms = sum(k['ms'] for k in kernels)
     roofline = {
-        'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved_gbs'], 'peak': HBM_PEAK_GBS,
+        'bound': 'hbm', 'kernel': dom['kernel'], 'role': dom['role'], 'achieved': dom['achieved_gbs'], 'peak': HBM_PEAK_GBS,
         'unit': 'GB/s', 'frac': round(dom['achieved_gbs'] / HBM_PEAK_GBS, 4),
         'traffic': load_traffic(args.traffic_json, workload, dom['kernel']) if world == 1 else None,
         'kernel_ms': dom['ms'], 'launches_timed': n_rec.value, 'algorithmic_bytes': dom['algorithmic_bytes'],
         'frac_of_measured_copy_peak_6290': round(dom['achieved_gbs'] / 6290.0, 4),
         'all_kernels': kernels,
+        # the whole SpMV against the same roofline: 2.60 GB of CSR + x + y over the sum of its three streaming
+        # kernels (device time) and over the step (wall, small kernels and launch gaps included)
+        'whole_spmv': {'algorithmic_bytes': nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8,
+                       'streaming_kernels_ms': round(k_sum_ms, 4),
+                       'frac_over_streaming_kernels': round((nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8)
+                                                            / (k_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_sum_ms > 0 else None,
+                       'frac_over_step': round((nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8)
+                                               / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
     out = {

@@ -23,11 +23,12 @@ with open(f'profiles/{tag}_spmv_kernel_stats.csv', 'w', newline='') as f:
 def pmc(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(f'{src}/{d}/*/*_counter_collection.csv'))):
-        if 'csrk::spmv' in r['Kernel_Name'] or 'csrk::panel' in r['Kernel_Name']:
+        if 'csrk::spmv' in r['Kernel_Name'] or 'csrk::panel' in r['Kernel_Name'] or 'csrk::acc_' in r['Kernel_Name'] \
+                or 'csrk::hot_pack' in r['Kernel_Name']:
             full = r['Kernel_Name'].split('csrk::')[1].split('(')[0]
             name = full.split('<')[0]
             if name == 'spmv_panel_kernel':      # two instantiations: tier 0 (LDS window), tier 1 (L2 window)
-                name += '<tier0' if ', true>' in full else '<tier1'
+                name += '<tier0>' if ', true,' in full else '<tier1>'
             agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 allc = {}
@@ -41,12 +42,13 @@ with open(f'profiles/{tag}_spmv_pmc_counters.csv', 'w', newline='') as f:
 traffic = {}
 for (k, c), v in allc.items():
     if c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        traffic[k] = traffic.get(k, 0.0) + v * 1024.0       # counters are in KB
+        traffic[k] = traffic.get(k, 0.0) + v * 1024.0 * (2.0 if c == 'FETCH_SIZE' else 1.0)   # KB; 128-B reads tallied as 64 B
 out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slots), each with '
-                 '--kernel-trace only; mean over the recorded launches; bytes = (FETCH_SIZE + WRITE_SIZE) * 1024. '
-                 'The guide\'s x2 correction of FETCH_SIZE holds for 16-B-per-lane coalesced streams; these kernels mix '
-                 '4/8/16-B loads and gathers, so the raw value is reported (it can under-count the read side).'}
+                 '--kernel-trace only; mean over the recorded launches. '
+                 'FETCH_SIZE tallies every L2->fabric read request at 64 B, but on gfx950 the vector path issues 128-B '
+                 'requests (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for these kernels, measured), so read bytes = 2 x '
+                 'FETCH_SIZE x 1024 (the correction of MI355X_MICROARCH.md, HBM section); writes = WRITE_SIZE x 1024.'}
 json.dump(out, open(f'profiles/{tag}_spmv_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(out['hbm_bytes_per_launch']))
 print({k: v for k, v in bench['roofline'].items() if k != 'all_kernels'})
