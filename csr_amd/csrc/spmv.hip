@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(1024) void acc_reduce_kernel(const double *__restri
 //   * a segmented scan over the lanes joins runs that cross lanes (fixed tree order: deterministic);
 //   * the tile's leading run, when it continues a row of the previous tile, goes to carry[] and the
 //     existing fix-up kernel adds it to y in tile order.
-// y is zeroed first (rows with no entries, rows served by the tiers until their reduce overwrites them).
+// Rows without a run (no entries, or served by the tiers) are cleared by the run that follows them.
 // Run numbering: run(e) = tile_base[t] - 1 + #{row starts in the tile up to and including e}, with
 // tile_base[t] = index of the row holding the tile's first entry among the non-empty rows, + 1 if that entry
 // is not the row's first.  Needs ncols < 2^30 (two flag bits); otherwise the tile kernel stays in charge.
@@ -1360,8 +1360,8 @@ __device__ __forceinline__ int wave_exscan_i32(int v, int lane)
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const double *__restrict__ x, const double *__restrict__ xh, int32_t n_lds,
-    int64_t n_view, int64_t n_tiles, double *__restrict__ y, int32_t *__restrict__ carry_row,
-    double *__restrict__ carry_val)
+    int64_t n_view, int64_t n_tiles, int32_t n_runs, int32_t nrows, double *__restrict__ y,
+    int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
 {
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
@@ -1479,15 +1479,41 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         if (lane == WAVE - 1) s_out[S + cnt] = okq ? Tq : T;     // the tile's last run (continued by the next tile's slot 0)
         // out: slot k -> the row of run tile_base - 1 + k; consecutive lanes write ascending (mostly
         // consecutive) rows.  LDS operations of one wavefront complete in order: no barrier needed.
-        for (int k = lane; k <= total; k += WAVE) {
-            const double val = s_out[k];
-            if (k == 0) {
-                const bool opens = (st & 1u) != 0;               // lane 0: the tile's first entry opens a row
-                carry_val[t] = val;
-                carry_row[t] = opens ? -1 : rowids[tb > 0 ? tb - 1 : 0];
-            } else {
-                y[rowids[tb - 1 + k]] = val;
+        // Rows without a run -- empty rows, rows served by the tiers (their reduce kernels overwrite y later
+        // in the stream) -- get their zero from the run that follows them: slot k also clears the rows
+        // between the previous run's row and its own.
+        for (int k0 = 0; k0 <= total; k0 += WAVE) {
+            const int k = k0 + lane;
+            int64_t g0 = 0, g1 = 0;                             // rows [g0, g1) to clear
+            if (k <= total) {
+                const double val = s_out[k];
+                if (k == 0) {
+                    const bool opens = (st & 1u) != 0;           // lane 0: the tile's first entry opens a row
+                    carry_val[t] = val;
+                    carry_row[t] = opens ? -1 : rowids[tb > 0 ? tb - 1 : 0];
+                } else {
+                    const int run = tb - 1 + k;
+                    const int32_t r = rowids[run];
+                    y[r] = val;
+                    g0 = run > 0 ? (int64_t)rowids[run - 1] + 1 : 0;
+                    g1 = r;
+                }
             }
+            const int64_t gap = g1 - g0;
+            if (gap > 0 && gap <= 4) {
+                for (int64_t q = g0; q < g1; q++) y[q] = 0.0;
+            }
+            // long gaps: the whole wavefront clears them, one after the other
+            unsigned long long big = __ballot(gap > 4);
+            while (big) {
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                const int64_t b0 = __shfl(g0, src, WAVE), b1 = __shfl(g1, src, WAVE);
+                for (int64_t q = b0 + lane; q < b1; q += WAVE) y[q] = 0.0;
+            }
+        }
+        if (total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
+            for (int64_t q = (int64_t)rowids[n_runs - 1] + 1 + lane; q < nrows; q += WAVE) y[q] = 0.0;
         }
         if (more) {
 #pragma unroll
@@ -2271,12 +2297,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 CSRK_LAUNCH_CHECK();
             }
             if (p->ls.on) {
-                CSRK_HIP(hipMemsetAsync(d_y, 0, (size_t)m->nrows * 8, s));
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
 spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
                     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
-                    p->ls.tile_base.as<int32_t>(), d_x, p->xh.as<double>(), p->n_hot_lds, p->ls.n_view, p->ls.n_tiles, d_y,
+                    p->ls.tile_base.as<int32_t>(), d_x, p->xh.as<double>(), p->n_hot_lds, p->ls.n_view, p->ls.n_tiles,
+                    p->ls.n_runs, m->nrows, d_y,
                     p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
