@@ -78,7 +78,7 @@ struct Panel {
     int32_t cb = 0, nb = 0, nrow = 0;            // block width (columns), blocks, long rows in this tier
     int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
     DevBuf row_list;                             // int32[nrow]: original row ids, ascending
-    DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y, tmp;
+    DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y;
 };
 
 // Tier 0 in accumulator form: one group of <= ACC_MAXROWS heavy rows (see "long rows, accumulator form")
@@ -117,8 +117,8 @@ struct SpmvPlan {
     DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered
     DevBuf hot_cols;    // int32[n_hot]: column of each slot
     DevBuf xh;          // double[n_hot]
-    hipStream_t side[2] = {nullptr, nullptr};   // panel tiers run on forked streams (joined before y is final)
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux = nullptr;    // auxiliary stream: hot pack, tier-1 fix-up/reduce1 beside the streaming kernels
+    hipEvent_t ev_fork = nullptr, ev_pack = nullptr, ev_aux = nullptr, ev_tier[2] = {nullptr, nullptr};
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
                         // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
                         // 131072-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
@@ -147,11 +147,9 @@ struct SpmvPlan {
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        for (int q = 0; q < 2; q++) {
-            if (side[q]) (void)hipStreamDestroy(side[q]);
-            if (ev_join[q]) (void)hipEventDestroy(ev_join[q]);
-        }
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (aux) (void)hipStreamDestroy(aux);
+        for (hipEvent_t e : {ev_fork, ev_pack, ev_aux, ev_tier[0], ev_tier[1]})
+            if (e) (void)hipEventDestroy(e);
         for (AccPanel *a : acc) delete a;
     }
 };
@@ -932,32 +930,6 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #undef PANEL_LOAD_TILE
 }
 
-// y'[b][h] -> chunk sums over b (lane = heavy row: coalesced), then -> y[heavy_row[h]] in chunk order
-constexpr int PANEL_RCHUNKS = 32;
-__global__ __launch_bounds__(256) void panel_reduce1_kernel(const double *__restrict__ yp, int32_t n_heavy,
-                                                           int32_t n_blocks, double *__restrict__ tmp)
-{
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ch = blockIdx.y;
-    if (h >= n_heavy) return;
-    const int per = (n_blocks + PANEL_RCHUNKS - 1) / PANEL_RCHUNKS;
-    const int b0 = ch * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
-    double acc = 0.0;
-    for (int b = b0; b < b1; b++) acc += yp[(int64_t)b * n_heavy + h];
-    tmp[(int64_t)ch * n_heavy + h] = acc;
-}
-
-__global__ __launch_bounds__(256) void panel_reduce2_kernel(const double *__restrict__ tmp, int32_t n_heavy,
-                                                           const int32_t *__restrict__ heavy_row, double *__restrict__ y)
-{
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_heavy) return;
-    double acc = 0.0;
-#pragma unroll 4
-    for (int ch = 0; ch < PANEL_RCHUNKS; ch++) acc += tmp[(int64_t)ch * n_heavy + h];
-    y[heavy_row[h]] = acc;
-}
-
 __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
                                        int64_t *__restrict__ out)
 {
@@ -1723,7 +1695,6 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
     CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
-    CSRK_TRY(pn->tmp.alloc((size_t)PANEL_RCHUNKS * n * 8));
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
     pn->on = true;
     pn->window = window;
@@ -1944,17 +1915,6 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->t0_rows = r0;
     p->t0_lens = len0;
     p->view_min = acc_form ? (base_heavy_min > p->heavy_min ? base_heavy_min : p->heavy_min) : p->heavy_min;
-    // Fork/join streams for the tiers: measured neutral on MI355X (1.231 vs 1.235 ms: the three kernels
-    // are each request/bandwidth-bound, so overlapping them only interleaves the same work); off unless
-    // CSRK_SPMV_STREAMS=1.
-    const char *ms = getenv("CSRK_SPMV_STREAMS");
-    if (ms && ms[0] == '1') {
-        CSRK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        for (int q = 0; q < 2; q++) {
-            CSRK_HIP(hipStreamCreateWithFlags(&p->side[q], hipStreamNonBlocking));
-            CSRK_HIP(hipEventCreateWithFlags(&p->ev_join[q], hipEventDisableTiming));
-        }
-    }
     return CSRK_OK;
 }
 
@@ -2151,6 +2111,14 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
         }
         if (allow_split) {
             CSRK_TRY(build_hot_cache<P>(m, p, s));
+            const char *ax = getenv("CSRK_SPMV_AUX");
+            // (measured on the headline matrix: 0.753 ms with the auxiliary stream, 0.727 without -- the event
+            // hand-overs cost more than the overlap of ~25 us of small kernels gains; off unless CSRK_SPMV_AUX=1)
+            if ((p->n_heavy || p->n_hot) && ax && ax[0] == '1') {
+                CSRK_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+                for (hipEvent_t *e : {&p->ev_fork, &p->ev_pack, &p->ev_aux, &p->ev_tier[0], &p->ev_tier[1]})
+                    CSRK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
             else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
@@ -2235,53 +2203,59 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     if (algo == CSRK_SPMV_MERGE && m->nnz < 2) algo = CSRK_SPMV_SCALAR;   // the tile kernel's pair loads need >= 2 entries
     switch (algo) {
     case CSRK_SPMV_MERGE: {
-        // Fork: the panel tiers are independent of the tile kernel until the final y writes, so they
-        // run on side streams and their tails / fix-up kernels overlap with it.  Join before the
-        // reduce2 kernels, which overwrite the zeros the tile kernel stored for the cut rows.
-        const bool fork = p->n_heavy && p->side[0];
-        if (fork) CSRK_HIP(hipEventRecord(p->ev_fork, s));
+        // Small kernels that do not depend on the big ones' results -- the hot-column pack (needs only x),
+        // the tier-1 carry fix-up and first reduce (need only the tier-1 kernel) -- run on the plan's auxiliary
+        // stream beside the streaming kernels; everything that writes y stays in order on `s`.
+        const bool aux = p->aux != nullptr;
+        hipStream_t sa = aux ? p->aux : s;
+        if (aux) {
+            CSRK_HIP(hipEventRecord(p->ev_fork, s));
+            CSRK_HIP(hipStreamWaitEvent(sa, p->ev_fork, 0));
+        }
+        if (p->n_hot) {
+            hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, sa>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
+                                                                             p->xh.as<double>());
+            CSRK_LAUNCH_CHECK();
+            if (aux) CSRK_HIP(hipEventRecord(p->ev_pack, sa));
+        }
         if (p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
-            hipStream_t sq = fork ? p->side[0] : s;
-            if (fork) CSRK_HIP(hipStreamWaitEvent(sq, p->ev_fork, 0));
-            KernelTimer kh(p, sq, 1);
+            KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
-                spmv_acc_kernel<ACC_CB, ACC_THREADS><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, sq>>>(
+                spmv_acc_kernel<ACC_CB, ACC_THREADS><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
                     ap->vals.as<double>(), ap->idx.as<uint32_t>(), d_x, m->ncols, ap->segs.as<AccSeg>(),
                     ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
                 CSRK_LAUNCH_CHECK();
             }
             kh.stop();
-            if (fork) CSRK_HIP(hipEventRecord(p->ev_join[0], sq));
         }
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
-            hipStream_t sq = fork ? p->side[q] : s;
-            if (fork) CSRK_HIP(hipStreamWaitEvent(sq, p->ev_fork, 0));
-            KernelTimer kh(p, sq, 1 + q);
+            KernelTimer kh(p, s, 1 + q);
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
         pn->carry_val.as<double>(), pn->nnz
             const unsigned grid = (unsigned)pn->groups;
             if (q == 0) {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, sq>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, sq>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, s>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, s>>>(PANEL_ARGS(int32_t));
             } else {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, sq>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, sq>>>(PANEL_ARGS(int32_t));
+                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
+                else spmv_panel_kernel<int32_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
             }
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
-            spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sq>>>(
+            if (aux) {
+                CSRK_HIP(hipEventRecord(p->ev_tier[q], s));
+                CSRK_HIP(hipStreamWaitEvent(sa, p->ev_tier[q], 0));
+            }
+            spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sa>>>(
                 pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
             CSRK_LAUNCH_CHECK();
-            panel_reduce1_kernel<<<dim3((unsigned)ceil_div(pn->nrow, 256), PANEL_RCHUNKS), 256, 0, sq>>>(
-                pn->y.as<double>(), pn->nrow, pn->nb, pn->tmp.as<double>());
-            CSRK_LAUNCH_CHECK();
-            if (fork) CSRK_HIP(hipEventRecord(p->ev_join[q], sq));
         }
+        if (aux && p->n_hot) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
         {
 #define MERGE_ARGS_LIGHT(CI)                                                                                        \
     p->rp_light.as<P>(), CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, p->nnz_light,                \
@@ -2291,11 +2265,6 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     rp, CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz, p->carry_row.as<int32_t>(),          \
         p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz, p->xh.as<double>()
             const unsigned grid = (unsigned)p->n_tiles;
-            if (p->n_hot) {
-                hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
-                                                                                p->xh.as<double>());
-                CSRK_LAUNCH_CHECK();
-            }
             if (p->ls.on) {
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
@@ -2337,8 +2306,11 @@ spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
             CSRK_LAUNCH_CHECK();
             }
         }
+        if (aux) {      // join: the reduces below read what the auxiliary stream produced
+            CSRK_HIP(hipEventRecord(p->ev_aux, sa));
+            CSRK_HIP(hipStreamWaitEvent(s, p->ev_aux, 0));
+        }
         if (p->n_heavy && !p->acc.empty()) {
-            if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[0], 0));
             for (AccPanel *ap : p->acc) {
                 acc_reduce_kernel<<<(unsigned)ceil_div(ap->nrow, WAVE), 1024, 0, s>>>(
                     ap->partial.as<double>(), ap->nrow, ap->n_wg, ap->row_list.as<int32_t>(), d_y);
@@ -2348,9 +2320,9 @@ spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
-            if (fork) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join[q], 0));
-            panel_reduce2_kernel<<<(unsigned)ceil_div(pn->nrow, 256), 256, 0, s>>>(
-                pn->tmp.as<double>(), pn->nrow, pn->row_list.as<int32_t>(), d_y);
+            // y[row] = sum over column blocks of the (block, row) partials, in block order
+            acc_reduce_kernel<<<(unsigned)ceil_div(pn->nrow, WAVE), 1024, 0, s>>>(
+                pn->y.as<double>(), pn->nrow, pn->nb, pn->row_list.as<int32_t>(), d_y);
             CSRK_LAUNCH_CHECK();
         }
         break;
