@@ -117,10 +117,12 @@ CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *til
 
 /* out[0..n) <- {0 tiles (or segments), 1 items per tile, 2 rows cut out of the tile path, 3 entries on
  * the tile path, 4 tier-0 tiles, 5 tier-0 column blocks, 6 tier-0 row threshold, 7 tier-0 block width,
- * 8 split mode (0 none, 2 panels), 9 tier-0 (block,row) pairs, 10 tier-0 entries, 11 tier-1 rows,
- * 12 tier-1 pairs, 13 tier-1 entries, 14 tier-1 row threshold, 15 tier-1 block width,
- * 16 columns in the hot-column pack (0: none), 17 sampled share of the tile path's entries on packed columns (ppm),
- * 18 reserved (0), 19 pack slots}; n <= 20. */
+ * 8 split mode (0 none, 2 panels), 9 tier-0 (block,row) pairs (pair form) or rows (accumulator form),
+ * 10 tier-0 entries, 11 tier-1 rows, 12 tier-1 pairs, 13 tier-1 entries, 14 tier-1 row threshold,
+ * 15 tier-1 block width, 16 columns in the hot-column pack (0: none), 17 sampled share of the row-major
+ * path's entries on packed columns (ppm), 18 tier-0 form (0 pairs, 1 accumulator), 19 pack slots,
+ * 20 short rows on the light stream (1) or on the merge-path tile kernel (0), 21 light-stream tiles,
+ * 22 non-empty rows of the light stream, 23 its workgroups}; n <= 24. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
