@@ -24,10 +24,11 @@
 
 namespace csrk {
 
-constexpr int RX_THREADS = 256;
+constexpr int RX_THREADS = 512;
 constexpr int RX_ROUNDS = 8;
-constexpr int RX_CHUNK = RX_THREADS * RX_ROUNDS;
+constexpr int RX_CHUNK = RX_THREADS * RX_ROUNDS;     // 4096 records per workgroup (8192: 0.67 vs 0.65 ms)
 constexpr int RX_WAVES = RX_THREADS / WAVE;
+constexpr int RX_WSPAN = WAVE * RX_ROUNDS;            // 512 consecutive records per wavefront
 
 // ---- output row pointers from the sorted keys ----------------------------------------------
 // A histogram with global atomics serialises on popular columns (1.8 ms for the MovieLens-shaped
@@ -35,13 +36,43 @@ constexpr int RX_WAVES = RX_THREADS / WAVE;
 // brp[c] = first position whose key is >= c (the reference's histogram + running sum,
 // csr/structure.py:180-188).
 template <class P>
-__global__ void rowptr_from_sorted_keys(const int32_t *__restrict__ keys, int64_t n, int32_t ncols, P *__restrict__ brp)
+__global__ __launch_bounds__(256) void rowptr_from_sorted_keys(const int32_t *__restrict__ keys, int64_t n, int32_t ncols,
+                                                              P *__restrict__ brp)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    const int64_t lo = i == 0 ? 0 : (int64_t)keys[i - 1] + 1;
-    const int64_t hi = i == n ? (int64_t)ncols : (int64_t)keys[i];
-    for (int64_t c = lo; c <= hi; c++) brp[c] = (P)i;
+    // four consecutive positions per thread: one 16-B load + the key before them
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 > n) return;
+    int32_t k[5];
+    k[0] = i0 == 0 ? -1 : keys[i0 - 1];
+    if (i0 + 4 <= n) {
+        const int4 v = *(const int4 *)(keys + i0);       // keys comes from the pool allocator: 256-B aligned
+        k[1] = v.x;
+        k[2] = v.y;
+        k[3] = v.z;
+        k[4] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) k[q + 1] = i0 + q < n ? keys[i0 + q] : ncols;      // position n: closes the last columns
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int64_t i = i0 + q;
+        if (i > n) break;
+        const int64_t lo = (int64_t)k[q] + 1;
+        const int64_t hi = i == n ? (int64_t)ncols : (int64_t)k[q + 1];
+        for (int64_t c = lo; c <= hi; c++) brp[c] = (P)i;
+    }
+}
+
+// Workgroup -> chunk: consecutive chunks go to workgroups b, b + 8, b + 16, ... -- which share an XCD and
+// hence an L2 (blocks are dealt round-robin over the 8 XCDs; a speed assumption only).  Neighbouring chunks
+// write neighbouring pieces of every digit's output run, each piece a fraction of a 128-B line: in one L2 the
+// pieces merge into whole lines before they are written back.
+__device__ __forceinline__ int64_t rx_chunk_of(int64_t b, int64_t n_chunks)
+{
+    const int64_t per = (n_chunks + 7) / 8;             // chunks per XCD group
+    const int64_t c = (b % 8) * per + b / 8;
+    return c;                                           // may be >= n_chunks (grid is padded to 8 * per)
 }
 
 // ---- radix pass: histogram ----------------------------------------------------------------
@@ -49,16 +80,83 @@ __global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const int32_t *__re
                                                             int64_t n_chunks, int64_t *__restrict__ table)
 {
     __shared__ int32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    const int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
+    const int cnt = (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
+    int32_t key[RX_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < RX_ROUNDS; r++) {
-        int64_t i = base + r * RX_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    for (int r = 0; r < RX_ROUNDS; r++) {        // unconditional (clamped) loads: all in flight together
+        const int k = r * RX_THREADS + threadIdx.x;
+        key[r] = keys[base + (k < cnt ? k : cnt - 1)];
     }
     __syncthreads();
-    table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = h[threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < RX_ROUNDS; r++)
+        if (r * RX_THREADS + (int)threadIdx.x < cnt) atomicAdd(&h[(key[r] >> shift) & 255], 1);
+    __syncthreads();
+    if (threadIdx.x < 256) table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- radix pass: table scan ------------------------------------------------------------------
+// table[d][c] (digit-major) -> exclusive prefix inside digit d's row (in place) and total[d]; the scatter
+// kernel adds the exclusive scan of the 256 totals itself.  One workgroup per digit, one launch -- instead
+// of a generic three-launch device scan of the 256 * n_chunks counts.
+constexpr int RXS_THREADS = 1024;
+constexpr int RXS_IPT = 8;
+__global__ __launch_bounds__(RXS_THREADS) void rx_scan_kernel(int64_t *__restrict__ table, int64_t n_chunks,
+                                                             int64_t *__restrict__ total)
+{
+    __shared__ int64_t s_w[RXS_THREADS / WAVE];
+    __shared__ int64_t s_carry;
+    int64_t *row = table + (int64_t)blockIdx.x * n_chunks;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += RXS_THREADS * RXS_IPT) {
+        const int64_t b = c0 + (int64_t)tid * RXS_IPT;
+        int64_t v[RXS_IPT], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < RXS_IPT; k++) {
+            v[k] = b + k < n_chunks ? row[b + k] : 0;
+            tsum += v[k];
+        }
+        int64_t inc = tsum;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        int64_t run = s_carry + inc - tsum;
+        for (int k = 0; k < w; k++) run += s_w[k];
+#pragma unroll
+        for (int k = 0; k < RXS_IPT; k++) {
+            if (b + k < n_chunks) row[b + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == RXS_THREADS - 1) s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) total[blockIdx.x] = s_carry;
+}
+
+// first / last source row whose extent meets each chunk (first radix pass of a transpose)
+template <class P>
+__device__ __forceinline__ int32_t row_of(const P *__restrict__ rp, int64_t i, int32_t lo, int32_t hi);
+
+template <class P>
+__global__ void rx_rowbounds_kernel(const P *__restrict__ rp, int32_t nrows, int64_t n, int64_t n_chunks, int chunk,
+                                    int32_t *__restrict__ rlo, int32_t *__restrict__ rhi)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int64_t first = c * chunk;
+    const int64_t last = first + chunk - 1 < n - 1 ? first + chunk - 1 : n - 1;
+    const int32_t a = row_of(rp, first, 0, nrows - 1);
+    rlo[c] = a;
+    rhi[c] = row_of(rp, last, a, nrows - 1);
 }
 
 // source row of entry i, searched inside [lo, hi] (rows whose extents meet this chunk)
@@ -93,46 +191,53 @@ template <class P, int VT, int MODE>
 __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     const int32_t *__restrict__ keys_in, const int32_t *__restrict__ rows_in, const void *__restrict__ vals_in,
     const P *__restrict__ rp, int32_t nrows, int64_t n, int shift, int64_t n_chunks,
-    const int64_t *__restrict__ table, int32_t *__restrict__ keys_out, int32_t *__restrict__ rows_out,
+    const int64_t *__restrict__ table, const int64_t *__restrict__ total, const int32_t *__restrict__ chunk_rlo,
+    const int32_t *__restrict__ chunk_rhi, int32_t *__restrict__ keys_out, int32_t *__restrict__ rows_out,
     double *__restrict__ vals_out)
 {
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
     constexpr bool FIRST = MODE == 1;
     __shared__ int64_t s_goff[256];               // global offset of this chunk's run per digit
     __shared__ int32_t s_loff[256];               // offset of the digit's run inside the chunk
-    __shared__ int32_t s_run[256];                // records of each digit already placed
-    __shared__ int32_t s_wcnt[RX_WAVES][256];     // per-wave digit counts of the current round
+    __shared__ int32_t s_wh[RX_WAVES][256];       // per-wavefront digit counts, then exclusive prefix over wavefronts
     __shared__ int32_t s_key[RX_CHUNK];           // the chunk in output order
     __shared__ int32_t s_row[RX_CHUNK];           // (FIRST: holds the source row of every entry first)
     __shared__ double s_val[HAS_V ? RX_CHUNK : 1];
-    __shared__ int32_t s_rlo, s_rhi;
     __shared__ int32_t s_tmax[RX_WAVES];
+    __shared__ int64_t s_dtot[4];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    const int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
+    const int64_t chunk = rx_chunk_of(blockIdx.x, n_chunks);
+    if (chunk >= n_chunks) return;
+    const int64_t base = chunk * RX_CHUNK;
     const int cnt = (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
-    s_goff[tid] = table[(int64_t)tid * n_chunks + blockIdx.x];
-    s_run[tid] = 0;
-    s_loff[tid] = 0;
+    if (tid < 256) {
+        // global offset of this chunk's run of digit `tid` = exclusive scan of the digit totals + the
+        // in-row prefix left by rx_scan_kernel
+        const int64_t t = total[tid];
+        int64_t inc = t;
 #pragma unroll
-    for (int k = 0; k < RX_WAVES; k++) s_wcnt[k][tid] = 0;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) s_dtot[w] = inc;
+        s_goff[tid] = inc - t + table[(int64_t)tid * n_chunks + chunk];
+    }
+#pragma unroll
+    for (int k = tid; k < RX_WAVES * 256; k += RX_THREADS) (&s_wh[0][0])[k] = 0;
 
-    // the chunk's records -> registers (coalesced), digits -> local histogram
+    // Record k of the chunk is owned by wavefront k / 512, round (k % 512) / 64, lane k % 64: a wavefront
+    // holds 512 CONSECUTIVE records (coalesced 64-record loads per round), so stable order inside the chunk is
+    // (wavefront, round, lane).
     int32_t key[RX_ROUNDS], row[RX_ROUNDS];
     double val[RX_ROUNDS];
     if (FIRST) {
         // Source rows for the whole chunk at once: mark each row's first entry with its id (the
         // largest id wins where empty rows share a position) and take a running maximum -- instead of
         // one binary search over rowptrs per entry.  s_row is the scratch array.
-        if (tid == 0) {
-            int64_t last = base + cnt - 1;
-            s_rlo = row_of(rp, base, 0, nrows - 1);
-            s_rhi = row_of(rp, last, s_rlo, nrows - 1);
-        }
-        for (int k = tid; k < RX_CHUNK; k += RX_THREADS) s_row[k] = 0;
-        __syncthreads();
-        const int32_t rlo = s_rlo, rhi = s_rhi;
-        if (tid == 0) s_row[0] = rlo;
+        const int32_t rlo = chunk_rlo[chunk], rhi = chunk_rhi[chunk];      // rx_rowbounds_kernel
+        for (int k = tid; k < RX_CHUNK; k += RX_THREADS) s_row[k] = k == 0 ? rlo : 0;
         __syncthreads();
         for (int32_t r = rlo + 1 + tid; r <= rhi; r += RX_THREADS) {
             const int64_t pos = (int64_t)rp[r] - base;
@@ -166,11 +271,12 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     }
 #pragma unroll
     for (int r = 0; r < RX_ROUNDS; r++) {
-        const int k = r * RX_THREADS + tid;
-        const int64_t i = base + (k < cnt ? k : cnt - 1);           // clamped: loads stay unconditional
+        const int k = w * RX_WSPAN + r * WAVE + lane;
+        const int kc = k < cnt ? k : cnt - 1;                       // clamped: loads stay unconditional
+        const int64_t i = base + kc;
         key[r] = keys_in[i];
         if (FIRST) {
-            row[r] = s_row[k < cnt ? k : cnt - 1];
+            row[r] = s_row[kc];
             if (VT == CSRK_VAL_F64) val[r] = ((const double *)vals_in)[i];
             else if (VT == CSRK_VAL_F32) val[r] = (double)((const float *)vals_in)[i];
             else val[r] = 0.0;
@@ -180,63 +286,69 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
             else val[r] = HAS_V ? ((const double *)vals_in)[i] : 0.0;
         }
     }
-    __syncthreads();                                  // FIRST: everyone has read its rows out of s_row
+    __syncthreads();                  // FIRST: everyone has read its rows out of s_row; s_wh is zeroed
+
+    // Stable rank of every record among the records of its digit in this wavefront: the wavefront's own
+    // digit counters (LDS, touched by this wavefront only, whose LDS operations complete in order) give the
+    // records of earlier rounds, a ballot match the lower lanes of this round.  No workgroup barrier inside.
+    int32_t rank[RX_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < RX_ROUNDS; r++)
-        if (r * RX_THREADS + tid < cnt) atomicAdd(&s_loff[(key[r] >> shift) & 255], 1);
+    for (int r = 0; r < RX_ROUNDS; r++) {
+        const bool valid = w * RX_WSPAN + r * WAVE + lane < cnt;
+        const int d = (key[r] >> shift) & 255;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long bm = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bm : ~bm;
+        }
+        const int below = __popcll(peers & ((1ull << lane) - 1ull));
+        const int old = s_wh[w][d];
+        rank[r] = old + below;
+        if (valid && below == 0) s_wh[w][d] = old + __popcll(peers);
+    }
     __syncthreads();
-    {   // exclusive scan of the 256 digit counts (one digit per thread)
-        const int32_t c = s_loff[tid];
-        int32_t inc = c;
+    if (tid < 256) {
+        // digit `tid`: counts per wavefront -> exclusive prefix over wavefronts; chunk total -> scan over digits
+        int32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; k++) {
+            const int32_t c = s_wh[k][tid];
+            s_wh[k][tid] = run;
+            run += c;
+        }
+        int32_t inc = run;
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) {
             const int32_t o = __shfl_up(inc, off, WAVE);
             if (lane >= off) inc += o;
         }
         if (lane == WAVE - 1) s_tmax[w] = inc;
-        __syncthreads();
-        int32_t pre = inc - c;
-        for (int k = 0; k < w; k++) pre += s_tmax[k];
-        s_loff[tid] = pre;
+        s_loff[tid] = inc - run;          // exclusive inside the wavefront; the other wavefronts' totals are added below
     }
     __syncthreads();
-
-    // stable ranking, round by round, into the LDS image
+    if (tid < 256) {
+        int32_t pre = s_loff[tid];
+        int64_t gpre = 0;
+        for (int k = 0; k < w; k++) {
+            pre += s_tmax[k];
+            gpre += s_dtot[k];
+        }
+        s_loff[tid] = pre;
+        s_goff[tid] += gpre;
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < RX_ROUNDS; r++) {
-        const bool valid = r * RX_THREADS + tid < cnt;
-        const int d = (key[r] >> shift) & 255;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            unsigned long long bm = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? bm : ~bm;
-        }
-        const int below = __popcll(peers & ((1ull << lane) - 1ull));
-        if (valid && below == 0) s_wcnt[w][d] = __popcll(peers);
-        __syncthreads();
-        if (valid) {
-            int pre = s_run[d];
-#pragma unroll
-            for (int k = 0; k < RX_WAVES; k++)
-                if (k < w) pre += s_wcnt[k][d];
-            const int o = s_loff[d] + pre + below;
+        if (w * RX_WSPAN + r * WAVE + lane < cnt) {
+            const int d = (key[r] >> shift) & 255;
+            const int o = s_loff[d] + s_wh[w][d] + rank[r];
             s_key[o] = key[r];
             s_row[o] = row[r];
             if (HAS_V) s_val[o] = val[r];
         }
-        __syncthreads();
-        {
-            int tot = 0;
-#pragma unroll
-            for (int k = 0; k < RX_WAVES; k++) {
-                tot += s_wcnt[k][tid];
-                s_wcnt[k][tid] = 0;
-            }
-            s_run[tid] += tot;
-        }
-        __syncthreads();
     }
+    __syncthreads();
 
     // write out: consecutive lanes -> consecutive positions of a digit's run
     for (int j = tid; j < cnt; j += RX_THREADS) {
@@ -268,8 +380,16 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
     int passes = bits <= 8 ? 1 : (bits + 7) / 8;
     const int64_t n_chunks = ceil_div(n, RX_CHUNK);
 
-    DevBuf table, keyA, keyB, rowA, rowB, valA, valB, keyL;
+    DevBuf table, total, rlo, rhi, keyA, keyB, rowA, rowB, valA, valB, keyL;
     CSRK_TRY(table.alloc((size_t)(256 * n_chunks + 1) * 8));
+    CSRK_TRY(total.alloc(256 * 8));
+    if (FROM_CSR) {
+        CSRK_TRY(rlo.alloc((size_t)n_chunks * 4));
+        CSRK_TRY(rhi.alloc((size_t)n_chunks * 4));
+        rx_rowbounds_kernel<P><<<(unsigned)ceil_div(n_chunks, 256), 256, 0, s>>>(rp, rp_rows, n, n_chunks, RX_CHUNK,
+                                                                              rlo.as<int32_t>(), rhi.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+    }
     CSRK_TRY(keyL.alloc((size_t)n * 4));          // sorted keys of the last pass -> run starts
     if (passes > 1) {
         CSRK_TRY(keyA.alloc((size_t)n * 4));
@@ -293,10 +413,13 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         double *v_out = !HAS_V ? nullptr : (last ? out_vals : ((p & 1) ? valB.as<double>() : valA.as<double>()));
         rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        CSRK_TRY(exclusive_scan_i64(table.as<int64_t>(), table.as<int64_t>(), 256 * n_chunks, s));
-        const unsigned grid = (unsigned)n_chunks;
+        rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks, total.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)(8 * ceil_div(n_chunks, 8));
         constexpr int VMID = HAS_V ? CSRK_VAL_F64 : CSRK_VAL_NONE;   // intermediates are float64
-#define RX_ARGS k_in, r_in, v_in, rp, rp_rows, n, shift, n_chunks, table.as<int64_t>(), k_out, r_out, v_out
+#define RX_ARGS                                                                                                     \
+    k_in, r_in, v_in, rp, rp_rows, n, shift, n_chunks, table.as<int64_t>(), total.as<int64_t>(), rlo.as<int32_t>(),    \
+        rhi.as<int32_t>(), k_out, r_out, v_out
         if (first)
             rx_scatter_kernel<P, VT, FROM_CSR ? 1 : 2><<<grid, RX_THREADS, 0, s>>>(RX_ARGS);
         else
@@ -307,7 +430,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         r_in = r_out;
         v_in = v_out;
     }
-    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(n + 1, 256), 256, 0, s>>>(keyL.as<int32_t>(), n, key_range, out_ptr);
+    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(ceil_div(n + 1, 4), 256), 256, 0, s>>>(keyL.as<int32_t>(), n, key_range, out_ptr);
     CSRK_LAUNCH_CHECK();
     CSRK_HIP(hipStreamSynchronize(s));   // temporaries go back to the pool on return
     return CSRK_OK;
