@@ -11,7 +11,8 @@ step of the path:
 
   allgather  (default) every rank contributes its y slice; slices are padded to the longest
              one so a single all_gather_into_tensor moves them (xGMI is point-to-point: the
-             7 peers' slices arrive over 7 links concurrently), then unpadded into y.
+             7 peers' slices arrive over 7 links concurrently), then unpadded into y by one
+             concatenation kernel.
   allreduce  the form BASELINE.json's north_star names: each rank writes its slice into a
              zeroed full-length y and the ranks sum.  Same result (the slices are disjoint, so
              every sum has one non-zero term and is exact), about twice the bytes per link.
@@ -44,6 +45,9 @@ class RowPartitionedSpMV:
             self.maxlen = max(self.lens)
             self.loc = torch.zeros(self.maxlen, dtype=torch.float64, device=device)
             self.gath = torch.zeros(world * self.maxlen, dtype=torch.float64, device=device)
+            # the slices of `gath` that make up y, in rank order: unpadded by ONE concatenation kernel
+            self.pieces = [self.gath[g * self.maxlen:g * self.maxlen + self.lens[g]] for g in range(world)
+                           if self.lens[g]]
 
     def _local(self, x, out):
         if self.timing and out.is_cuda:
@@ -71,10 +75,8 @@ class RowPartitionedSpMV:
         if self.mode == 'allgather':
             self._local(x, self.loc[:self.r1 - self.r0])
             dist.all_gather_into_tensor(self.gath, self.loc, group=self.group)
-            for g in range(self.world):
-                if self.lens[g]:
-                    self.y[self.bounds[g]:self.bounds[g + 1]].copy_(
-                        self.gath[g * self.maxlen:g * self.maxlen + self.lens[g]])
+            if self.pieces:
+                torch.cat(self.pieces, out=self.y)
             return self.y
         # allreduce: zero what the previous step left in the other ranks' slices
         if self.r0 > 0:
