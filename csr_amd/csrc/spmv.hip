@@ -89,6 +89,17 @@ struct AccPanel {
     DevBuf row_list, vals, idx, segs, wg_seg, partial;
 };
 
+// A light stream (see "short rows: the light stream"): a private tiled copy of a set of rows ("runs") plus
+// the tables the one-wavefront-per-tile kernel needs.  Two instances per plan: the short rows of the matrix,
+// and tier 1 (runs = (column block, row) pairs, output = the pair partials).
+struct LightStream {
+    bool on = false;
+    int64_t n_tiles = 0;
+    int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
+    unsigned grid = 0;
+    DevBuf vals, idx, rowids, tile_base, carry_idx, carry_row, carry_val;
+};
+
 struct SpmvPlan {
     int algo = CSRK_SPMV_MERGE;
     // merge
@@ -122,14 +133,8 @@ struct SpmvPlan {
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
                         // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
                         // 131072-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
-    // the light stream: private tiled copy of the rows that stay on the row-major path
-    struct {
-        bool on = false;
-        int64_t n_view = 0, n_tiles = 0;
-        int32_t n_runs = 0;
-        unsigned grid = 0;
-        DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
-    } ls;
+    LightStream ls;                       // the rows that stay on the row-major path
+    LightStream t1s;                      // tier 1 as a stream of (column block, row) runs
     std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
     std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths: source of either form
     std::vector<int64_t> t0_lens;
@@ -1245,8 +1250,10 @@ __global__ __launch_bounds__(1024) void acc_reduce_kernel(const double *__restri
 // is not the row's first.  Needs ncols < 2^30 (two flag bits); otherwise the tile kernel stays in charge.
 constexpr int LS_THREADS = 1024;            // one persistent workgroup per CU
 constexpr int LS_HOT_LDS = 8192;            // packed columns kept in LDS (64 KiB)
+constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile
 constexpr int LS_SEQ = 3;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
 constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
+constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
 
 // smallest r in [0, nrows) with rpv[r + 1] > L (the row holding view entry L); L < rpv[nrows]
 template <class P>
@@ -1278,24 +1285,44 @@ __global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const
     if (r < nrows && rpv[r + 1] > rpv[r]) rowids[ridx[r]] = (int32_t)r;
 }
 
-// one thread per stream slot: view entry L of row r is the actual entry rp[r] + (L - rpv[r]) (rows of the
-// view are whole rows of the matrix or empty); slots past the view's end are padding
-template <class P, int VT>
-__global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ rp, const P *__restrict__ rpv, int32_t nrows,
-                                                     const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                                     int64_t n_view, int64_t n_slots, double *__restrict__ svals,
-                                                     uint32_t *__restrict__ sidx)
+// A stream is laid out as up to 8 sub-streams (one for the short rows; one per XCD for tier 1), each a
+// whole number of tiles: sub-stream q holds the view entries [ent0[q], ent0[q+1]) in the logical slots
+// starting at slot0[q] (a multiple of ACC_TILE); slots past a sub-stream's entries are padding.
+struct LsSegs {
+    int32_t n;
+    int64_t slot0[9], ent0[9];
+};
+
+__device__ __forceinline__ int ls_seg_of(const LsSegs &sg, int64_t slot)
 {
-    const int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= n_slots) return;
-    const int64_t t = L / ACC_TILE;
-    const int el = (int)(L % ACC_TILE);
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++)
+        if (k < sg.n && slot >= sg.slot0[k]) q = k;
+    return q;
+}
+
+// One thread per logical slot: view entry L of view row r is the source entry src[r] + (L - rpv[r]) (a view
+// row is a whole row of the source or empty).  phys_tile (optional): where each logical tile is stored.
+template <class P, int VT>
+__global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
+                                                     const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                     LsSegs sg, int64_t n_slots, const int32_t *__restrict__ phys_tile,
+                                                     double *__restrict__ svals, uint32_t *__restrict__ sidx)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int64_t lt = slot / ACC_TILE;
+    const int64_t t = phys_tile ? (int64_t)phys_tile[lt] : lt;
+    const int el = (int)(slot % ACC_TILE);
+    const int q = ls_seg_of(sg, slot);
+    const int64_t L = sg.ent0[q] + (slot - sg.slot0[q]);
     double v = 0.0;
-    uint32_t ix = 0;
-    if (L < n_view) {
+    uint32_t ix = LS_PAD;
+    if (L < sg.ent0[q + 1]) {
         const int32_t r = ls_row_of(rpv, nrows, L);
         const int64_t first = (int64_t)rpv[r];
-        const int64_t a = (int64_t)rp[r] + (L - first);
+        const int64_t a = (int64_t)src[r] + (L - first);
         v = ValLoad<VT>::at(vs, a);
         const int32_t c = ci[a];
         ix = c < 0 ? (LS_HOT_BIT | (uint32_t)~c) : (uint32_t)c;
@@ -1305,15 +1332,21 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ rp, 
     sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
 }
 
+// per logical tile: run numbering base (stored at the tile's physical place) and the inverse placement
 template <class P>
 __global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
-                                   int64_t n_tiles, int32_t *__restrict__ tile_base)
+                                   LsSegs sg, int64_t n_tiles, const int32_t *__restrict__ phys_tile,
+                                   int32_t *__restrict__ tile_base, int32_t *__restrict__ carry_idx)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int64_t e0 = t * ACC_TILE;
+    const int64_t lt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lt >= n_tiles) return;
+    const int64_t slot = lt * ACC_TILE;
+    const int q = ls_seg_of(sg, slot);
+    const int64_t e0 = sg.ent0[q] + (slot - sg.slot0[q]);      // < ent0[q + 1]: a sub-stream has no empty tile
     const int32_t r = ls_row_of(rpv, nrows, e0);
+    const int64_t t = phys_tile ? (int64_t)phys_tile[lt] : lt;
     tile_base[t] = ridx[r] + ((int64_t)rpv[r] == e0 ? 0 : 1);
+    if (carry_idx) carry_idx[t] = (int32_t)lt;
 }
 
 __device__ __forceinline__ int wave_exscan_i32(int v, int lane)
@@ -1331,10 +1364,15 @@ __device__ __forceinline__ int wave_exscan_i32(int v, int lane)
 // here instead of gathered), then one staging buffer of ACC_TILE + 2 run sums per wavefront.
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
-    const int32_t *__restrict__ tile_base, const double *__restrict__ x, const double *__restrict__ xh, int32_t n_lds,
-    int64_t n_view, int64_t n_tiles, int32_t n_runs, int32_t nrows, double *__restrict__ y,
-    int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
+    const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
+    const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
+    double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
 {
+    // No FMA contraction in this kernel: the reference rounds every product before adding it.  (HIP's rounding
+    // intrinsics for multiply and add are plain * and + inside inline functions compiled with
+    // -ffp-contract=fast and fuse after inlining -- measured: 2041 instead of 75 rows of BASELINE configs[0]
+    // differed in the last bits; the pragma governs the operators written in this body.)
+#pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
@@ -1381,8 +1419,15 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             inl[j] = hot && (int32_t)c < n_lds;
             gv[j] = 0.0;
             const double *g = hot ? xh + c : x + c;
-            if (!inl[j]) gv[j] = *g;
+            if (!inl[j] && e[j] != LS_PAD) gv[j] = *g;          // padding slots gather nothing and multiply 0 * 0
             lv[j] = s_hot[inl[j] ? c : 0];
+        }
+        // row ids of the tile's first run slots (slot k <-> run tb - 1 + k): requested now, used at the end
+        int32_t rid[LS_RID];
+#pragma unroll
+        for (int i = 0; i < LS_RID; i++) {
+            const int run = tb - 1 + lane + i * WAVE;
+            rid[i] = rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)];
         }
         // row starts: bit j of st = entry j opens a row
         uint32_t st = 0;
@@ -1391,15 +1436,12 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         const int cnt = __popc(st);
         const int S = wave_exscan_i32(cnt, lane);          // row starts in the lanes below
         const int total = __shfl(S + cnt, WAVE - 1, WAVE);   // row starts in the tile
-        const bool tail_tile = t == n_tiles - 1;
-        const int64_t e_first = t * ACC_TILE + lane * ACC_K;
-        // products, rounded on their own like the reference's `v * x` (no FMA contraction: short rows are
-        // to come out bit-identical to the sequential loop)
+        // products, rounded on their own like the reference's `v * x` (contraction is off in this kernel:
+        // short rows are to come out bit-identical to the sequential loop)
         double pr[ACC_K];
 #pragma unroll
         for (int j = 0; j < ACC_K; j++) {
-            pr[j] = __dmul_rn(a[j], inl[j] ? lv[j] : gv[j]);
-            if (tail_tile) pr[j] = e_first + j < n_view ? pr[j] : 0.0;     // padding: masked after the multiply
+            pr[j] = a[j] * (inl[j] ? lv[j] : gv[j]);
         }
         // Run sums go to the wavefront's staging buffer: slot 0 = the tile's leading run (the part of a row
         // begun in an earlier tile; 0.0 if the tile opens a row), slot k = the run opened by the tile's k-th
@@ -1417,7 +1459,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 }
                 acc = 0.0;
             }
-            acc = __dadd_rn(acc, pr[j]);
+            acc = acc + pr[j];
         }
         const bool has_start = st != 0;
         if (!has_start) hs = acc;
@@ -1439,7 +1481,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             const bool take = lane > 0 && xok && !hok;
             double sum = Xq;
 #pragma unroll
-            for (int j = 0; j < ACC_K; j++) sum = __dadd_rn(sum, j < first ? pr[j] : -0.0);
+            for (int j = 0; j < ACC_K; j++) sum = sum + (j < first ? pr[j] : -0.0);
             Hq = take ? sum : Hq;
             hok = hok || take;
             if (!has_start) {
@@ -1454,20 +1496,34 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         // Rows without a run -- empty rows, rows served by the tiers (their reduce kernels overwrite y later
         // in the stream) -- get their zero from the run that follows them: slot k also clears the rows
         // between the previous run's row and its own.
-        for (int k0 = 0; k0 <= total; k0 += WAVE) {
+        // (The row ids of the first LS_RID * 64 slots were requested with the gathers -- the dependent
+        // rowids -> store round trips per 64 runs were a third of a tile's latency; the id of the previous run's
+        // row is the lane below's.)
+        int32_t r_last = -1;                                   // row of the slot before this batch of 64
+#pragma unroll 1
+        for (int k0 = 0, it = 0; k0 <= total; k0 += WAVE, it++) {
             const int k = k0 + lane;
+            const int run = tb - 1 + k;
+            int32_t r;
+            if (it < LS_RID) {
+                r = it == 0 ? rid[0] : (it == 1 ? rid[1] : (it == 2 ? rid[2] : rid[3]));
+            } else {
+                r = rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)];
+            }
+            int32_t r_prev = __shfl_up(r, 1, WAVE);
+            if (lane == 0) r_prev = r_last;
+            r_last = __shfl(r, WAVE - 1, WAVE);
             int64_t g0 = 0, g1 = 0;                             // rows [g0, g1) to clear
             if (k <= total) {
                 const double val = s_out[k];
                 if (k == 0) {
                     const bool opens = (st & 1u) != 0;           // lane 0: the tile's first entry opens a row
-                    carry_val[t] = val;
-                    carry_row[t] = opens ? -1 : rowids[tb > 0 ? tb - 1 : 0];
+                    const int64_t ct = carry_idx ? (int64_t)carry_idx[t] : t;     // the tile's place in run order
+                    carry_val[ct] = val;
+                    carry_row[ct] = opens ? -1 : r;              // r = rowids[tb - 1] (clamped when tb == 0: then it opens)
                 } else {
-                    const int run = tb - 1 + k;
-                    const int32_t r = rowids[run];
                     y[r] = val;
-                    g0 = run > 0 ? (int64_t)rowids[run - 1] + 1 : 0;
+                    g0 = run > 0 ? (int64_t)r_prev + 1 : 0;
                     g1 = r;
                 }
             }
@@ -2023,6 +2079,63 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
+// Build the arrays of one light stream from a view: view row r (r < nrows_view) is the source entries
+// src[r] .. src[r] + (rpv[r+1] - rpv[r]) of (ci, vs); `sg` places the view's entries in sub-streams, `phys`
+// (optional) places the logical tiles in memory.
+template <class P, int VT>
+static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, int32_t nrows_view, const int32_t *ci,
+                        const void *vs, const LsSegs &sg, int64_t n_tiles, const std::vector<int32_t> *phys, int32_t n_out,
+                        hipStream_t s)
+{
+    ls->on = false;
+    DevBuf ridx, dphys;
+    CSRK_TRY(ridx.alloc((size_t)(nrows_view + 2) * 4));
+    const unsigned gr = (unsigned)ceil_div((int64_t)nrows_view + 1, 256);
+    ls_rowflag_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i32(ridx.as<int32_t>(), ridx.as<int32_t>(), nrows_view, s));
+    int32_t n_runs = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + nrows_view, 4, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    if (n_runs < 1) return CSRK_OK;
+    CSRK_TRY(ls->rowids.alloc((size_t)n_runs * 4));
+    ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    const int32_t *d_phys = nullptr;
+    if (phys) {
+        CSRK_TRY(dphys.alloc((size_t)n_tiles * 4));
+        CSRK_HIP(hipMemcpyAsync(dphys.p, phys->data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
+        CSRK_TRY(ls->carry_idx.alloc((size_t)n_tiles * 4));
+        d_phys = dphys.as<int32_t>();
+    }
+    CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
+    CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
+    ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
+        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, ls->vals.as<double>(), ls->idx.as<uint32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
+    ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
+        rpv, nrows_view, ridx.as<int32_t>(), sg, n_tiles, d_phys, ls->tile_base.as<int32_t>(),
+        phys ? ls->carry_idx.as<int32_t>() : (int32_t *)nullptr);
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(ls->carry_row.alloc((size_t)n_tiles * 4));
+    CSRK_TRY(ls->carry_val.alloc((size_t)n_tiles * 8));
+    int cus = 0;
+    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
+    const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
+    ls->grid = (unsigned)(wgs < need ? wgs : need);
+    ls->n_tiles = n_tiles;
+    ls->n_runs = n_runs;
+    ls->n_out = n_out;
+    CSRK_HIP(hipStreamSynchronize(s));      // ridx, dphys are freed on return; *phys is a host temporary
+    ls->on = true;
+    return CSRK_OK;
+}
+
 // Copy the rows of the row-major path (the light view, or the whole matrix when nothing was cut out) into
 // the light stream.  Built with the lazy plan.  Skipped (the tile kernel stays in charge) when ncols needs
 // the two flag bits, when the copy does not fit in device memory, or with CSRK_SPMV_STREAM=0.
@@ -2047,44 +2160,115 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
     if ((size_t)n_tiles * ACC_TILE * 12 + ((size_t)m->nrows + n_tiles) * 8 + (64u << 20) > mfree && !(env && env[0] == '1'))
         return CSRK_OK;
-    DevBuf ridx;
-    CSRK_TRY(ridx.alloc((size_t)(m->nrows + 2) * 4));
-    const unsigned gr = (unsigned)ceil_div((int64_t)m->nrows + 1, 256);
-    ls_rowflag_kernel<P><<<gr, 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>());
+    LsSegs sg;
+    sg.n = 1;
+    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles * ACC_TILE, sg.ent0[k] = n_view;
+    sg.slot0[0] = 0;
+    sg.ent0[0] = 0;
+    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, ci, m->d_values, sg, n_tiles, nullptr, m->nrows, s)));
+    if (p->ls.on) p->ci_hot.release();      // the stream carries the renumbered columns
+    return CSRK_OK;
+}
+
+// Tier 1 as a stream: the (column block, row) pairs of the pair panel become the runs of a light stream whose
+// output is the pair partials.  The column blocks are dealt to 8 sub-streams (block b -> b % 8) and the
+// sub-streams' tiles interleaved in groups of 16, so that -- one workgroup of 16 wavefronts per CU, workgroup
+// w on XCD w % 8 -- the tiles of block b are gathered by one XCD and ONE L2 holds its 1 MiB x window (a speed
+// assumption only, as in the pair kernel it replaces: one wavefront per tile, no workgroup barriers, 12 B per
+// entry + 4 B per pair instead of the merge-path tile kernel's bookkeeping).
+__global__ void t1_view_kernel(const void *__restrict__ prp, int p64, const int32_t *__restrict__ blk_perm, int32_t n_heavy,
+                               int64_t pairs, int64_t *__restrict__ src, int64_t *__restrict__ lens)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= pairs) return;
+    const int64_t pr = (int64_t)blk_perm[r / n_heavy] * n_heavy + r % n_heavy;
+    const int64_t a = p64 ? ((const int64_t *)prp)[pr] : (int64_t)((const int32_t *)prp)[pr];
+    const int64_t b = p64 ? ((const int64_t *)prp)[pr + 1] : (int64_t)((const int32_t *)prp)[pr + 1];
+    src[r] = a;
+    lens[r] = b - a;
+}
+
+static int build_tier1_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    Panel *pn = &p->tier[1];
+    p->t1s.on = false;
+    // Measured on the headline matrix: 0.152 ms as a stream against 0.101 ms for the pair kernel (both far from
+    // the HBM rate: every gather lane that misses L1 pulls a 128-B line into the CU, ~4 clocks each, and the
+    // pair kernel's entry-per-lane order makes fewer distinct lines per instruction) -- so the pair kernel stays
+    // the default and the stream form is kept for experiments: CSRK_SPMV_TIER1=stream.
+    const char *env = getenv("CSRK_SPMV_TIER1");
+    if (!pn->on || !(env && !strcmp(env, "stream")) || (int64_t)m->ncols > (int64_t)LS_COL_MASK) return CSRK_OK;
+    if (pn->rows > INT32_MAX - 2 || pn->nnz < 1) return CSRK_OK;
+    const int32_t nb = pn->nb, H = pn->nrow;
+    const int64_t pairs = pn->rows;
+    const int n_sub = nb >= 2 * HEAVY_STREAMS ? HEAVY_STREAMS : 1;
+    std::vector<int32_t> perm;
+    std::vector<int64_t> sub_blk0((size_t)n_sub + 1, 0);      // first permuted block of each sub-stream
+    for (int q = 0; q < n_sub; q++) {
+        sub_blk0[(size_t)q] = (int64_t)perm.size();
+        for (int32_t b = q; b < nb; b += n_sub) perm.push_back(b);
+    }
+    sub_blk0[(size_t)n_sub] = nb;
+    DevBuf dperm, src, rpv;
+    CSRK_TRY(dperm.alloc((size_t)nb * 4));
+    CSRK_TRY(src.alloc((size_t)(pairs + 1) * 8));
+    CSRK_TRY(rpv.alloc((size_t)(pairs + 2) * 8));
+    CSRK_HIP(hipMemcpyAsync(dperm.p, perm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+    t1_view_kernel<<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(pn->rp.p, pn->p64 ? 1 : 0, dperm.as<int32_t>(), H, pairs,
+                                                                src.as<int64_t>(), rpv.as<int64_t>());
     CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(ridx.as<int32_t>(), ridx.as<int32_t>(), m->nrows, s));
-    int32_t n_runs = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + m->nrows, 4, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(exclusive_scan_i64(rpv.as<int64_t>(), rpv.as<int64_t>(), pairs, s));
+    // entries before each sub-stream
+    std::vector<int64_t> e0((size_t)n_sub + 1);
+    for (int q = 0; q <= n_sub; q++)
+        CSRK_HIP(hipMemcpyAsync(&e0[(size_t)q], rpv.as<int64_t>() + sub_blk0[(size_t)q] * H, 8, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
-    if (n_runs < 1) return CSRK_OK;
-    CSRK_TRY(p->ls.rowids.alloc((size_t)n_runs * 4));
-    ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>(), p->ls.rowids.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(p->ls.vals.alloc((size_t)n_tiles * ACC_TILE * 8));
-    CSRK_TRY(p->ls.idx.alloc((size_t)n_tiles * ACC_TILE * 4));
-    ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        rp, rpv, m->nrows, ci, m->d_values, n_view, n_tiles * ACC_TILE, p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(p->ls.tile_base.alloc((size_t)n_tiles * 4));
-    ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(rpv, m->nrows, ridx.as<int32_t>(), n_tiles,
-                                                                         p->ls.tile_base.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(p->ls.carry_row.alloc((size_t)n_tiles * 4));
-    CSRK_TRY(p->ls.carry_val.alloc((size_t)n_tiles * 8));
-    int cus = 0;
-    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
-    if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
-    const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
-    p->ls.grid = (unsigned)(wgs < need ? wgs : need);
-    p->ls.n_view = n_view;
-    p->ls.n_tiles = n_tiles;
-    p->ls.n_runs = n_runs;
-    CSRK_HIP(hipStreamSynchronize(s));      // ridx is freed on return
-    p->ls.on = true;
-    p->ci_hot.release();                    // the stream carries the renumbered columns
+    LsSegs sg;
+    std::vector<int64_t> sub_tiles;      // tiles of the non-empty sub-streams, in order
+    int64_t slot = 0;
+    sg.n = 0;
+    for (int q = 0; q < n_sub; q++) {
+        const int64_t len = e0[(size_t)q + 1] - e0[(size_t)q];
+        if (len == 0) continue;
+        sg.slot0[sg.n] = slot;
+        sg.ent0[sg.n] = e0[(size_t)q];
+        sg.n++;
+        sub_tiles.push_back(ceil_div(len, ACC_TILE));
+        slot += ceil_div(len, ACC_TILE) * ACC_TILE;
+    }
+    if (sg.n == 0) return CSRK_OK;
+    for (int k = sg.n; k < 9; k++) sg.slot0[k] = slot, sg.ent0[k] = e0[(size_t)n_sub];
+    // (empty sub-streams contribute no entries, so ent0[k + 1] is where sub-stream k's entries end)
+    const int64_t n_tiles = slot / ACC_TILE;
+    if (n_tiles > INT32_MAX) return CSRK_OK;
+    size_t mfree = 0, mtotal = 0;
+    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if ((size_t)n_tiles * ACC_TILE * 12 + (size_t)pairs * 8 + (64u << 20) > mfree) return CSRK_OK;
+    // tiles of the sub-streams interleaved in groups of 16
+    std::vector<int32_t> phys((size_t)n_tiles);
+    {
+        std::vector<int64_t> cur((size_t)sg.n), end((size_t)sg.n);
+        for (int k = 0; k < sg.n; k++) {
+            cur[(size_t)k] = sg.slot0[k] / ACC_TILE;
+            end[(size_t)k] = cur[(size_t)k] + sub_tiles[(size_t)k];
+        }
+        int64_t pos = 0;
+        while (pos < n_tiles)
+            for (int k = 0; k < sg.n; k++)
+                for (int u = 0; u < LS_THREADS / WAVE && cur[(size_t)k] < end[(size_t)k]; u++) phys[(size_t)cur[(size_t)k]++] = (int32_t)pos++;
+    }
+    CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1s, src.as<int64_t>(), rpv.as<int64_t>(), (int32_t)pairs,
+                                                   pn->ci.as<int32_t>(), pn->vs.p, sg, n_tiles, &phys, (int32_t)pairs, s)));
+    if (p->t1s.on) {
+        // the pair kernel's own arrays are no longer needed (the partials y', the row list and the geometry are)
+        pn->rp.release();
+        pn->ci.release();
+        pn->vs.release();
+        pn->tile.release();
+        pn->group.release();
+        pn->carry_row.release();
+        pn->carry_val.release();
+    }
     return CSRK_OK;
 }
 
@@ -2124,6 +2308,7 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
                 for (hipEvent_t *e : {&p->ev_fork, &p->ev_pack, &p->ev_aux, &p->ev_tier[0], &p->ev_tier[1]})
                     CSRK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
+            CSRK_TRY(build_tier1_stream(m, p, s));
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
             else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
@@ -2236,6 +2421,21 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
+            if (q == 1 && p->t1s.on) {      // tier 1 as a stream of (block, row) runs -> pair partials
+                constexpr size_t t1_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
+                LightStream &t = p->t1s;
+                KernelTimer kh(p, s, 2);
+                spmv_lstream_kernel<<<t.grid, LS_THREADS, t1_lds, s>>>(
+                    t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
+                    t.carry_idx.as<int32_t>(), d_x, (const double *)nullptr, 0, t.n_tiles, t.n_runs, t.n_out,
+                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>());
+                kh.stop();
+                CSRK_LAUNCH_CHECK();
+                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, sa>>>(
+                    t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
+                CSRK_LAUNCH_CHECK();
+                continue;
+            }
             KernelTimer kh(p, s, 1 + q);
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
@@ -2275,8 +2475,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
 spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
                     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
-                    p->ls.tile_base.as<int32_t>(), d_x, p->xh.as<double>(), p->n_hot_lds, p->ls.n_view, p->ls.n_tiles,
-                    p->ls.n_runs, m->nrows, d_y,
+                    p->ls.tile_base.as<int32_t>(), (const int32_t *)nullptr, d_x, p->xh.as<double>(), p->n_hot_lds,
+                    p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,
                     p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
                 kl.stop();
                 CSRK_LAUNCH_CHECK();

@@ -37,10 +37,15 @@ def split_mode(request, monkeypatch):
         monkeypatch.setenv('CSRK_SPMV_STREAM', '0')
     else:
         monkeypatch.delenv('CSRK_SPMV_STREAM', raising=False)
-    if 'pairs' in request.param:
+    if 'pairs' in request.param:      # tier 0 in its (block, row)-pair form (merge-path panel kernel), like tier 1
         monkeypatch.setenv('CSRK_SPMV_TIER0', 'pairs')
+        monkeypatch.delenv('CSRK_SPMV_TIER1', raising=False)
     else:
         monkeypatch.delenv('CSRK_SPMV_TIER0', raising=False)
+        if request.param == 'forced_split_hot':      # ... and once with tier 1 as a stream of (block, row) runs
+            monkeypatch.setenv('CSRK_SPMV_TIER1', 'stream')
+        else:
+            monkeypatch.delenv('CSRK_SPMV_TIER1', raising=False)
     if 'hot' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HOT', '1')
     else:
