@@ -79,6 +79,7 @@ SIGNATURES = {
     'csrk_center_rows': (_int, [handle_t, _vp]),
     'csrk_order_columns': (_int, [handle_t]),
     'csrk_filter_zeros': (_int, [handle_t, C.POINTER(handle_t)]),
+    'csrk_pick_rows': (_int, [handle_t, C.c_void_p, C.c_int64, C.c_int, C.POINTER(handle_t)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

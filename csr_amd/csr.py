@@ -179,6 +179,19 @@ class CSR:
         vs = self.values[st:ed] if self.values is not None else None
         return CSR(end - begin, self.ncols, ed - st, rps, cis, vs)
 
+    def pick_rows(self, rows, *, include_values=True):
+        """
+        csr/csr.py:347-364 -> csr/structure.py:84-149: the given rows, in order (a row may appear more than
+        once), as a new matrix; values are dropped with include_values=False.  Runs on the device when the
+        active kernel provides `pick_rows`.
+        """
+        rows = np.asarray(rows)
+        assert rows.ndim == 1
+        K, pick = self._ext('pick_rows')
+        with releasing(K.to_handle(self), K) as h:
+            with releasing(pick(h, rows, include_values), K) as ph:
+                return K.from_handle(ph)
+
     # ---- device operations beyond the kernel protocol -----------------------------------------
     def _ext(self, name):
         K = get_kernel()

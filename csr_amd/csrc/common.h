@@ -125,6 +125,10 @@ Matrix *from_handle(csrk_handle_t h);          // nullptr (and error set) if inv
 inline csrk_handle_t to_handle(Matrix *m) { return reinterpret_cast<csrk_handle_t>(m); }
 void free_spmv_plan(SpmvPlan *p);
 void free_spmm_plan(SpmmPlan *p);
+// Drop the handle's SpMV / SpMM plans (they hold re-ordered COPIES of colinds and values, so every operation
+// that changes the matrix in place -- unit_rows, center_rows, order_columns -- must call this).  Waits for the
+// device first: a launch may still be reading the plan.  Caller holds m->mu.
+void invalidate_plans(Matrix *m);
 
 // Create an owning matrix with freshly allocated (uninitialised) device arrays.
 int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_type, Matrix **out);

@@ -138,6 +138,21 @@ Matrix *from_handle(csrk_handle_t h)
     return m;
 }
 
+void invalidate_plans(Matrix *m)
+{
+    if (!m->spmv_plan && !m->spmm_plan) return;
+    (void)hipDeviceSynchronize();
+    if (m->spmm_plan) {                 // may hold a view into the SpMV plan: goes first
+        free_spmm_plan(m->spmm_plan);
+        m->spmm_plan = nullptr;
+    }
+    if (m->spmv_plan) {
+        free_spmv_plan(m->spmv_plan);
+        m->spmv_plan = nullptr;
+    }
+    m->spmv_calls = 0;
+}
+
 int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_type, Matrix **out)
 {
     Matrix *m = new (std::nothrow) Matrix();

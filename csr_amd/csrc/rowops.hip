@@ -196,6 +196,7 @@ static int row_stat(Matrix *m, void *out_host)
     CSRK_REQUIRE(out_host || m->nrows == 0, "output is NULL");
     if (m->nrows == 0) return CSRK_OK;
     std::lock_guard<std::mutex> lk(m->mu);
+    invalidate_plans(m);          // the values change in place; the plans hold copies of them
     DevBuf d, longs, nl;
     CSRK_TRY(d.alloc((size_t)m->nrows * m->val_bytes()));
     const int64_t max_long = m->nnz / ROW_LONG + 1;           // at most this many rows can be that long
@@ -300,6 +301,125 @@ __global__ void cast_f64_to_f32_kernel(const double *__restrict__ in, float *__r
     if (i < n) out[i] = (float)in[i];   // exact: the doubles were widened floats
 }
 
+// ---- pick_rows (csr/csr.py:347-364 -> csr/structure.py:84-149) ---------------------------------------
+// The reference walks the requested rows twice: sum their lengths, then copy each row's colinds (and
+// values) to a running position that becomes the new row pointer.  Here: lengths -> exclusive scan ->
+// one wavefront per picked row copies it.  A row may be picked more than once.  HBM-bound byte moving.
+template <class P>
+__global__ void pick_len_kernel(const P *__restrict__ rp, const int32_t *__restrict__ rows, int64_t nr, int32_t nrows,
+                                int64_t *__restrict__ len, int32_t *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nr) return;
+    int64_t l = 0;
+    if (i < nr) {
+        const int32_t r = rows[i];
+        if (r < 0 || r >= nrows)
+            atomicOr(bad, 1);
+        else
+            l = (int64_t)rp[r + 1] - (int64_t)rp[r];
+    }
+    len[i] = l;
+}
+
+// One thread per OUTPUT entry (consecutive lanes write consecutive addresses whatever the row lengths -- a
+// wavefront per picked row needed 13 ms for 2M rows of the headline matrix, whose 10^6-entry rows each kept one
+// wavefront busy): the workgroup's 2048 entries span the picked rows [i0, i1], found by two binary searches
+// over the output offsets; each thread then searches only that span.
+constexpr int PICK_EPT = 8;
+template <class P, class PO, class T>
+__global__ __launch_bounds__(256) void pick_copy_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                       const T *__restrict__ vs, const int32_t *__restrict__ rows,
+                                                       int64_t nr, const int64_t *__restrict__ off, int64_t nnz,
+                                                       int32_t *__restrict__ oci, T *__restrict__ ovs)
+{
+    __shared__ int64_t s_span[2];
+    const int64_t base = (int64_t)blockIdx.x * (256 * PICK_EPT);
+    if (threadIdx.x < 2) {
+        // last picked row whose offset is <= the workgroup's first (threadIdx 0) / last (1) entry
+        int64_t o = threadIdx.x == 0 ? base : base + 256 * PICK_EPT - 1;
+        o = o < nnz - 1 ? o : nnz - 1;
+        int64_t lo = 0, hi = nr - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= o)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        s_span[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const int64_t i0 = s_span[0], i1 = s_span[1];
+#pragma unroll
+    for (int k = 0; k < PICK_EPT; k++) {
+        const int64_t o = base + k * 256 + threadIdx.x;
+        if (o >= nnz) break;
+        int64_t lo = i0, hi = i1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= o)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int64_t src = (int64_t)rp[rows[lo]] + (o - off[lo]);
+        oci[o] = ci[src];
+        if (vs) ovs[o] = vs[src];
+    }
+}
+
+template <class PO>
+__global__ void pick_ptr_kernel(const int64_t *__restrict__ off, int64_t nr, PO *__restrict__ orp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nr) orp[i] = (PO)off[i];
+}
+
+template <class P, class T>
+static int pick_impl(Matrix *m, const int32_t *d_rows, int64_t nr, int vt, Matrix **out)
+{
+    DevBuf len, bad;
+    CSRK_TRY(len.alloc((size_t)(nr + 2) * 8));
+    CSRK_TRY(bad.alloc(4));
+    CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, nullptr));
+    pick_len_kernel<P><<<(unsigned)ceil_div(nr + 1, 256), 256>>>((const P *)m->d_rowptrs, d_rows, nr, m->nrows,
+                                                                len.as<int64_t>(), bad.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(len.as<int64_t>(), len.as<int64_t>(), nr, nullptr));
+    int64_t nnz = 0;
+    int32_t is_bad = 0;
+    CSRK_HIP(hipMemcpy(&nnz, len.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost));
+    CSRK_HIP(hipMemcpy(&is_bad, bad.p, 4, hipMemcpyDeviceToHost));
+    CSRK_REQUIRE(!is_bad, "pick_rows: row index out of range [0, %d)", m->nrows);
+    const int p64 = nnz > INT32_MAX;
+    Matrix *t = nullptr;
+    CSRK_TRY(new_matrix((int32_t)nr, m->ncols, nnz, p64, vt, &t));
+    const unsigned gp = (unsigned)ceil_div(nr + 1, 256), grid = (unsigned)ceil_div(nnz, 256 * PICK_EPT);
+    const T *vs = vt == CSRK_VAL_NONE ? (const T *)nullptr : (const T *)m->d_values;
+    if (p64)
+        pick_ptr_kernel<int64_t><<<gp, 256>>>(len.as<int64_t>(), nr, (int64_t *)t->d_rowptrs);
+    else
+        pick_ptr_kernel<int32_t><<<gp, 256>>>(len.as<int64_t>(), nr, (int32_t *)t->d_rowptrs);
+    if (nnz > 0) {
+        if (p64)
+            pick_copy_kernel<P, int64_t, T><<<grid, 256>>>((const P *)m->d_rowptrs, m->d_colinds, vs, d_rows, nr,
+                                                          len.as<int64_t>(), nnz, t->d_colinds, (T *)t->d_values);
+        else
+            pick_copy_kernel<P, int32_t, T><<<grid, 256>>>((const P *)m->d_rowptrs, m->d_colinds, vs, d_rows, nr,
+                                                          len.as<int64_t>(), nnz, t->d_colinds, (T *)t->d_values);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();      // `len` goes back to the pool on return
+    if (e != hipSuccess) {
+        set_error("pick_rows failed: %s", hipGetErrorString(e));
+        delete t;
+        return CSRK_ERR_HIP;
+    }
+    *out = t;
+    return CSRK_OK;
+}
+
 }  // namespace csrk
 
 using namespace csrk;
@@ -318,6 +438,32 @@ int csrk_center_rows(csrk_handle_t h, void *means)
     Matrix *m = from_handle(h);
     if (!m) return CSRK_ERR_INVALID;
     return row_stat<false>(m, means);
+}
+
+int csrk_pick_rows(csrk_handle_t h, const int32_t *rows, int64_t n_rows, int with_values, csrk_handle_t *out)
+{
+    CSRK_REQUIRE(out, "out is NULL");
+    *out = 0;
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(n_rows >= 0 && n_rows <= INT32_MAX - 1, "bad row count %lld", (long long)n_rows);
+    CSRK_REQUIRE(rows || n_rows == 0, "rows is NULL");
+    DevBuf d_rows;
+    CSRK_TRY(d_rows.alloc((size_t)(n_rows ? n_rows : 1) * 4));
+    if (n_rows) CSRK_HIP(hipMemcpy(d_rows.p, rows, (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    const int vt = (with_values && m->val_type != CSRK_VAL_NONE) ? m->val_type : CSRK_VAL_NONE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    Matrix *t = nullptr;
+    int rc;
+    if (m->ptr64)
+        rc = vt == CSRK_VAL_F32 ? pick_impl<int64_t, float>(m, d_rows.as<int32_t>(), n_rows, vt, &t)
+                                : pick_impl<int64_t, double>(m, d_rows.as<int32_t>(), n_rows, vt, &t);
+    else
+        rc = vt == CSRK_VAL_F32 ? pick_impl<int32_t, float>(m, d_rows.as<int32_t>(), n_rows, vt, &t)
+                                : pick_impl<int32_t, double>(m, d_rows.as<int32_t>(), n_rows, vt, &t);
+    if (rc != CSRK_OK) return rc;
+    *out = to_handle(t);
+    return CSRK_OK;
 }
 
 int csrk_filter_zeros(csrk_handle_t h, csrk_handle_t *out)
@@ -365,7 +511,7 @@ int csrk_order_columns(csrk_handle_t h)
         set_error("order_columns copy-back failed: %s", hipGetErrorString(e));
         return CSRK_ERR_HIP;
     }
-    // the SpMV plan depends only on rowptrs, which are unchanged
+    invalidate_plans(m);      // the SpMV / SpMM plans hold re-ordered copies of colinds and values
     return CSRK_OK;
 }
 

@@ -7,7 +7,7 @@ Protocol members (same names and meaning as csr/kernels/numba/__init__.py:13-67 
 csr/kernels/mkl/*): max_nnz, to_handle, from_handle, release_handle, order_columns,
 mult_ab, mult_abt, mult_vec.  Extra members for the operations the reference runs
 outside its kernel protocol but on the same hot path: transpose, row_nnzs, unit_rows,
-center_rows, filter_zeros, mult_dense.
+center_rows, filter_zeros, pick_rows, mult_dense.
 
 A handle owns a copy of the matrix in HBM, like the MKL kernel's handle
 (csr/kernels/mkl/handle.py:47-70).  There is no CPU fallback: without a GPU every call
@@ -204,6 +204,14 @@ def unit_rows(h):
 def center_rows(h):
     "csr/transform.py:13-26: mean-centre rows IN PLACE on the handle; returns the means"
     return _row_stat(lib.csrk_center_rows, h)
+
+
+def pick_rows(h, rows, include_values=True):
+    "csr/csr.py:347-364 on the device: NEW handle with the given rows (in order, repeats allowed)"
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = handle_t(0)
+    check(lib.csrk_pick_rows(_live(h), rows.ctypes.data_as(C.c_void_p), rows.size, int(bool(include_values)), C.byref(out)))
+    return _wrap(out.value)
 
 
 def filter_zeros(h):

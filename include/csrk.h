@@ -186,6 +186,15 @@ CSRK_API int csrk_center_rows(csrk_handle_t h, void *means);
  * Stable sort of every row by column index; values follow.                              */
 CSRK_API int csrk_order_columns(csrk_handle_t h);
 
+/* ---- pick_rows ---------------------------------------------------------------------------
+ * csr/csr.py:347-364 -> csr/structure.py:84-149 (_pick_rows, _pick_rows_nvs).  NEW handle with the
+ * rows rows[0..n_rows) of h, in that order (a row may appear more than once); `rows` is a host
+ * array.  with_values = 0 drops the values; otherwise they keep their dtype.  Row pointers are
+ * int32 (as the reference's) unless the result has more than 2^31 - 1 entries.  An index outside
+ * [0, nrows) is CSRK_ERR_INVALID (the reference raises IndexError).                        */
+CSRK_API int csrk_pick_rows(csrk_handle_t h, const int32_t *rows, int64_t n_rows, int with_values,
+                            csrk_handle_t *out);
+
 /* ---- _filter_zeros ----------------------------------------------------------------------
  * csr/_struct.py:61-76.  Returns a NEW handle without the entries whose value is
  * exactly 0.0 (NaN is kept).  Requires float64 values.                                  */

@@ -417,3 +417,30 @@ ORC_EXPORT void orc_spmm_dense(int32_t nrows, const int64_t *rp, const int32_t *
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------
+ * pick_rows: csr/structure.py:84-117 (_pick_rows_nvs) and :120-149 (_pick_rows).
+ * First pass sums the picked rows' lengths (:89-94 / :125-130); second pass copies each
+ * picked row's colinds (and values, any element size `vsize`; vs == NULL: structure
+ * only) to the running position and records it in the new row pointers (:103-115 /
+ * :139-147).  A row may be picked more than once.  Call with out_* == NULL to get the
+ * result's nnz only.  Returns nnz.
+ * ------------------------------------------------------------------------------- */
+ORC_EXPORT int64_t orc_pick_rows(const int64_t *rp, const int32_t *ci, const void *vs, int32_t vsize,
+                                 const int32_t *rows, int64_t nr, int64_t *out_rp, int32_t *out_ci, void *out_vs)
+{
+    int64_t nnz = 0;
+    for (int64_t ii = 0; ii < nr; ii++) nnz += rp[rows[ii] + 1] - rp[rows[ii]];
+    if (!out_rp) return nnz;
+    int64_t pos = 0;
+    for (int64_t ii = 0; ii < nr; ii++) {
+        int64_t sp = rp[rows[ii]], ep = rp[rows[ii] + 1];
+        int64_t itc = ep - sp;
+        memcpy(out_ci + pos, ci + sp, (size_t)itc * sizeof(int32_t));
+        if (vs) memcpy((char *)out_vs + (size_t)pos * vsize, (const char *)vs + (size_t)sp * vsize, (size_t)itc * vsize);
+        out_rp[ii] = pos;
+        pos += itc;
+    }
+    out_rp[nr] = pos;
+    return nnz;
+}

@@ -232,6 +232,26 @@ def gen_shard(n=20):
     np.savez_compressed(os.path.join(OUT, 'shard.npz'), **d)
 
 
+def gen_pick(n=40):
+    "pick_rows (csr/csr.py:347-364, csr/structure.py:84-149); draws as tests/test_transform.py:38-62"
+    rng = np.random.default_rng(20261003)
+    d = {'n': np.array(n)}
+    for c in range(n):
+        m = draw_csr(rng)
+        include = bool(rng.integers(0, 2))
+        k = int(rng.integers(0, m.nrows * 10 + 1))
+        rows = rng.integers(0, m.nrows, size=k).astype(np.int32)
+        if c == 0:
+            rows = np.zeros(0, dtype=np.int32)          # nothing picked
+        put(d, f'c{c}_', m)
+        d[f'c{c}_rows'] = rows
+        d[f'c{c}_include'] = np.array(include)
+        sub = m.pick_rows(rows, include_values=include)
+        assert sub.nrows == len(rows)
+        put(d, f'c{c}_out_', sub)
+    np.savez_compressed(os.path.join(OUT, 'pick.npz'), **d)
+
+
 if __name__ == '__main__':
     gen_kat()
     gen_spmv()
@@ -240,5 +260,6 @@ if __name__ == '__main__':
     gen_rows()
     gen_spgemm()
     gen_shard()
+    gen_pick()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

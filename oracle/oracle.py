@@ -41,6 +41,7 @@ def lib():
         _LIB.orc_sym_mm.restype = C.c_int64
         _LIB.orc_mult_ab.restype = C.c_int64
         _LIB.orc_filter_zeros.restype = C.c_int64
+        _LIB.orc_pick_rows.restype = C.c_int64
         _LIB.orc_free.argtypes = [C.c_void_p]
     return _LIB
 
@@ -217,6 +218,27 @@ def sort_rows(nrows, rowptrs, colinds, values):
     lib().orc_sort_rows(C.c_int32(nrows), _p(rp, _i64p), _p(ci, _i32p),
                         None if vs is None else _p(vs, _f64p))
     return ci, vs
+
+
+def pick_rows(rowptrs, colinds, values, rows, include_values=True):
+    """
+    csr/csr.py:347-364 -> csr/structure.py:84-149: the picked rows, in the order given (repeats allowed),
+    as (rowptrs int32, colinds, values-or-None); values keep their dtype.
+    """
+    rp = _rp64(rowptrs)
+    ci = _ci(colinds)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    vs = np.ascontiguousarray(values) if (include_values and values is not None) else None
+    vsize = 0 if vs is None else vs.dtype.itemsize
+    vp = None if vs is None else vs.ctypes.data_as(C.c_void_p)
+    nnz = lib().orc_pick_rows(_p(rp, _i64p), _p(ci, _i32p), vp, C.c_int32(vsize), _p(rows, _i32p),
+                              C.c_int64(len(rows)), None, None, None)
+    orp = np.empty(len(rows) + 1, dtype=np.int64)
+    oci = np.empty(nnz, dtype=np.int32)
+    ovs = None if vs is None else np.empty(nnz, dtype=vs.dtype)
+    lib().orc_pick_rows(_p(rp, _i64p), _p(ci, _i32p), vp, C.c_int32(vsize), _p(rows, _i32p), C.c_int64(len(rows)),
+                        _p(orp, _i64p), _p(oci, _i32p), None if ovs is None else ovs.ctypes.data_as(C.c_void_p))
+    return orp.astype(np.int32), oci, ovs
 
 
 def spmm_dense(nrows, rowptrs, colinds, values, B):

@@ -354,6 +354,92 @@ def test_filter_zeros(golden):
     assert np.array_equal(f.values, vs, equal_nan=True)
 
 
+# ---- pick_rows ----------------------------------------------------------------------------------------------
+
+def test_pick_rows_golden(golden):
+    "csr/csr.py:347-364 on the device against the reference's outputs: index and byte work, bit-exact"
+    from csr_amd.kernels import hip as K
+    g = golden('pick')
+    for c in range(int(g['n'])):
+        m, out = Mat(g, f'c{c}_'), Mat(g, f'c{c}_out_')
+        rows, include = g[f'c{c}_rows'], bool(g[f'c{c}_include'])
+        h = K.to_handle(_csr(m))
+        try:
+            ph = K.pick_rows(h, rows, include)
+            sub = K.from_handle(ph)
+            K.release_handle(ph)
+        finally:
+            K.release_handle(h)
+        assert (sub.nrows, sub.ncols, sub.nnz) == (len(rows), m.ncols, out.nnz)
+        assert np.array_equal(sub.rowptrs, out.rowptrs) and np.array_equal(sub.colinds, out.colinds)
+        if include and m.values is not None:
+            assert sub.values.dtype == m.values.dtype and np.array_equal(sub.values, out.values)
+        else:
+            assert sub.values is None
+
+
+def test_pick_rows_large_and_errors():
+    "power-law rows incl. a 200k-entry row, int64 pointers, CSR.pick_rows; out-of-range index -> error"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(31)
+    lens = np.minimum((rng.pareto(0.9, 20000) * 3).astype(np.int64), 200000)
+    lens[77] = 200000
+    for ptr64, dt in ((False, np.float64), (True, np.float32)):
+        m = _rand(rng, 20000, 50000, lens, dtype=dt, ptr64=ptr64)
+        rows = rng.integers(0, m.nrows, size=30000).astype(np.int32)
+        rows[:3] = 77                                   # the long row, three times
+        sub = m.pick_rows(rows)
+        rp, ci, vs = O.pick_rows(m.rowptrs, m.colinds, m.values, rows, True)
+        assert sub.nrows == len(rows) and np.array_equal(sub.rowptrs, rp)
+        assert np.array_equal(sub.colinds, ci) and sub.values.dtype == dt and np.array_equal(sub.values, vs)
+        nv = m.pick_rows(rows[:100], include_values=False)
+        assert nv.values is None and np.array_equal(nv.colinds, ci[:rp[100]])
+    h = K.to_handle(m)
+    try:
+        with pytest.raises(ValueError):          # CSRK_ERR_INVALID (the reference: IndexError)
+            K.pick_rows(h, np.array([0, m.nrows], dtype=np.int32))
+        with pytest.raises(ValueError):
+            K.pick_rows(h, np.array([-1], dtype=np.int32))
+    finally:
+        K.release_handle(h)
+
+
+def test_in_place_ops_invalidate_the_spmv_plan(monkeypatch):
+    """
+    unit_rows / center_rows / order_columns change values or columns in place; the SpMV plan holds re-ordered
+    copies of them (tiers, light stream), so a later mult_vec on the same handle must see the new matrix.
+    """
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
+    monkeypatch.setenv('CSRK_SPMV_HOT', '1')
+    rng = np.random.default_rng(12)
+    lens = rng.integers(1, 30, size=3000)
+    lens[5] = 4000
+    lens[9] = 600
+    m = _rand(rng, 3000, 20000, lens, sort=True)     # ascending columns: the long rows go to the tiers
+    x = rng.uniform(-1, 1, size=m.ncols)
+    h = K.to_handle(m)
+    try:
+        for _ in range(2):
+            y0 = K.mult_vec(h, x)                       # plan built (eagerly: split + stream)
+        ref0 = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+        assert np.allclose(y0, ref0, rtol=1e-12, atol=1e-12)
+        K.unit_rows(h)
+        u = K.from_handle(h)
+        y1 = K.mult_vec(h, x)
+        ref1 = O.mult_vec(u.nrows, u.ncols, u.rowptrs, u.colinds, u.values, x)
+        assert np.allclose(y1, ref1, rtol=1e-12, atol=1e-12) and not np.allclose(y1, y0)
+        K.order_columns(h)
+        s2 = K.from_handle(h)
+        y2 = K.mult_vec(h, x)
+        ref2 = O.mult_vec(s2.nrows, s2.ncols, s2.rowptrs, s2.colinds, s2.values, x)
+        assert np.allclose(y2, ref2, rtol=1e-12, atol=1e-12)
+    finally:
+        K.release_handle(h)
+
+
 # ---- dense-panel SpMM ------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize('k', [64, 7, 130])

@@ -206,3 +206,23 @@ def test_spmm_dense_matches_spgemm_semantics():
     B = rng.uniform(-1, 1, (nc, k))
     Cm = O.spmm_dense(nr, rp, np.array(ci, dtype=np.int32), np.array(vs), B)
     assert Cm == pytest.approx(dense @ B, rel=1e-12, abs=1e-14)
+
+
+def test_pick_rows_golden(golden):
+    "csr/csr.py:347-364 (tests/test_transform.py:38-62): picked rows in order, repeats allowed, values optional"
+    g = golden('pick')
+    seen_novals = seen_f4 = seen_repeat = 0
+    for c in range(int(g['n'])):
+        m, out = Mat(g, f'c{c}_'), Mat(g, f'c{c}_out_')
+        rows, include = g[f'c{c}_rows'], bool(g[f'c{c}_include'])
+        rp, ci, vs = O.pick_rows(m.rowptrs, m.colinds, m.values, rows, include)
+        assert out.nrows == len(rows) and out.ncols == m.ncols
+        assert rp.dtype == np.int32 and np.array_equal(rp, out.rowptrs) and np.array_equal(ci, out.colinds)
+        if include and m.values is not None:
+            assert vs.dtype == m.values.dtype and np.array_equal(vs, out.values)
+            seen_f4 += vs.dtype == np.float32
+        else:
+            assert vs is None and out.values is None
+            seen_novals += 1
+        seen_repeat += len(set(rows.tolist())) < len(rows)
+    assert seen_novals > 3 and seen_f4 > 1 and seen_repeat > 3
