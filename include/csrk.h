@@ -86,7 +86,10 @@ CSRK_API int csrk_create(int32_t nrows, int32_t ncols, int64_t nnz,
                          const void *values, int val_type,
                          csrk_handle_t *out);
 /* Wrap arrays that already live in HBM.  Nothing is copied or owned: the caller keeps
- * them alive for the handle's lifetime (same contract as to_handle, docs/kernels.rst). */
+ * them alive AND UNCHANGED for the handle's lifetime (same contract as to_handle,
+ * docs/kernels.rst): the SpMV / SpMM plans built on the second call keep re-ordered copies of
+ * colinds and values.  (libcsrk's own in-place operations -- csrk_unit_rows, csrk_center_rows,
+ * csrk_order_columns -- drop those plans themselves.) */
 CSRK_API int csrk_create_device(int32_t nrows, int32_t ncols, int64_t nnz,
                                 const void *d_rowptrs, int ptr_is_64,
                                 const int32_t *d_colinds,
