@@ -171,3 +171,31 @@ def test_transpose_config5_full_size():
         for q in (h, t, tt):
             check(lib.csrk_free(q))
         check(lib.csrk_trim_cache())
+
+
+def test_bench_two_ranks_plumbing():
+    """
+    bench.py's N > 1 path end to end on ONE GPU: two ranks share cuda:0 over gloo (RCCL refuses two ranks on
+    a device; BENCH_TEST_SHARE_GPU is the bench's own test hook).  Covers shard generation, the per-rank
+    plans, the row-partitioned step with its exchange, the max-over-ranks timing and rank 0's JSON line.
+    """
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_TEST_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--scale', '0.05']
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'strong'
+    assert d['config']['parallelism'] == 'row-partition x2' and 'multi_gpu' in d
