@@ -54,17 +54,21 @@ constexpr int SG_SLOTS = 2048;
 constexpr int SG_CAP = 1024;      // max products for the LDS hash path (load factor <= 0.5)
 constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take the wave-per-row kernels
 
-// products per output row: ub[i] = sum_{j in A_i} |B_j|
-__global__ void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub)
+// products per output row: ub[i] = sum_{j in A_i} |B_j| (one wavefront per row: a thread per row spent 1.9 ms
+// on 2000 rows of a MovieLens-shaped A, whose rows have up to 7000 entries)
+__global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
     if (i >= a.nrows) return;
-    int64_t s = rp_at(a, i), e = rp_at(a, i + 1), tot = 0;
-    for (int64_t jj = s; jj < e; jj++) {
-        int32_t j = a.ci[jj];
+    const int64_t s = rp_at(a, i), e = rp_at(a, i + 1);
+    int64_t tot = 0;
+    for (int64_t jj = s + lane; jj < e; jj += WAVE) {
+        const int32_t j = a.ci[jj];
         tot += rp_at(b, j + 1) - rp_at(b, j);
     }
-    ub[i] = tot;
+    for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
+    if (lane == 0) ub[i] = tot;
 }
 
 __global__ void sg_list_large(const int64_t *__restrict__ ub, int32_t nrows, int32_t *__restrict__ list,
@@ -388,6 +392,125 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
     }
 }
 
+// ---- rows with many products, accumulated in LDS -------------------------------------------------------
+// The dense path above keeps a row's `work` / `index` arrays in HBM and pays one memory-side atomic per
+// product (plus one on the marker): ~16 ps per product.  When the output row is nearly full -- every A B^T
+// block of a MovieLens-shaped matrix -- it is cheaper to keep the accumulator ON CHIP:
+//   symbolic: one LDS bit per output column (up to 2^20 columns), set with ds_or, counted with popcount;
+//   numeric:  the output columns are taken in tiles of SGL_W = 16384 (128 KiB of float64 accumulators + a bit
+//             per column); per tile the row's products are walked once (products outside the tile are
+//             skipped), accumulated with ds_add_f64, and the tile is compacted in ascending column order.
+// One persistent 1024-thread workgroup per CU.  Ascending columns, cancellation zeros kept, like the other
+// paths; sums by LDS atomics (last bits may vary run to run, as before).
+constexpr int SGL_THREADS = 1024;
+constexpr int SGL_W = 16384;
+constexpr int SGL_MAXBITS = 1 << 20;       // symbolic: columns per LDS bitmask (128 KiB)
+constexpr int SGL_MAXTILES = 8;            // numeric: more column tiles than this -> the HBM path
+
+__global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
+                                                                     int32_t n_large, int32_t *__restrict__ cnt)
+{
+    extern __shared__ uint32_t sgl_bits[];
+    __shared__ int32_t s_tot;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int nwords = (b.ncols + 31) / 32;
+    for (int q = blockIdx.x; q < n_large; q += gridDim.x) {
+        const int i = list[q];
+        for (int k = tid; k < nwords; k += SGL_THREADS) sgl_bits[k] = 0;
+        if (tid == 0) s_tot = 0;
+        __syncthreads();
+        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        for (int64_t jj = as + w; jj < ae; jj += SGL_THREADS / WAVE) {
+            const int32_t j = a.ci[jj];
+            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
+            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
+                const int32_t k = b.ci[kk];
+                atomicOr(&sgl_bits[k >> 5], 1u << (k & 31));
+            }
+        }
+        __syncthreads();
+        int c = 0;
+        for (int k = tid; k < nwords; k += SGL_THREADS) c += __popc(sgl_bits[k]);
+        for (int off = WAVE / 2; off; off >>= 1) c += __shfl_down(c, off, WAVE);
+        if (lane == 0 && c) atomicAdd(&s_tot, c);
+        __syncthreads();
+        if (tid == 0) cnt[i] = s_tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
+                                                                    int32_t n_rows, const int32_t *__restrict__ c_rp,
+                                                                    int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+{
+    extern __shared__ __align__(16) unsigned char sgl_smem[];
+    double *s_work = (double *)sgl_smem;                         // SGL_W
+    uint32_t *s_bits = (uint32_t *)(s_work + SGL_W);             // SGL_W / 32
+    __shared__ int32_t s_wsum[SGL_THREADS / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int32_t nc = b.ncols;
+    for (int q = blockIdx.x; q < n_rows; q += gridDim.x) {
+        const int i = list[q];
+        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        int pos = c_rp[i];
+        for (int32_t t0 = 0; t0 < nc; t0 += SGL_W) {
+            const int32_t t1 = t0 + SGL_W < nc ? t0 + SGL_W : nc;
+            for (int k = tid; k < SGL_W; k += SGL_THREADS) s_work[k] = 0.0;
+            for (int k = tid; k < SGL_W / 32; k += SGL_THREADS) s_bits[k] = 0;
+            __syncthreads();
+            for (int64_t jj = as + w; jj < ae; jj += SGL_THREADS / WAVE) {
+                const int32_t j = a.ci[jj];
+                const double av = val_at(a, jj);
+                const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
+                for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
+                    const int32_t k = b.ci[kk];
+                    if (k >= t0 && k < t1) {
+                        atomicAdd(&s_work[k - t0], av * val_at(b, kk));
+                        atomicOr(&s_bits[(k - t0) >> 5], 1u << ((k - t0) & 31));
+                    }
+                }
+            }
+            __syncthreads();
+            // ascending compaction of the tile, 1024 columns at a time
+            for (int32_t k0 = 0; k0 < t1 - t0; k0 += SGL_THREADS) {
+                const int32_t k = k0 + tid;
+                const bool occ = k < t1 - t0 && ((s_bits[k >> 5] >> (k & 31)) & 1u);
+                const unsigned long long bal = __ballot(occ);
+                const int below = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wsum[w] = __popcll(bal);
+                __syncthreads();
+                int woff = 0, tot = 0;
+#pragma unroll
+                for (int u = 0; u < SGL_THREADS / WAVE; u++) {
+                    if (u < w) woff += s_wsum[u];
+                    tot += s_wsum[u];
+                }
+                if (occ) {
+                    c_ci[pos + woff + below] = t0 + k;
+                    c_vs[pos + woff + below] = s_work[k];
+                }
+                pos += tot;
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// large rows (list[0..n_large)) -> those whose output is nearly full and narrow enough for the LDS tiles
+// (list_a) and the others (list_b)
+__global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large, const int32_t *__restrict__ cnt, int32_t nc,
+                               int32_t *__restrict__ list_a, int32_t *__restrict__ list_b, int32_t *__restrict__ n_ab)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_large) return;
+    const int32_t i = list[q];
+    const bool lds = (int64_t)cnt[i] * 8 >= nc && (int64_t)nc <= (int64_t)SGL_W * SGL_MAXTILES;
+    if (lds)
+        list_a[atomicAdd(&n_ab[0], 1)] = i;
+    else
+        list_b[atomicAdd(&n_ab[1], 1)] = i;
+}
+
 static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
 {
     CSRK_REQUIRE(a->ncols == b->nrows, "mult_ab: A is %d x %d but B is %d x %d", a->nrows, a->ncols, b->nrows, b->ncols);
@@ -395,7 +518,10 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
                  "mult_ab needs values on both operands (csr/kernels/numba/multiply.py:115,120)");
     const int32_t nr = a->nrows;
     MatView av = view_of(a), bv = view_of(b);
-    DevBuf ub, cnt, list, nl, work, mark, scratch;
+    DevBuf ub, cnt, list, nl, work, mark, scratch, list_a, list_b, n_ab;
+    int grid_lds = 256;
+    int32_t n_lds = 0, n_hbm = 0;
+    bool lds_symbolic = false;
     int64_t scratch_len = 1;
     while (scratch_len < (int64_t)b->ncols) scratch_len <<= 1;     // padded length for the bitonic network
     CSRK_TRY(ub.alloc((size_t)(nr + 1) * 8));
@@ -408,12 +534,21 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
     int grid_dense = 0;
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
-        sg_count_products<<<g, 256>>>(av, bv, ub.as<int64_t>());
+        sg_count_products<<<(unsigned)ceil_div((int64_t)nr * WAVE, 256), 256>>>(av, bv, ub.as<int64_t>());
         CSRK_LAUNCH_CHECK();
         sg_list_large<<<g, 256>>>(ub.as<int64_t>(), nr, list.as<int32_t>(), nl.as<int32_t>());
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipMemcpy(&n_large, nl.p, 4, hipMemcpyDeviceToHost));
-        if (n_large > 0) {
+        int cus = 0;
+        CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
+        grid_lds = cus > 0 ? cus : 256;
+        lds_symbolic = n_large > 0 && b->ncols <= SGL_MAXBITS;
+        if (lds_symbolic) {
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_symbolic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_numeric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+        }
+        auto alloc_dense = [&]() -> int {       // HBM work / marker rows of the dense path, when some row needs it
+            if (work.p) return CSRK_OK;
             const int64_t per = (int64_t)b->ncols * 12 + scratch_len * 4;
             int64_t g_max = (4ll << 30) / (per > 0 ? per : 1);
             if (g_max < 1) g_max = 1;
@@ -424,7 +559,9 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
             CSRK_TRY(scratch.alloc((size_t)grid_dense * scratch_len * 4));
             CSRK_HIP(hipMemset(work.p, 0, work.bytes));
             CSRK_HIP(hipMemset(mark.p, 0, mark.bytes));
-        }
+            return CSRK_OK;
+        };
+        if (n_large > 0 && !lds_symbolic) CSRK_TRY(alloc_dense());
         // symbolic (rows with no products keep the zero count of the memset)
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
         sg_wave_kernel<64, false><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
@@ -433,11 +570,31 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         CSRK_LAUNCH_CHECK();
         sg_hash_kernel<false><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
-        if (n_large > 0) {
+        if (n_large > 0 && lds_symbolic) {
+            const size_t lds = (size_t)((b->ncols + 31) / 32) * 4;
+            sg_lds_symbolic_kernel<<<(unsigned)(n_large < grid_lds ? n_large : grid_lds), SGL_THREADS, lds>>>(
+                av, bv, list.as<int32_t>(), n_large, cnt.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            // numeric: nearly full rows -> LDS tiles, the others -> HBM work rows
+            CSRK_TRY(list_a.alloc((size_t)n_large * 4));
+            CSRK_TRY(list_b.alloc((size_t)n_large * 4));
+            CSRK_TRY(n_ab.alloc(8));
+            CSRK_HIP(hipMemset(n_ab.p, 0, 8));
+            sg_split_large<<<(unsigned)ceil_div(n_large, 256), 256>>>(list.as<int32_t>(), n_large, cnt.as<int32_t>(), b->ncols,
+                                                                     list_a.as<int32_t>(), list_b.as<int32_t>(),
+                                                                     n_ab.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            int32_t nab[2] = {0, 0};
+            CSRK_HIP(hipMemcpy(nab, n_ab.p, 8, hipMemcpyDeviceToHost));
+            n_lds = nab[0];
+            n_hbm = nab[1];
+            if (n_hbm > 0) CSRK_TRY(alloc_dense());
+        } else if (n_large > 0) {
             sg_dense_kernel<false><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
                                                               mark.as<int32_t>(), nullptr, 0, cnt.as<int32_t>(), nullptr,
                                                               nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
+            n_hbm = n_large;
         }
     }
     // row pointers: int64 scan first so an overflowing product is detected, not wrapped
@@ -462,9 +619,15 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
                                                (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
         sg_hash_kernel<true><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
                                                          c->d_colinds, (double *)c->d_values);
-        if (n_large > 0)
-            sg_dense_kernel<true><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
-                                                             mark.as<int32_t>(), scratch.as<int32_t>(), scratch_len, nullptr,
+        if (n_lds > 0)
+            sg_lds_numeric_kernel<<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,
+                                    (size_t)SGL_W * 8 + SGL_W / 8>>>(av, bv, list_a.as<int32_t>(), n_lds,
+                                                                     (const int32_t *)c->d_rowptrs, c->d_colinds,
+                                                                     (double *)c->d_values);
+        if (n_hbm > 0)
+            sg_dense_kernel<true><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
+                                                             n_hbm, work.as<double>(), mark.as<int32_t>(),
+                                                             scratch.as<int32_t>(), scratch_len, nullptr,
                                                              (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
     }
     hipError_t e = hipDeviceSynchronize();
