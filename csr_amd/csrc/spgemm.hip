@@ -12,7 +12,11 @@
 //     per row, open-addressing hash table of 2048 slots in LDS (keys by atomicCAS, values by
 //     LDS float64 atomic add); the occupied slots are compacted and bitonic-sorted by column
 //     in LDS, so the output structure is deterministic and ascending;
-//   * heavier rows: a persistent grid of workgroups, each owning a dense float64 work row and
+//   * heavier rows whose output is nearly full (>= 1/8 of the columns; every A B^T block of a
+//     MovieLens-shaped matrix): accumulated ON CHIP by persistent 1024-thread workgroups -- an LDS bit
+//     per output column for the symbolic pass, 16384-column float64 tiles for the numeric pass
+//     (ds_add_f64), ascending compaction -- see "rows with many products, accumulated in LDS";
+//   * other heavy rows: a persistent grid of workgroups, each owning a dense float64 work row and
 //     marker row in HBM (the reference's `work` / `index` arrays, multiply.py:62,106); touched
 //     columns are listed as they are first marked, the list is bitonic-sorted, the sums gathered.
 // Like the reference, entries that cancel to exactly 0.0 are KEPT (csr/csr.py:555 filters
@@ -408,13 +412,19 @@ constexpr int SGL_MAXBITS = 1 << 20;       // symbolic: columns per LDS bitmask 
 constexpr int SGL_MAXTILES = 8;            // numeric: more column tiles than this -> the HBM path
 
 __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
-                                                                     int32_t n_large, int32_t *__restrict__ cnt)
+                                                                     int32_t n_large, int32_t *__restrict__ cnt,
+                                                                     int32_t *__restrict__ next)
 {
     extern __shared__ uint32_t sgl_bits[];
-    __shared__ int32_t s_tot;
+    __shared__ int32_t s_tot, s_q;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int nwords = (b.ncols + 31) / 32;
-    for (int q = blockIdx.x; q < n_large; q += gridDim.x) {
+    for (;;) {
+        // rows are claimed one at a time (product counts differ by orders of magnitude between rows)
+        if (tid == 0) s_q = atomicAdd(next, 1);
+        __syncthreads();
+        const int q = s_q;
+        if (q >= n_large) break;
         const int i = list[q];
         for (int k = tid; k < nwords; k += SGL_THREADS) sgl_bits[k] = 0;
         if (tid == 0) s_tot = 0;
@@ -441,15 +451,21 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a,
 
 __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                                     int32_t n_rows, const int32_t *__restrict__ c_rp,
-                                                                    int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+                                                                    int32_t *__restrict__ c_ci, double *__restrict__ c_vs,
+                                                                    int32_t *__restrict__ next)
 {
     extern __shared__ __align__(16) unsigned char sgl_smem[];
     double *s_work = (double *)sgl_smem;                         // SGL_W
     uint32_t *s_bits = (uint32_t *)(s_work + SGL_W);             // SGL_W / 32
     __shared__ int32_t s_wsum[SGL_THREADS / WAVE];
+    __shared__ int32_t s_q;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int32_t nc = b.ncols;
-    for (int q = blockIdx.x; q < n_rows; q += gridDim.x) {
+    for (;;) {
+        if (tid == 0) s_q = atomicAdd(next, 1);
+        __syncthreads();
+        const int q = s_q;
+        if (q >= n_rows) break;
         const int i = list[q];
         const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
         int pos = c_rp[i];
@@ -518,7 +534,7 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
                  "mult_ab needs values on both operands (csr/kernels/numba/multiply.py:115,120)");
     const int32_t nr = a->nrows;
     MatView av = view_of(a), bv = view_of(b);
-    DevBuf ub, cnt, list, nl, work, mark, scratch, list_a, list_b, n_ab;
+    DevBuf ub, cnt, list, nl, work, mark, scratch, list_a, list_b, n_ab, next;
     int grid_lds = 256;
     int32_t n_lds = 0, n_hbm = 0;
     bool lds_symbolic = false;
@@ -572,8 +588,10 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         CSRK_LAUNCH_CHECK();
         if (n_large > 0 && lds_symbolic) {
             const size_t lds = (size_t)((b->ncols + 31) / 32) * 4;
+            CSRK_TRY(next.alloc(8));
+            CSRK_HIP(hipMemset(next.p, 0, 8));
             sg_lds_symbolic_kernel<<<(unsigned)(n_large < grid_lds ? n_large : grid_lds), SGL_THREADS, lds>>>(
-                av, bv, list.as<int32_t>(), n_large, cnt.as<int32_t>());
+                av, bv, list.as<int32_t>(), n_large, cnt.as<int32_t>(), next.as<int32_t>());
             CSRK_LAUNCH_CHECK();
             // numeric: nearly full rows -> LDS tiles, the others -> HBM work rows
             CSRK_TRY(list_a.alloc((size_t)n_large * 4));
@@ -623,7 +641,7 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
             sg_lds_numeric_kernel<<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,
                                     (size_t)SGL_W * 8 + SGL_W / 8>>>(av, bv, list_a.as<int32_t>(), n_lds,
                                                                      (const int32_t *)c->d_rowptrs, c->d_colinds,
-                                                                     (double *)c->d_values);
+                                                                     (double *)c->d_values, next.as<int32_t>() + 1);
         if (n_hbm > 0)
             sg_dense_kernel<true><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
                                                              n_hbm, work.as<double>(), mark.as<int32_t>(),
