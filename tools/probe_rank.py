@@ -1,0 +1,23 @@
+# scratch: local SpMV time of ONE rank's row range for world = 1, 2, 4, 8 (what the N-GPU bench computes per rank
+# before the exchange); usage: PYTHONPATH=. python tools/probe_rank.py
+import ctypes as C, torch
+from csr_amd import synth
+from csr_amd._lib import lib, check, handle_t
+dev = 'cuda'
+n = 10_000_000; nnz = 200_000_000
+x = synth.dense_vector(n, device=dev)
+for world in (1, 2, 4, 8):
+    for rank in sorted({0, world - 1}):
+        sh = synth.powerlaw_csr(n, n, nnz, device=dev, rank=rank, world=world)
+        rp, ci, vs = sh['rowptrs'], sh['colinds'], sh['values']
+        nl = sh['row_end'] - sh['row_begin']
+        h = handle_t(0)
+        check(lib.csrk_create_device(nl, n, int(ci.numel()), rp.data_ptr(), 0, ci.data_ptr(), vs.data_ptr(), 2, C.byref(h)))
+        y = torch.empty(nl, dtype=torch.float64, device=dev)
+        for _ in range(4): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+        for _ in range(30): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
+        e1.record(); torch.cuda.synchronize()
+        st = (C.c_int64 * 24)(); check(lib.csrk_spmv_plan_stats(h, st, 24))
+        print(f'world {world} rank {rank}: rows {nl} nnz {int(ci.numel())}: {e0.elapsed_time(e1) / 30:.4f} ms  (tier0 rows {st[9]} entries {st[10]}, tier1 entries {st[13]}, light {st[3]}, pack {st[16]})', flush=True)
+        check(lib.csrk_free(h)); del sh, rp, ci, vs, y
