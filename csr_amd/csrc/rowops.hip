@@ -34,23 +34,55 @@ __device__ __forceinline__ double wmax_nan(double v, bool nan)
     return __any(nan) ? __builtin_nan("") : v;   // np.max propagates NaN (transform.py:52)
 }
 
+// reductions over aligned groups of LPR lanes (LPR a power of two <= 64); every lane gets the result
+template <int LPR>
+__device__ __forceinline__ double gsum(double v)
+{
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ double gmax_nan(double v, bool nan)
+{
+    int f = nan ? 1 : 0;
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, WAVE);
+        v = o > v ? o : v;
+        f |= __shfl_xor(f, off, WAVE);
+    }
+    return f ? __builtin_nan("") : v;   // np.max propagates NaN (transform.py:52)
+}
+
 constexpr int ROW_LONG = 8192;     // rows longer than this get a whole workgroup
 
 template <class T> struct FInfo;
 template <> struct FInfo<double> { static constexpr int maxexp = 1024, minexp = -1022; };
 template <> struct FInfo<float> { static constexpr int maxexp = 128, minexp = -126; };
 
-template <class P, class T>
+// LPR lanes per row: a whole wavefront (64) for ordinary rows, 8 when the average row has < 16 entries (a
+// power-law matrix with millions of 1-entry rows kept 63 of 64 lanes idle: 6 ms for the headline matrix)
+template <class P, class T, int LPR>
 __global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
                                                        T *__restrict__ norms, int32_t nrows,
-                                                       int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
+                                                       int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long,
+                                                       const int32_t *__restrict__ row_list, int32_t med_min,
+                                                       int32_t *__restrict__ med_rows, int32_t *__restrict__ n_med)
 {
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (r >= nrows) return;
+    // row_list (optional): the rows to process; med_min > 0: rows with more entries than that (and <= ROW_LONG)
+    // are left to a second, wavefront-per-row launch over med_rows
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (q >= nrows) return;
+    const int64_t r = row_list ? row_list[q] : q;
     const int64_t sp = rp[r], ep = rp[r + 1];
     if (ep - sp > ROW_LONG) {             // left to the workgroup-per-row kernel
         if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
+        return;
+    }
+    if (med_min > 0 && ep - sp > med_min) {
+        if (lane == 0) med_rows[atomicAdd(n_med, 1)] = (int32_t)r;
         return;
     }
     if (sp == ep) {                       // empty row: norm 0 (transform.py:36-38)
@@ -59,12 +91,12 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp
     }
     double vmax = 0.0;
     bool nan = false;
-    for (int64_t k = sp + lane; k < ep; k += WAVE) {
+    for (int64_t k = sp + lane; k < ep; k += LPR) {
         double a = fabs((double)vs[k]);
         nan |= a != a;
         vmax = a > vmax ? a : vmax;
     }
-    vmax = wmax_nan(vmax, nan);
+    vmax = gmax_nan<LPR>(vmax, nan);
     // (m, e) = frexp(vmax); pnexp = clamp(-e, minexp, maxexp - 1); prenorm = 2^pnexp (:55-58)
     int ve = 0;
     if (vmax == vmax && !isinf(vmax)) (void)frexp(vmax, &ve);
@@ -73,29 +105,36 @@ __global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp
     pnexp = pnexp < FInfo<T>::minexp ? FInfo<T>::minexp : pnexp;
     const T prenorm = (T)ldexp(1.0, pnexp);
     double ss = 0.0;
-    for (int64_t k = sp + lane; k < ep; k += WAVE) {
+    for (int64_t k = sp + lane; k < ep; k += LPR) {
         T v = vs[k] * prenorm;            // :59
         ss += (double)v * (double)v;
     }
-    const T inorm = (T)sqrt(wsum(ss));    // :62
+    const T inorm = (T)sqrt(gsum<LPR>(ss));    // :62
     if (lane == 0) norms[r] = inorm / prenorm;   // :63
-    for (int64_t k = sp + lane; k < ep; k += WAVE) {
+    for (int64_t k = sp + lane; k < ep; k += LPR) {
         T v = vs[k] * prenorm;
         vs[k] = v / inorm;                // :64
     }
 }
 
-template <class P, class T>
+template <class P, class T, int LPR>
 __global__ __launch_bounds__(256) void center_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
                                                          T *__restrict__ means, int32_t nrows,
-                                                         int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long)
+                                                         int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long,
+                                                         const int32_t *__restrict__ row_list, int32_t med_min,
+                                                         int32_t *__restrict__ med_rows, int32_t *__restrict__ n_med)
 {
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (r >= nrows) return;
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    if (q >= nrows) return;
+    const int64_t r = row_list ? row_list[q] : q;
     const int64_t sp = rp[r], ep = rp[r + 1];
     if (ep - sp > ROW_LONG) {
         if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
+        return;
+    }
+    if (med_min > 0 && ep - sp > med_min) {
+        if (lane == 0) med_rows[atomicAdd(n_med, 1)] = (int32_t)r;
         return;
     }
     if (sp == ep) {
@@ -103,10 +142,10 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const P *__restrict__ 
         return;
     }
     double s = 0.0;
-    for (int64_t k = sp + lane; k < ep; k += WAVE) s += (double)vs[k];
-    const T m = (T)(wsum(s) / (double)(ep - sp));
+    for (int64_t k = sp + lane; k < ep; k += LPR) s += (double)vs[k];
+    const T m = (T)(gsum<LPR>(s) / (double)(ep - sp));
     if (lane == 0) means[r] = m;
-    for (int64_t k = sp + lane; k < ep; k += WAVE) vs[k] = vs[k] - m;
+    for (int64_t k = sp + lane; k < ep; k += LPR) vs[k] = vs[k] - m;
 }
 
 // Rows longer than ROW_LONG entries: one 1024-thread workgroup per row (a single wavefront would need
@@ -203,15 +242,43 @@ static int row_stat(Matrix *m, void *out_host)
     CSRK_TRY(longs.alloc((size_t)max_long * 4));
     CSRK_TRY(nl.alloc(4));
     CSRK_HIP(hipMemset(nl.p, 0, 4));
-    unsigned grid = (unsigned)ceil_div((int64_t)m->nrows * WAVE, 256);
+    // Mostly short rows (power-law matrices: half the rows of the headline matrix have <= 1 entry): 8 lanes per
+    // row for rows of <= 64 entries, the others collected and given a wavefront each in a second launch.
+    const bool short_rows = m->nnz / (int64_t)m->nrows < 64;
+    constexpr int MED_MIN = 64;
+    DevBuf meds, nm;
+    if (short_rows) {
+        CSRK_TRY(meds.alloc((size_t)(m->nnz / MED_MIN + 1) * 4));
+        CSRK_TRY(nm.alloc(4));
+        CSRK_HIP(hipMemset(nm.p, 0, 4));
+    }
+    unsigned grid = (unsigned)ceil_div((int64_t)m->nrows * (short_rows ? 8 : WAVE), 256);
+#define ROW_ARGS(T, LIST, N, MEDMIN)                                                                      \
+    (const P_ *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), N, longs.as<int32_t>(), nl.as<int32_t>(), LIST, MEDMIN,    \
+        meds.as<int32_t>(), nm.as<int32_t>()
 #define GO(P, T)                                                                                          \
     do {                                                                                                  \
-        if (UNIT)                                                                                         \
-            unit_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows,     \
-                                                  longs.as<int32_t>(), nl.as<int32_t>());                 \
+        typedef P P_;                                                                                     \
+        if (UNIT && short_rows)                                                                           \
+            unit_rows_kernel<P, T, 8><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, MED_MIN));      \
+        else if (UNIT)                                                                                    \
+            unit_rows_kernel<P, T, WAVE><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, 0));         \
+        else if (short_rows)                                                                              \
+            center_rows_kernel<P, T, 8><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, MED_MIN));    \
         else                                                                                              \
-            center_rows_kernel<P, T><<<grid, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), m->nrows,   \
-                                                    longs.as<int32_t>(), nl.as<int32_t>());               \
+            center_rows_kernel<P, T, WAVE><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, 0));       \
+        CSRK_LAUNCH_CHECK();                                                                              \
+        if (short_rows) {                                                                                 \
+            int32_t n_med = 0;                                                                            \
+            CSRK_HIP(hipMemcpy(&n_med, nm.p, 4, hipMemcpyDeviceToHost));                                  \
+            if (n_med > 0) {                                                                              \
+                const unsigned gm = (unsigned)ceil_div((int64_t)n_med * WAVE, 256);                       \
+                if (UNIT)                                                                                 \
+                    unit_rows_kernel<P, T, WAVE><<<gm, 256>>>(ROW_ARGS(T, meds.as<int32_t>(), n_med, 0)); \
+                else                                                                                      \
+                    center_rows_kernel<P, T, WAVE><<<gm, 256>>>(ROW_ARGS(T, meds.as<int32_t>(), n_med, 0));           \
+            }                                                                                             \
+        }                                                                                                 \
         CSRK_LAUNCH_CHECK();                                                                              \
         int32_t n_long = 0;                                                                               \
         CSRK_HIP(hipMemcpy(&n_long, nl.p, 4, hipMemcpyDeviceToHost));                                     \
@@ -225,6 +292,7 @@ static int row_stat(Matrix *m, void *out_host)
         if (m->val_type == CSRK_VAL_F64) GO(int32_t, double); else GO(int32_t, float);
     }
 #undef GO
+#undef ROW_ARGS
     CSRK_LAUNCH_CHECK();
     CSRK_HIP(hipMemcpy(out_host, d.p, (size_t)m->nrows * m->val_bytes(), hipMemcpyDeviceToHost));
     return CSRK_OK;
