@@ -200,7 +200,7 @@ def test_spmv_shapes(algo, shape):
 
 def test_spmv_many_heavy_rows(monkeypatch, split_mode):
     """
-    More long rows than one accumulator group holds (8192): tier 0 runs as several groups.  The
+    More long rows than one accumulator group holds (15360): tier 0 runs as several groups.  The
     threshold is lowered so that a small matrix has that many "heavy" rows; rows of every length
     around a lane's 8 entries and a tile's 512, dense runs inside one column block, a last block
     narrower than 4096 columns.
@@ -211,9 +211,9 @@ def test_spmv_many_heavy_rows(monkeypatch, split_mode):
     monkeypatch.setenv('CSRK_HEAVY_MIN', '64')
     monkeypatch.setenv('CSRK_TIERB_MIN', '0')
     rng = np.random.default_rng(2026)
-    nrows = 9500
+    nrows = 19000
     lens = rng.integers(64, 130, size=nrows)
-    lens[::7] = 3                       # light rows in between
+    lens[::7] = 3                       # light rows in between (16285 rows stay >= 64: two groups)
     lens[5] = 30000                     # > one column block's worth per block
     lens[9000] = 511
     lens[9001] = 512
