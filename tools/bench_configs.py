@@ -2,8 +2,10 @@
 """
 Measurements for BASELINE.json configs[2] (dense-panel SpMM, A 2M x 2M nnz 5e7, k = 64) and
 configs[4] (transpose + A B^T on a MovieLens-25M-shaped 162541 x 59047 matrix, nnz 2.5e7), with
-size-independent parity properties at full size.  Not the driver's bench (bench.py is); the numbers
-go into DESIGN.md.   PYTHONPATH=. python tools/bench_configs.py [spmm|transpose|abt|all]
+size-independent parity properties at full size and the CPU oracle (sequential restatement of the
+reference loops, 1 core) timed beside each on a bounded sample.  Not the driver's bench (bench.py is); the
+numbers go into DESIGN.md and profiles/r01_configs.json.
+    PYTHONPATH=. python tools/bench_configs.py [spmm|transpose|abt|all]
 """
 import ctypes as C
 import json
@@ -62,9 +64,23 @@ if what in ('spmm', 'all'):
     check(lib.csrk_spmv_device(habs, xa.data_ptr(), bound.data_ptr(), None))
     torch.cuda.synchronize()
     err = float(((Cm[:, 0] - y).abs() / (bound + 1e-300)).max())
+    # CPU baseline: the oracle's dense-panel product on the first rows of A holding ~2e6 entries
+    from oracle import oracle as O
+    rp_h = m['rowptrs'].cpu().numpy()
+    r_s = int(np.searchsorted(rp_h, 2_000_000))
+    e_s = int(rp_h[r_s])
+    ci_h, vs_h = m['colinds'][:e_s].cpu().numpy(), m['values'][:e_s].cpu().numpy()
+    B_h = B.cpu().numpy()
+    t0 = time.perf_counter()
+    C_h = O.spmm_dense(r_s, rp_h[:r_s + 1], ci_h, vs_h, B_h)
+    t_cpu = time.perf_counter() - t0
+    samp_err = float(np.max(np.abs(C_h - Cm[:r_s].cpu().numpy())) / max(1e-300, float(np.max(np.abs(C_h)))))
     print(json.dumps({'config': 'spmm_dense 2Mx2M nnz5e7 k64 f64', 'ms': round(ms, 3), 'gflops': round(2 * nnz * k / ms / 1e6, 1),
                       'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBs_alg': round(alg / ms / 1e6, 1),
-                      'col0_vs_spmv_max_err_over_bound': err}), flush=True)
+                      'col0_vs_spmv_max_err_over_bound': err,
+                      'cpu_baseline': {'gflops': round(2 * e_s * k / t_cpu / 1e9, 3), 'cores': 1, 'kind': 'port',
+                                       'sample': f'first {r_s} rows ({e_s} entries), {t_cpu:.2f} s',
+                                       'gpu_vs_oracle_max_rel_err_on_sample': samp_err}}), flush=True)
     check(lib.csrk_free(h)); check(lib.csrk_free(habs))
     del m, B, Cm
 
@@ -106,9 +122,21 @@ if what in ('transpose', 'all'):
     check(lib.csrk_export(t, rpt.ctypes.data_as(C.c_void_p), None, None))
     hist_ok = np.array_equal(np.diff(rpt), np.bincount(m['colinds'].cpu().numpy(), minlength=nc))
     alg = 4 * nnz + (4 + 8) * nnz + (4 + 8) * nnz + (nr + nc + 2) * 4
+    # CPU baseline + full-size bit-exact check: the oracle's transpose of the whole matrix
+    from oracle import oracle as O
+    rp_h, ci_h, vs_h = m['rowptrs'].cpu().numpy(), m['colinds'].cpu().numpy(), m['values'].cpu().numpy()
+    t0 = time.perf_counter()
+    _, _, orp, oci, ovs = O.transpose(nr, nc, rp_h, ci_h, vs_h)
+    t_cpu = time.perf_counter() - t0
+    ci_t = np.empty(nnz, np.int32); vs_t = np.empty(nnz)
+    check(lib.csrk_export(t, rpt.ctypes.data_as(C.c_void_p), ci_t.ctypes.data_as(C.c_void_p), vs_t.ctypes.data_as(C.c_void_p)))
+    exact = bool(np.array_equal(rpt, orp) and np.array_equal(ci_t, oci) and np.array_equal(vs_t, ovs))
     print(json.dumps({'config': 'transpose ML25M-shape 162541x59047 nnz 25000095 (wall time per csrk_transpose call, result arrays from the pool)',
                       'ms': round(ms, 3), 'algorithmic_GB': round(alg / 1e9, 3), 'achieved_GBs_alg': round(alg / ms / 1e6, 1),
-                      'double_transpose_bit_exact': bool(ok), 'rowptrs_match_histogram': bool(hist_ok)}), flush=True)
+                      'double_transpose_bit_exact': bool(ok), 'rowptrs_match_histogram': bool(hist_ok),
+                      'bit_exact_vs_oracle_full_size': exact,
+                      'cpu_baseline': {'ms': round(t_cpu * 1e3, 1), 'GBs_alg': round(alg / t_cpu / 1e9, 2), 'cores': 1, 'kind': 'port',
+                                       'sample': 'the whole matrix, one pass'}}), flush=True)
     for o in outs:
         check(lib.csrk_free(o))
     check(lib.csrk_free(tt))
@@ -137,7 +165,23 @@ if what in ('abt', 'all'):
     cb = torch.zeros(nc, dtype=torch.float64, device=dev).index_add_(0, m['colinds'][:eb].long(), m['values'][:eb])
     want = float((ca * cb).sum())
     got = float(vsc.sum())
+    # warm call, and the oracle (transpose + mult_ab, the reference's mult_abt) on the same block
+    c2 = handle_t(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    check(lib.csrk_spgemm_abt(ha, hb, C.byref(c2)))
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) * 1e3
+    check(lib.csrk_free(c2))
+    from oracle import oracle as O
+    ci_h, vs_h = m['colinds'].cpu().numpy(), m['values'].cpu().numpy()
+    t0 = time.perf_counter()
+    tnr, tnc, trp, tci, tvs = O.transpose(20000, nc, rpb.cpu().numpy(), ci_h[:eb], vs_h[:eb])
+    r = O.mult_ab((2000, nc, rpa.cpu().numpy(), ci_h[:ea], vs_h[:ea]), (tnr, tnc, trp, tci, tvs))
+    t_cpu = time.perf_counter() - t0
     print(json.dumps({'config': 'mult_abt (2000 x 59047) x (20000 x 59047)^T, ML25M-shape rows', 'ms_first_call': round(ms, 1),
-                      'product_nnz': nnzc.value, 'checksum_rel_err': abs(got - want) / abs(want),
-                      'cols_sorted': bool(all(np.all(np.diff(cic[rpc[i]:rpc[i + 1]]) > 0) for i in range(0, 2000, 97)))}), flush=True)
+                      'ms': round(ms2, 1), 'product_nnz': nnzc.value, 'checksum_rel_err': abs(got - want) / abs(want),
+                      'cols_sorted': bool(all(np.all(np.diff(cic[rpc[i]:rpc[i + 1]]) > 0) for i in range(0, 2000, 97))),
+                      'cpu_baseline': {'ms': round(t_cpu * 1e3, 1), 'cores': 1, 'kind': 'port', 'product_nnz': int(len(r[3])),
+                                       'sample': 'the same block, one pass'}}), flush=True)
     check(lib.csrk_free(c)); check(lib.csrk_free(ha)); check(lib.csrk_free(hb))
