@@ -229,6 +229,24 @@ def test_spmv_many_heavy_rows(monkeypatch, split_mode):
     _check(y, ref, _abs_bound(m, x))
 
 
+def test_spmv_structure_only_and_f32_in_the_tiers():
+    "values absent (every entry counts 1.0, csr/csr.py:254-262) or float32, with rows long enough for every tier"
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    lens = rng.integers(0, 30, size=6000)
+    lens[[5, 900, 4000]] = [5000, 700, 2049]
+    lens[100:110] = 200
+    for dtype in (None, np.float32):
+        m = _random_csr(rng, 6000, 40000, lens, dtype=np.float32 if dtype else np.float64, sort=True)
+        if dtype is None:
+            m.values = None
+        x = rng.uniform(-1, 1, size=m.ncols)
+        for algo in ALGOS:
+            y = _mult_vec(m, x, algo)
+            ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+            _check(y, ref, _abs_bound(m, x))
+
+
 def test_spmv_deterministic():
     "no float atomics: repeated launches are bitwise identical"
     rng = np.random.default_rng(11)
