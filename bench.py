@@ -132,8 +132,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the first step runs the plan-less kernel, the second builds the plan (tiers, streams, pack): time both
+    first_ms = plan_ms = None
+    for i in range(args.warmup):
+        if i < 2:
+            torch.cuda.synchronize()
+            t_w = time.perf_counter()
         op.step(x)
+        if i < 2:
+            torch.cuda.synchronize()
+            if i == 0:
+                first_ms = (time.perf_counter() - t_w) * 1e3
+            else:
+                plan_ms = (time.perf_counter() - t_w) * 1e3
     barrier()
     check(lib.csrk_spmv_profile_begin(h, args.steps))
     op.timing = world > 1
@@ -217,6 +228,10 @@ def main():
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),
         'roofline': roofline,
         'gen_seconds': round(t_gen, 2),
+        # one-off costs on this handle, outside the timed region: the first call (plan-less kernel) and the second
+        # (which builds the SpMV plan before launching)
+        'first_call_ms': None if first_ms is None else round(first_ms, 2),
+        'plan_build_call_ms': None if plan_ms is None else round(plan_ms, 2),
     }
     if compute_ms is not None:
         # per step: the slowest rank's local SpMV (device events) and what the exchange adds on top
