@@ -2059,8 +2059,24 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
         CSRK_HIP(hipMemcpyAsync(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
         CSRK_HIP(hipMemcpyAsync(hn.data(), hcnt.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
         CSRK_HIP(hipStreamSynchronize(s));
-        for (int32_t i = 0; i < n_hot; i++) ord[(size_t)i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return hn[(size_t)a] > hn[(size_t)b]; });
+        // stable, count descending: two 16-bit LSD radix passes over the complemented count (a comparison sort of
+        // 4 * 10^5 indices through a lambda took tens of ms of the plan)
+        {
+            std::vector<int32_t> tmp((size_t)n_hot);
+            std::vector<uint32_t> bucket(65537);
+            for (int32_t i = 0; i < n_hot; i++) ord[(size_t)i] = i;
+            for (int pass = 0; pass < 2; pass++) {
+                const int sh = 16 * pass;
+                std::fill(bucket.begin(), bucket.end(), 0u);
+                for (int32_t i = 0; i < n_hot; i++) bucket[((~(uint32_t)hn[(size_t)i] >> sh) & 0xffffu) + 1]++;
+                for (size_t b = 0; b < 65536; b++) bucket[b + 1] += bucket[b];
+                for (int32_t i = 0; i < n_hot; i++) {
+                    const int32_t o = ord[(size_t)i];
+                    tmp[bucket[(~(uint32_t)hn[(size_t)o] >> sh) & 0xffffu]++] = o;
+                }
+                ord.swap(tmp);
+            }
+        }
         for (int32_t i = 0; i < n_hot; i++) sorted[(size_t)i] = hc[(size_t)ord[(size_t)i]];
         CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, s));
         CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
