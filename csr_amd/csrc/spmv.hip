@@ -963,7 +963,7 @@ __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t 
 //     the heads are folded in, in tile order, by one wavefront after the segment's barrier.  So every
 //     accumulator sees its addends in a fixed order whichever wavefront took which tile: results are
 //     bitwise reproducible, although ds_add_f64 is used for the adds.
-//   * At the end the workgroup stores its accumulators (H * 8 B) and acc_reduce_kernel sums the
+//   * At the end the workgroup stores its accumulators (H * 8 B) and acc_reduce_multi_kernel sums the
 //     workgroups' partials in workgroup order into y.
 // HBM traffic: 12 B per entry + one 32 KiB window per segment + n_wg * H * 8 B of partials (14 MB on the
 // headline matrix) -- against 12 B + 20 B per pair + windows for the pair form.
@@ -1202,28 +1202,70 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
     for (int h = tid; h < H; h += PT) partial[(int64_t)blockIdx.x * H + h] = s_acc[h];
 }
 
-// y[row_list[h]] = sum over workgroups of partial[w][h], in workgroup order.  64 heavy rows per
-// workgroup, 16 lanes-groups each summing a contiguous range of workgroups, joined in order through LDS.
-__global__ __launch_bounds__(1024) void acc_reduce_kernel(const double *__restrict__ partial, int32_t H, int32_t n_wg,
-                                                         const int32_t *__restrict__ row_list, double *__restrict__ y)
+// (The ordered reduce -- y[row_list[h]] = sum over workgroups / column blocks w of partial[w][h], in order: 64
+// rows per workgroup, 16 lane groups each summing a contiguous range of w, joined in order through LDS -- is
+// acc_reduce_multi_kernel below.)
+// The per-SpMV epilogue work is a handful of tiny kernels (carry fix-ups of the light stream and of tier 1,
+// ordered reduces of tier 0 and tier 1: ~5 us each, mostly launch latency).  They are issued as ONE fix-up
+// launch and ONE reduce launch, each covering up to four jobs (a job = a contiguous range of workgroups).
+struct FixJob {
+    const int32_t *carry_row;
+    const double *carry_val;
+    int64_t n;
+    double *y;
+    int32_t blocks;
+};
+struct RedJob {
+    const double *partial;
+    const int32_t *row_list;
+    int32_t H, n_wg, blocks;
+};
+struct FixJobs {
+    FixJob j[4];
+    int32_t n;
+};
+struct RedJobs {
+    RedJob j[4];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) void spmv_fixup_multi_kernel(FixJobs jobs)
+{
+    int b = blockIdx.x, q = 0;
+    while (q + 1 < jobs.n && b >= jobs.j[q].blocks) b -= jobs.j[q++].blocks;
+    const FixJob &J = jobs.j[q];
+    const int64_t t = (int64_t)b * 256 + threadIdx.x;
+    if (t >= J.n) return;
+    const int32_t row = J.carry_row[t];
+    if (row < 0) return;
+    if (t > 0 && J.carry_row[t - 1] == row) return;
+    double acc = J.carry_val[t];
+    for (int64_t u = t + 1; u < J.n && J.carry_row[u] == row; u++) acc += J.carry_val[u];
+    J.y[row] = acc + J.y[row];
+}
+
+__global__ __launch_bounds__(1024) void acc_reduce_multi_kernel(RedJobs jobs, double *__restrict__ y)
 {
     __shared__ double s_p[16][WAVE];
+    int b = blockIdx.x, q = 0;
+    while (q + 1 < jobs.n && b >= jobs.j[q].blocks) b -= jobs.j[q++].blocks;
+    const RedJob &J = jobs.j[q];
     const int lane = threadIdx.x & (WAVE - 1), g = threadIdx.x / WAVE;
-    const int h = blockIdx.x * WAVE + lane;
-    const int per = (n_wg + 15) / 16;
-    const int w0 = g * per, w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    const int h = b * WAVE + lane;
+    const int per = (J.n_wg + 15) / 16;
+    const int w0 = g * per, w1 = w0 + per < J.n_wg ? w0 + per : J.n_wg;
     double acc = 0.0;
-    if (h < H) {
+    if (h < J.H) {
 #pragma unroll 8
-        for (int w = w0; w < w1; w++) acc += partial[(int64_t)w * H + h];
+        for (int w = w0; w < w1; w++) acc += J.partial[(int64_t)w * J.H + h];
     }
     s_p[g][lane] = acc;
     __syncthreads();
-    if (g == 0 && h < H) {
+    if (g == 0 && h < J.H) {
         double tot = s_p[0][lane];
 #pragma unroll
-        for (int q = 1; q < 16; q++) tot += s_p[q][lane];
-        y[row_list[h]] = tot;
+        for (int u = 1; u < 16; u++) tot += s_p[u][lane];
+        y[J.row_list[h]] = tot;
     }
 }
 
@@ -2414,6 +2456,40 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         // stream beside the streaming kernels; everything that writes y stays in order on `s`.
         const bool aux = p->aux != nullptr;
         hipStream_t sa = aux ? p->aux : s;
+        // epilogue jobs, launched together at the end (immediately and separately with the auxiliary stream)
+        FixJobs fix;
+        RedJobs red;
+        fix.n = red.n = 0;
+        auto flush_fix = [&]() -> int {
+            if (fix.n == 0) return CSRK_OK;
+            unsigned g = 0;
+            for (int i = 0; i < fix.n; i++) g += (unsigned)fix.j[i].blocks;
+            spmv_fixup_multi_kernel<<<g, 256, 0, s>>>(fix);
+            CSRK_LAUNCH_CHECK();
+            fix.n = 0;
+            return CSRK_OK;
+        };
+        auto add_fix = [&](const int32_t *cr, const double *cv, int64_t n, double *yy) -> int {
+            if (n <= 0) return CSRK_OK;
+            if (fix.n == 4) CSRK_TRY(flush_fix());
+            fix.j[fix.n++] = FixJob{cr, cv, n, yy, (int32_t)ceil_div(n, 256)};
+            return CSRK_OK;
+        };
+        auto flush_red = [&]() -> int {
+            if (red.n == 0) return CSRK_OK;
+            unsigned g = 0;
+            for (int i = 0; i < red.n; i++) g += (unsigned)red.j[i].blocks;
+            acc_reduce_multi_kernel<<<g, 1024, 0, s>>>(red, d_y);
+            CSRK_LAUNCH_CHECK();
+            red.n = 0;
+            return CSRK_OK;
+        };
+        auto add_red = [&](const double *part, const int32_t *rows, int32_t H, int32_t n_wg) -> int {
+            if (H <= 0) return CSRK_OK;
+            if (red.n == 4) CSRK_TRY(flush_red());
+            red.j[red.n++] = RedJob{part, rows, H, n_wg, (int32_t)ceil_div(H, WAVE)};
+            return CSRK_OK;
+        };
         if (aux) {
             CSRK_HIP(hipEventRecord(p->ev_fork, s));
             CSRK_HIP(hipStreamWaitEvent(sa, p->ev_fork, 0));
@@ -2447,9 +2523,13 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                     pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>());
                 kh.stop();
                 CSRK_LAUNCH_CHECK();
-                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, sa>>>(
-                    t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
-                CSRK_LAUNCH_CHECK();
+                if (aux) {
+                    spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, sa>>>(
+                        t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
+                    CSRK_LAUNCH_CHECK();
+                } else {
+                    CSRK_TRY(add_fix(t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>()));
+                }
                 continue;
             }
             KernelTimer kh(p, s, 1 + q);
@@ -2471,10 +2551,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             if (aux) {
                 CSRK_HIP(hipEventRecord(p->ev_tier[q], s));
                 CSRK_HIP(hipStreamWaitEvent(sa, p->ev_tier[q], 0));
+                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sa>>>(
+                    pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
+                CSRK_LAUNCH_CHECK();
+            } else {
+                CSRK_TRY(add_fix(pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>()));
             }
-            spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sa>>>(
-                pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
-            CSRK_LAUNCH_CHECK();
         }
         if (aux && p->n_hot) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
         {
@@ -2496,13 +2578,13 @@ spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
                     p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
-                if (p->n_heavy)
-                    spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(p->ls.n_tiles, 256), 256, 0, s>>>(
-                        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y);
-                else
+                if (p->n_heavy) {
+                    CSRK_TRY(add_fix(p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y));
+                } else {
                     spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->ls.n_tiles * WAVE, 256), 256, 0, s>>>(
                         p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y);
-                CSRK_LAUNCH_CHECK();
+                    CSRK_LAUNCH_CHECK();
+                }
             } else {
             KernelTimer kt(p, s);
             if (p->n_hot) {
@@ -2531,21 +2613,17 @@ spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
             CSRK_HIP(hipEventRecord(p->ev_aux, sa));
             CSRK_HIP(hipStreamWaitEvent(s, p->ev_aux, 0));
         }
-        if (p->n_heavy && !p->acc.empty()) {
-            for (AccPanel *ap : p->acc) {
-                acc_reduce_kernel<<<(unsigned)ceil_div(ap->nrow, WAVE), 1024, 0, s>>>(
-                    ap->partial.as<double>(), ap->nrow, ap->n_wg, ap->row_list.as<int32_t>(), d_y);
-                CSRK_LAUNCH_CHECK();
-            }
-        }
+        CSRK_TRY(flush_fix());      // the carries of the light stream and of the tiers, one launch
+        if (p->n_heavy && !p->acc.empty())
+            for (AccPanel *ap : p->acc)
+                CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg));
         for (int q = 0; q < 2 && p->n_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             // y[row] = sum over column blocks of the (block, row) partials, in block order
-            acc_reduce_kernel<<<(unsigned)ceil_div(pn->nrow, WAVE), 1024, 0, s>>>(
-                pn->y.as<double>(), pn->nrow, pn->nb, pn->row_list.as<int32_t>(), d_y);
-            CSRK_LAUNCH_CHECK();
+            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb));
         }
+        CSRK_TRY(flush_red());      // the ordered reduces of the tiers, one launch
         break;
     }
     case CSRK_SPMV_VECTOR: {
