@@ -146,7 +146,10 @@ def main():
             else:
                 plan_ms = (time.perf_counter() - t_w) * 1e3
     barrier()
-    check(lib.csrk_spmv_profile_begin(h, args.steps))
+    # kernel event pairs on every 5th step (they cost ~20 us per timed SpMV: 0.713 vs 0.693 ms with / without)
+    if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
+        check(lib.csrk_spmv_profile_every(h, 5 if args.steps >= 10 else 1))
+        check(lib.csrk_spmv_profile_begin(h, args.steps))
     op.timing = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -154,7 +157,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_rec, k_ms2 = C.c_int(0), (C.c_float * 3)(0.0, 0.0, 0.0)
-    check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
+    if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
+        check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
     compute_ms = None
     if world > 1:
         t = torch.tensor([elapsed, op.compute_ms()], dtype=torch.float64, device=dev)

@@ -149,6 +149,9 @@ struct SpmvPlan {
     std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1/2 = panel tier 0/1
     int ev_used = 0;
     bool profiling = false;
+    int prof_every = 1;           // profile every n-th launch group only (an event pair costs ~3 us on the stream)
+    int prof_calls = 0;
+    bool prof_this = false;       // the launch group in progress is being timed
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
@@ -165,7 +168,7 @@ struct KernelTimer {   // records an event pair around one launch when the plan 
     int slot = -1;
     KernelTimer(SpmvPlan *p_, hipStream_t s_, int chan = 0) : p(p_), s(s_)
     {
-        if (p->profiling && p->ev_used + 2 <= (int)p->ev.size()) {
+        if (p->profiling && p->prof_this && p->ev_used + 2 <= (int)p->ev.size()) {
             slot = p->ev_used;
             p->ev_used += 2;
             p->ev_chan[slot / 2] = chan;
@@ -2664,6 +2667,7 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     std::lock_guard<std::mutex> lk(m->mu);
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan_locked(m, s, &p, true));
+    p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
 #define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
@@ -2810,7 +2814,20 @@ int csrk_spmv_profile_begin(csrk_handle_t h, int max_records)
     }
     p->ev_chan.assign(p->ev.size() / 2, 0);
     p->ev_used = 0;
+    p->prof_calls = 0;
     p->profiling = true;
+    return CSRK_OK;
+}
+
+int csrk_spmv_profile_every(csrk_handle_t h, int every_n)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(every_n >= 1, "every_n must be >= 1");
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));
+    std::lock_guard<std::mutex> lk(m->mu);
+    p->prof_every = every_n;
     return CSRK_OK;
 }
 

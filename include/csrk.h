@@ -135,6 +135,10 @@ CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
  * recorded launches and mean_ms[3], their mean durations in milliseconds (0 if a kernel did not run).
  * At most `max_records` launches are recorded. */
 CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
+/* Time only every n-th csrk_spmv_device call between begin and end (default 1: all of them).  The event
+ * pairs sit on the launch stream between the kernels and cost ~3 us apiece -- 20 us per SpMV with three
+ * timed kernels, 3 % of the headline step; call before csrk_spmv_profile_begin. */
+CSRK_API int csrk_spmv_profile_every(csrk_handle_t h, int every_n);
 CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);
 
 /* ---- mult_ab / mult_abt: sparse x sparse -> sparse ------------------------------------
