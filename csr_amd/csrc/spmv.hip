@@ -2,27 +2,27 @@
 // (csr/kernels/numba/__init__.py:55-67: one sequential pass over nnz with a moving row
 // cursor) and lk_mkl_spmv (csr/kernels/mkl/mkl_ops.c:116-126).
 //
-// Three kernels, selected per handle (csrk_set_spmv_algo; AUTO = merge):
+// Algorithms, selected per handle (csrk_set_spmv_algo; AUTO = merge):
 //
-//  merge   Merge-path tiles.  The path over (row ends, nnz) is cut into tiles of a fixed
-//          number of ITEMS = rows + nnz, so a tile's work is bounded whatever the row-length
-//          distribution (power-law rows, millions of empty rows, one 10^6-entry row).
-//          One 256-thread workgroup per tile:
-//            phase 1  streams the tile's colinds/values fully coalesced, gathers x[col],
-//                     and stages the products in LDS; loads the tile's row ends to LDS;
-//            phase 2  one lane per row sums its (short) row from LDS in storage order --
-//                     the reference's order, so short rows are bit-identical to it -- and
-//                     rows with >= 64 entries in the tile are summed by a whole wavefront
-//                     (strided partials + __shfl_down tree);
-//          a row cut by a tile boundary leaves one partial per tile in carry[], and a
-//          second tiny kernel adds each row's partials in tile order (no float atomics:
-//          results are bitwise reproducible run to run).
-//          HBM traffic per nnz: 4 B colind + 8 B value, read exactly once, + the x gather;
-//          per row: 4/8 B row pointer + 8 B y.
+//  merge   The production path.  FIRST call on a handle: the merge-path tile kernel on the CSR arrays as they
+//          are (no plan beyond the tile coordinates) -- the path over (row ends, nnz) is cut into tiles of a
+//          fixed number of ITEMS = rows + nnz, so a tile's work is bounded whatever the row-length
+//          distribution; one 256-thread workgroup per tile stages products in LDS, one lane per row sums its
+//          row in storage order, rows cut by a tile boundary leave a carry that a tiny kernel adds in tile
+//          order.  From the SECOND call on, a plan built once per handle (see "plan" below and DESIGN.md
+//          section 4) splits the rows three ways, each with a private, pre-decoded 12 B/entry stream:
+//            tier 0  the (up to 15360) longest rows: column-block-major, x window AND one accumulator per
+//                    row in LDS (spmv_acc_kernel, "long rows, accumulator form");
+//            tier 1  rows of 128 .. tier-0 threshold: (column block, row) pairs over 1 MiB x windows kept in
+//                    one XCD's L2 (spmv_panel_kernel, "long rows, panel form");
+//            light   everything else: one wavefront per 512-entry tile, hot columns from LDS / a packed,
+//                    L2-resident copy of x, short rows bit-identical to the sequential loop
+//                    (spmv_lstream_kernel, "short rows: the light stream").
+//          No float atomics decide an order anywhere: results are bitwise reproducible run to run.
 //  vector  One wavefront per row segment (rows longer than 4096 entries are split);
 //          coalesced 64-lane strides over colinds/values, __shfl_down reduction, ordered
-//          partial combine.  The classic CSR-vector shape; best when most rows are >= 64.
-//  scalar  One lane per row.  Best for tiny uniform rows; kept mainly as an A/B baseline.
+//          partial combine.  The classic CSR-vector shape; kept as an A/B baseline.
+//  scalar  One lane per row.  Kept as an A/B baseline.
 //
 // All kernels accumulate in float64 whatever the storage dtype, like the reference
 // (float32 values are widened on load; structure-only matrices multiply by 1.0,
