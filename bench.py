@@ -18,8 +18,10 @@ One JSON line is printed by rank 0:
              panel tier 1: DESIGN.md section 4): that kernel's own algorithmic bytes per launch
              (12 B per entry it processes + its row pointers / partials + x once) divided by its
              mean duration, measured live with hipEvent pairs recorded around that kernel on its
-             launch stream during the timed steps (csrk_spmv_profile_begin/end); `all_kernels`
-             lists every kernel, `hbm_gbs_end_to_end` is 2.60 GB / step time;
+             launch stream during every 5th timed step (csrk_spmv_profile_every/begin/end: a pair
+             costs ~3 us on the stream, six per step would add 3 % to the step); `all_kernels`
+             lists every kernel, `whole_spmv` the same fraction for the whole 2.60 GB,
+             `hbm_gbs_end_to_end` is 2.60 GB / step time;
              peak = 8000 GB/s (HBM3E spec); traffic = per-launch HBM bytes from the committed
              rocprofv3 PMC summary (profiles/), or null;
   cpu_baseline  the oracle's sequential restatement of the reference loop (oracle/csr_oracle.c,
