@@ -485,20 +485,51 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
 // ---- hot-column cache: plan-time kernels ------------------------------------------------------------
 // Column reference counts over the rows the tile kernel serves, from every `row_stride`-th row and at
 // most 128 entries of it (a sample is enough to rank popularity); total[0] = entries counted.
+// Popular columns collect millions of these increments: as global atomics they serialise (14 ms for the 4*10^7
+// sampled entries of the headline matrix).  Each persistent workgroup therefore counts into an LDS hash table
+// first (a column that finds a slot within HOT_PROBE probes stays there; the others go straight to memory) and
+// flushes its <= HOT_TABLE distinct columns once at the end.
+constexpr int HOT_TABLE = 8192, HOT_PROBE = 4;
 template <class P>
 __global__ __launch_bounds__(256) void hot_count_kernel(const P *__restrict__ rp, const P *__restrict__ rp_light,
                                                        const int32_t *__restrict__ ci, int32_t nrows, int64_t row_stride,
                                                        int32_t *__restrict__ cnt, unsigned long long *__restrict__ total)
 {
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * row_stride;
+    __shared__ int32_t s_key[HOT_TABLE];
+    __shared__ int32_t s_cnt[HOT_TABLE];
+    for (int k = threadIdx.x; k < HOT_TABLE; k += 256) {
+        s_key[k] = -1;
+        s_cnt[k] = 0;
+    }
+    __syncthreads();
+    const int64_t n_sampled = (nrows + row_stride - 1) / row_stride;
     unsigned long long n = 0;
-    if (r < nrows && !(rp_light && rp_light[r + 1] == rp_light[r])) {   // not a row cut out to the panels
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_sampled; q += (int64_t)gridDim.x * 256) {
+        const int64_t r = q * row_stride;
+        if (rp_light && rp_light[r + 1] == rp_light[r]) continue;      // a row cut out to the tiers
         const int64_t s = rp[r];
         int64_t e = rp[r + 1];
         e = e - s > 128 ? s + 128 : e;
-        for (int64_t k = s; k < e; k++) atomicAdd(&cnt[ci[k]], 1);
-        n = (unsigned long long)(e - s);
+        for (int64_t k = s; k < e; k++) {
+            const int32_t c = ci[k];
+            uint32_t slot = ((uint32_t)c * 2654435761u) >> 19;      // 13 bits
+            bool done = false;
+#pragma unroll
+            for (int pr = 0; pr < HOT_PROBE && !done; pr++) {
+                const int32_t old = atomicCAS(&s_key[slot], -1, c);
+                if (old == -1 || old == c) {
+                    atomicAdd(&s_cnt[slot], 1);
+                    done = true;
+                }
+                slot = (slot + 1) & (HOT_TABLE - 1);
+            }
+            if (!done) atomicAdd(&cnt[c], 1);
+        }
+        n += (unsigned long long)(e - s);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < HOT_TABLE; k += 256)
+        if (s_key[k] >= 0) atomicAdd(&cnt[s_key[k]], s_cnt[k]);
     for (int off = WAVE / 2; off; off >>= 1) n += __shfl_down(n, off, WAVE);
     if ((threadIdx.x & (WAVE - 1)) == 0 && n) atomicAdd(total, n);
 }
@@ -2048,7 +2079,8 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * 4, s));
     CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
     const int64_t row_stride = p->nnz_light > (1ll << 25) ? p->nnz_light >> 25 : 1;
-    hot_count_kernel<P><<<(unsigned)ceil_div(ceil_div(m->nrows, row_stride), 256), 256, 0, s>>>(
+    const int64_t hc_need = ceil_div(ceil_div(m->nrows, row_stride), 256);
+    hot_count_kernel<P><<<(unsigned)(hc_need < 2048 ? hc_need : 2048), 256, 0, s>>>(
         (const P *)m->d_rowptrs, p->n_heavy ? p->rp_light.as<P>() : (const P *)nullptr, m->d_colinds, m->nrows,
         row_stride, cnt.as<int32_t>(), census.as<unsigned long long>());
     CSRK_LAUNCH_CHECK();
