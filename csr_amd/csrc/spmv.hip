@@ -125,7 +125,9 @@ struct SpmvPlan {
     int32_t n_hot_lds = 0;        // slots [0, n_hot_lds) hold the most referenced columns (kept in LDS by the light stream)
     int32_t hot_slots = 0;
     double hot_cover = 0.0;       // sampled fraction of the tile kernel's entries on packed columns
-    DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered
+    DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered (tile kernel only: built when the
+                        // light stream is not)
+    DevBuf hot_slot;    // int32[ncols]: slot of a packed column, -1 otherwise (kept until the stream / ci_hot is built)
     DevBuf hot_cols;    // int32[n_hot]: column of each slot
     DevBuf xh;          // double[n_hot]
     hipStream_t aux = nullptr;    // auxiliary stream: hot pack, tier-1 fix-up/reduce1 beside the streaming kernels
@@ -587,13 +589,13 @@ __global__ void hot_slot_kernel(const int32_t *__restrict__ hot_cols, int32_t n_
     if (k < n_hot) slot[hot_cols[k]] = k;
 }
 
-__global__ void hot_remap_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ cnt,
-                                 const int32_t *__restrict__ slot, int32_t thr, int32_t *__restrict__ ci_hot)
+__global__ void hot_remap_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ slot_map,
+                                 int32_t *__restrict__ ci_hot)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnz) return;
-    const int32_t c = ci[k];
-    ci_hot[k] = cnt[c] >= thr ? ~slot[c] : c;
+    const int32_t c = ci[k], sl = slot_map[c];
+    ci_hot[k] = sl >= 0 ? ~sl : c;
 }
 
 // ---- long rows: cut out of the merge path ------------------------------------------------------
@@ -1384,7 +1386,8 @@ template <class P, int VT>
 __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
                                                      const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                                      LsSegs sg, int64_t n_slots, const int32_t *__restrict__ phys_tile,
-                                                     double *__restrict__ svals, uint32_t *__restrict__ sidx)
+                                                     const int32_t *__restrict__ slot_map, double *__restrict__ svals,
+                                                     uint32_t *__restrict__ sidx)
 {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
@@ -1401,7 +1404,8 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
         const int64_t a = (int64_t)src[r] + (L - first);
         v = ValLoad<VT>::at(vs, a);
         const int32_t c = ci[a];
-        ix = c < 0 ? (LS_HOT_BIT | (uint32_t)~c) : (uint32_t)c;
+        const int32_t sl = slot_map ? slot_map[c] : -1;         // slot of a packed column
+        ix = sl >= 0 ? (LS_HOT_BIT | (uint32_t)sl) : (uint32_t)c;
         if (L == first) ix |= LS_START_BIT;
     }
     svals[t * ACC_TILE + acc_val_slot(el)] = v;
@@ -2158,13 +2162,13 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
         CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, s));
         CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
     }
-    hot_slot_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(p->hot_cols.as<int32_t>(), n_hot, slot.as<int32_t>());
+    // column -> slot map (-1: not packed); the light stream's fill reads it, as does the renumbered colinds copy
+    // the tile kernel needs when no stream is built
+    CSRK_TRY(p->hot_slot.alloc((size_t)nc * 4));
+    CSRK_HIP(hipMemsetAsync(p->hot_slot.p, 0xff, (size_t)nc * 4, s));
+    hot_slot_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(p->hot_cols.as<int32_t>(), n_hot, p->hot_slot.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(p->xh.alloc((size_t)n_hot * 8));
-    CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
-    hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, cnt.as<int32_t>(),
-                                                                    slot.as<int32_t>(), thr, p->ci_hot.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
     const int32_t n_top = n_hot < LS_HOT_LDS ? n_hot : LS_HOT_LDS;
     p->n_hot = n_hot;
     p->n_hot_lds = n_top;
@@ -2178,7 +2182,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
 template <class P, int VT>
 static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, int32_t nrows_view, const int32_t *ci,
                         const void *vs, const LsSegs &sg, int64_t n_tiles, const std::vector<int32_t> *phys, int32_t n_out,
-                        hipStream_t s)
+                        const int32_t *slot_map, hipStream_t s)
 {
     ls->on = false;
     DevBuf ridx, dphys;
@@ -2204,7 +2208,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
     ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, ls->vals.as<double>(), ls->idx.as<uint32_t>());
+        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
     ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
@@ -2247,7 +2251,7 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     if (!p->n_heavy && !p->n_hot && !(env && env[0] == '1')) return CSRK_OK;
     const P *rp = (const P *)m->d_rowptrs;
     const P *rpv = p->n_heavy ? p->rp_light.as<P>() : rp;
-    const int32_t *ci = p->n_hot ? p->ci_hot.as<int32_t>() : m->d_colinds;
+    const int32_t *slot_map = p->n_hot ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr;
     const int64_t n_tiles = ceil_div(n_view, ACC_TILE);
     size_t mfree = 0, mtotal = 0;
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
@@ -2258,8 +2262,8 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles * ACC_TILE, sg.ent0[k] = n_view;
     sg.slot0[0] = 0;
     sg.ent0[0] = 0;
-    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, ci, m->d_values, sg, n_tiles, nullptr, m->nrows, s)));
-    if (p->ls.on) p->ci_hot.release();      // the stream carries the renumbered columns
+    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles, nullptr, m->nrows,
+                                  slot_map, s)));
     return CSRK_OK;
 }
 
@@ -2351,7 +2355,8 @@ static int build_tier1_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
                 for (int u = 0; u < LS_THREADS / WAVE && cur[(size_t)k] < end[(size_t)k]; u++) phys[(size_t)cur[(size_t)k]++] = (int32_t)pos++;
     }
     CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1s, src.as<int64_t>(), rpv.as<int64_t>(), (int32_t)pairs,
-                                                   pn->ci.as<int32_t>(), pn->vs.p, sg, n_tiles, &phys, (int32_t)pairs, s)));
+                                                   pn->ci.as<int32_t>(), pn->vs.p, sg, n_tiles, &phys, (int32_t)pairs,
+                                                   (const int32_t *)nullptr, s)));
     if (p->t1s.on) {
         // the pair kernel's own arrays are no longer needed (the partials y', the row list and the geometry are)
         pn->rp.release();
@@ -2405,6 +2410,14 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
             else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
+            if (p->n_hot && !p->ls.on) {        // the tile kernel stays in charge: it reads a renumbered colinds copy
+                CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
+                hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, p->hot_slot.as<int32_t>(),
+                                                                                p->ci_hot.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+                CSRK_HIP(hipStreamSynchronize(s));
+            }
+            p->hot_slot.release();
         }
     } else if (p->algo == CSRK_SPMV_VECTOR) {
         CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
