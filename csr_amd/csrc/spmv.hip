@@ -1033,12 +1033,49 @@ __host__ __device__ __forceinline__ int acc_idx_slot(int e)
     return (j >> 2) * (4 * WAVE) + lane * 4 + (j & 3);        // two 16-B loads per lane
 }
 
+// Where each column block starts inside each heavy row, from ONE pass over the rows' (ascending) columns:
+// pstart[b * H + c] = entries of heavy row c in blocks < b, for b = 0 .. n_blocks (the last = the row's length).
+// One wavefront per 4096-entry piece of a row; an entry whose block differs from its predecessor's opens that
+// block and every empty block skipped in between.  (A binary search per (block, row) pair -- 3.7 * 10^7 pairs on
+// the headline matrix, twice -- was 14 ms of the plan.)
+constexpr int ACC_PIECE = 4096;
+template <class P>
+__global__ __launch_bounds__(256) void acc_pairstart_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                           const int32_t *__restrict__ heavy_row, int32_t n_heavy,
+                                                           int32_t n_blocks, int32_t cb, const int32_t *__restrict__ task_row,
+                                                           const int32_t *__restrict__ task_piece, int64_t n_tasks,
+                                                           int32_t *__restrict__ pstart)
+{
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (q >= n_tasks) return;
+    const int32_t c = task_row[q];
+    const int64_t s = rp[heavy_row[c]], e = rp[heavy_row[c] + 1];
+    const int64_t k0 = s + (int64_t)task_piece[q] * ACC_PIECE;
+    const int64_t k1 = k0 + ACC_PIECE < e ? k0 + ACC_PIECE : e;
+    for (int64_t k = k0 + lane; k < k1; k += WAVE) {
+        const int32_t b = ci[k] / cb;
+        const int32_t bp = k > s ? ci[k - 1] / cb : -1;
+        for (int32_t bb = bp + 1; bb <= b; bb++) pstart[(int64_t)bb * n_heavy + c] = (int32_t)(k - s);
+        if (k == e - 1)
+            for (int32_t bb = b + 1; bb <= n_blocks; bb++) pstart[(int64_t)bb * n_heavy + c] = (int32_t)(e - s);
+    }
+}
+
+__global__ void acc_paircount_kernel(const int32_t *__restrict__ pstart, int64_t pairs, int32_t n_heavy,
+                                     int64_t *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pairs) cnt[i] = (int64_t)pstart[i + n_heavy] - (int64_t)pstart[i];
+}
+
 // one thread per (block, heavy row) pair: copies the pair's entries into the tiled stream
 template <class P, int VT>
 __global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                 const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks, int32_t cb,
                                 const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
-                                double *__restrict__ pvals, uint32_t *__restrict__ pidx)
+                                const int32_t *__restrict__ pstart, double *__restrict__ pvals,
+                                uint32_t *__restrict__ pidx)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -1046,8 +1083,7 @@ __global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restr
     const int64_t n = off[i + 1] - off[i];
     if (n == 0) return;
     const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
+    const int64_t lo = (int64_t)rp[r] + pstart[i];
     int64_t L = blk_tile0[b] * ACC_TILE + (off[i] - off[(int64_t)b * n_heavy]);      // logical position
     for (int64_t k = lo; k < lo + n; k++, L++) {
         const int64_t t = L / ACC_TILE;
@@ -1846,17 +1882,34 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
 // Build one accumulator-form group: the listed heavy rows (<= ACC_MAXROWS, ascending) as a tiled,
 // column-block-major (value, packed index) stream plus the persistent workgroups' segment lists.
 template <class P, int VT>
-static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, int32_t n, int64_t nnz_rows, hipStream_t s)
+static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const int64_t *lens, int32_t n, int64_t nnz_rows,
+                           hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
     const int64_t pairs = (int64_t)n * nb;
     CSRK_TRY(ap->row_list.alloc((size_t)n * 4));
     CSRK_HIP(hipMemcpyAsync(ap->row_list.p, rows, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    DevBuf off, bends;
+    DevBuf off, bends, pstart, d_trow, d_tpiece;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
-    const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
-    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>());
+    // block starts inside every row (one pass over the rows' entries), then the pair counts
+    std::vector<int32_t> trow, tpiece;
+    for (int32_t c = 0; c < n; c++)
+        for (int64_t pc = 0; pc * ACC_PIECE < lens[c]; pc++) {
+            trow.push_back(c);
+            tpiece.push_back((int32_t)pc);
+        }
+    const int64_t n_tasks = (int64_t)trow.size();
+    CSRK_TRY(pstart.alloc((size_t)(pairs + n) * 4));
+    CSRK_TRY(d_trow.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
+    CSRK_TRY(d_tpiece.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
+    CSRK_HIP(hipMemcpyAsync(d_trow.p, trow.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(d_tpiece.p, tpiece.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
+    acc_pairstart_kernel<P><<<(unsigned)ceil_div(n_tasks * WAVE, 256), 256, 0, s>>>(
+        rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, d_trow.as<int32_t>(), d_tpiece.as<int32_t>(), n_tasks,
+        pstart.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    acc_paircount_kernel<<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(pstart.as<int32_t>(), pairs, n, off.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
     CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
@@ -1873,7 +1926,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, int32_t
     CSRK_TRY(ap->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
     acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
         rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
-        ap->vals.as<double>(), ap->idx.as<uint32_t>());
+        pstart.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint32_t>());
     CSRK_LAUNCH_CHECK();
     acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
                                                ap->idx.as<uint32_t>());
@@ -2038,7 +2091,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
             AccPanel *ap = new (std::nothrow) AccPanel();                                                          \
             CSRK_REQUIRE(ap, "out of host memory");                                                                \
             p->acc.push_back(ap);                                                                                  \
-            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, (int32_t)(g1 - g0), gn, s)));                  \
+            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
         }                                                                                                          \
         if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
     } while (0)
