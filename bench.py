@@ -8,8 +8,12 @@ on a 10M x 10M power-law CSR with nnz = 2e8, through the libcsrk C ABI on MI355X
 N = 1 runs in-process; for N > 1 the driver launches one rank per GPU
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`), the matrix is
 row-range partitioned (nnz balanced) with x replicated, and one step = local SpMV + the exchange
-that completes y on every rank (RCCL all-gather by default, `--collective allreduce` for the
-all-reduce north_star names).  The matrix is FIXED as N grows ("scaling": "strong").
+that completes y on every rank.  xGMI is point-to-point and the exchange of the 80 MB y is link-bound, so
+how RCCL drives the links decides the step: before the warm-up the candidates of csr_amd/dist.py (padded
+all-gather; point-to-point sends straight into y; the same pipelined behind the product in 2 / 4 chunks
+per rank) are each timed for 8 steps and the fastest runs the timed region (`multi_gpu.candidates_ms_per_step`;
+`--collective allreduce` forces the all-reduce north_star names, `--collective NAME` any other).
+The matrix is FIXED as N grows ("scaling": "strong").
 
 One JSON line is printed by rank 0:
   value      whole-job GFLOP/s = 2 * nnz / (max-over-ranks wall time per step), inputs resident
@@ -49,7 +53,9 @@ def parse():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the matrix (testing only; INVALID as a result)')
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
-    ap.add_argument('--collective', default='allgather', choices=['allgather', 'allreduce'])
+    ap.add_argument('--collective', default='auto',
+                    choices=['auto', 'allgather', 'allreduce', 'p2p', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
+                    help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
@@ -83,7 +89,7 @@ def main():
 
     from csr_amd import synth
     from csr_amd._lib import lib, check, handle_t, SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR
-    from csr_amd.dist import RowPartitionedSpMV, hip_local_spmv
+    from csr_amd.dist import RowPartitionedSpMV, PipelinedRowPartitionedSpMV, chunk_cuts, hip_local_spmv
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -127,31 +133,119 @@ def main():
                                  ci.data_ptr(), vs.data_ptr(), 2, C.byref(h)))
     algo_code = {'auto': SPMV_AUTO, 'merge': SPMV_MERGE, 'vector': SPMV_VECTOR, 'scalar': SPMV_SCALAR}[args.algo]
     check(lib.csrk_set_spmv_algo(h, algo_code))
-    op = RowPartitionedSpMV(shard['bounds'], rank, world, hip_local_spmv(h.value), dev, mode=args.collective)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the first step runs the plan-less kernel, the second builds the plan (tiers, streams, pack): time both
-    first_ms = plan_ms = None
-    for i in range(args.warmup):
-        if i < 2:
-            torch.cuda.synchronize()
-            t_w = time.perf_counter()
-        op.step(x)
-        if i < 2:
-            torch.cuda.synchronize()
-            if i == 0:
-                first_ms = (time.perf_counter() - t_w) * 1e3
+    # the first call on a handle runs the plan-less kernel, the second builds the plan (tiers, streams, pack):
+    # both timed here, outside the warm-up and the timed region
+    local = hip_local_spmv(h.value)
+    y_tmp = torch.zeros(max(n_loc, 1), dtype=torch.float64, device=dev)
+    once = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        local(x, y_tmp[:n_loc])
+        torch.cuda.synchronize()
+        once.append((time.perf_counter() - t_w) * 1e3)
+    first_ms, plan_ms = once
+    del y_tmp
+
+    # N > 1: the ways of completing y on every rank (csr_amd/dist.py).  Chunked candidates hold one handle per chunk
+    # (views of this rank's arrays, row pointers rebased).
+    keep = []                  # tensors the chunk handles borrow
+
+    def chunk_handles(K):
+        cuts = chunk_cuts(rp, K)
+        hs = []
+        for c in range(K):
+            a, b = cuts[c], cuts[c + 1]
+            e0, e1 = int(rp[a].item()), int(rp[b].item())
+            rpc = (rp[a:b + 1] - rp[a]).contiguous()
+            cic, vsc = ci[e0:e1], vs[e0:e1]
+            keep.extend([rpc, cic, vsc])
+            hc = handle_t(0)
+            check(lib.csrk_create_device(b - a, ncols, e1 - e0, rpc.data_ptr(), int(rpc.dtype == torch.int64),
+                                         cic.data_ptr() if e1 > e0 else ci.data_ptr(),
+                                         vsc.data_ptr() if e1 > e0 else vs.data_ptr(), 2, C.byref(hc)))
+            check(lib.csrk_set_spmv_algo(hc, algo_code))
+            hs.append(hc)
+        table = [None] * world
+        dist.all_gather_object(table, [shard['row_begin'] + c for c in cuts])
+        return hs, table
+
+    def make_op(name):
+        "-> (operator, handles it owns)"
+        if world == 1 or name in ('allgather', 'allreduce'):
+            return RowPartitionedSpMV(shard['bounds'], rank, world, local, dev,
+                                      mode=name if world > 1 else 'allgather'), []
+        exch, _, k = name.partition('-k')
+        K = int(k) if k else 1
+        if K == 1:
+            table = [[shard['bounds'][g], shard['bounds'][g + 1]] for g in range(world)]
+            return PipelinedRowPartitionedSpMV(table, rank, world, [local], dev, exchange=exch), []
+        hs, table = chunk_handles(K)
+        return PipelinedRowPartitionedSpMV(table, rank, world, [hip_local_spmv(hc.value) for hc in hs], dev,
+                                           exchange=exch), hs
+
+    calibration = None
+    if world > 1 and args.collective == 'auto':
+        # measure, don't guess: the exchange is bound by the point-to-point links and by how well RCCL drives them,
+        # which a 1-GPU box cannot show.  Every candidate runs 3 untimed steps (its chunk handles build their
+        # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
+        calibration, best = {}, None
+        for name in ('allgather', 'p2p', 'p2p-k2', 'p2p-k4'):
+            cand, hs, err = None, [], None
+            try:
+                cand, hs = make_op(name)
+                for _ in range(3):
+                    cand.step(x)
+                torch.cuda.synchronize()
+            except Exception as e:                       # e.g. a backend without this exchange (gloo test hook)
+                err = f'{type(e).__name__}: {e}'[:200]
+            bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                calibration[name] = err or 'failed on another rank'
+                for hc in hs:
+                    check(lib.csrk_free(hc))
+                continue
+            barrier()
+            t_c = time.perf_counter()
+            for _ in range(8):
+                cand.step(x)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            calibration[name] = round(float(t.item()) / 8 * 1e3, 4)
+            if best is None or calibration[name] < calibration[best[0]]:
+                if best is not None:
+                    for hc in best[2]:
+                        check(lib.csrk_free(hc))
+                best = (name, cand, hs)
             else:
-                plan_ms = (time.perf_counter() - t_w) * 1e3
+                for hc in hs:
+                    check(lib.csrk_free(hc))
+            del cand
+        if best is None:
+            sys.exit(f'no exchange candidate ran: {calibration}')
+        collective, op, op_handles = best
+    else:
+        collective = args.collective if world > 1 else 'none'
+        if collective == 'auto':
+            collective = 'none'
+        op, op_handles = make_op(collective)
+    # the handle whose kernels are timed for the roofline: the rank's row range, or its first chunk
+    hp = op_handles[0] if op_handles else h
+    for _ in range(args.warmup):
+        op.step(x)
     barrier()
     # kernel event pairs on every 5th step (they cost ~20 us per timed SpMV: 0.713 vs 0.693 ms with / without)
     if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-        check(lib.csrk_spmv_profile_every(h, 5 if args.steps >= 10 else 1))
-        check(lib.csrk_spmv_profile_begin(h, args.steps))
+        check(lib.csrk_spmv_profile_every(hp, 5 if args.steps >= 10 else 1))
+        check(lib.csrk_spmv_profile_begin(hp, args.steps))
     op.timing = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,21 +254,37 @@ def main():
     elapsed = time.perf_counter() - t0
     n_rec, k_ms2 = C.c_int(0), (C.c_float * 3)(0.0, 0.0, 0.0)
     if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-        check(lib.csrk_spmv_profile_end(h, C.byref(n_rec), k_ms2))
+        check(lib.csrk_spmv_profile_end(hp, C.byref(n_rec), k_ms2))
     compute_ms = None
+    exchange_ok = None
     if world > 1:
+        # every rank must hold the same complete y: the wrapping int64 sum of the bit patterns of a rank's own slice,
+        # summed over ranks, equals that of the whole vector on every rank (order-independent, exact)
+        own = y[shard['row_begin']:shard['row_end']].view(torch.int64).sum().reshape(1)
+        tot = own.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        agree = (y.view(torch.int64).sum().reshape(1) == tot).to(torch.float64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(agree.item() > 0)
+        if not exchange_ok:
+            sys.exit(f'EXCHANGE FAILURE: rank {rank} does not hold the complete y after {collective}')
         t = torch.tensor([elapsed, op.compute_ms()], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_ms = float(t[0].item()), float(t[1].item())
 
-    algo_name = lib.csrk_spmv_algo_name(h).decode()
+    algo_name = lib.csrk_spmv_algo_name(hp).decode()
     n_tiles, tile_items = C.c_int64(0), C.c_int32(0)
-    check(lib.csrk_spmv_plan_info(h, C.byref(n_tiles), C.byref(tile_items)))
+    check(lib.csrk_spmv_plan_info(hp, C.byref(n_tiles), C.byref(tile_items)))
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
     st = (C.c_int64 * 24)()
-    check(lib.csrk_spmv_plan_stats(h, st, 24))
+    check(lib.csrk_spmv_plan_stats(hp, st, 24))
+    if op_handles:
+        # the roofline block describes the first chunk's handle (the kernels that were timed)
+        i_r, i_c, i_n, i_p, i_v = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int(0), C.c_int(0)
+        check(lib.csrk_info(hp, C.byref(i_r), C.byref(i_c), C.byref(i_n), C.byref(i_p), C.byref(i_v)))
+        n_loc, nnz_loc = i_r.value, i_n.value
     n_heavy, nnz_path = int(st[2]), int(st[3])
     # Algorithmic bytes of ONE launch of each streaming kernel on this rank:
     # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer and
@@ -230,7 +340,7 @@ def main():
                    'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
                    'hot_column_cache': {'columns': int(st[16]), 'entry_share_sampled': round(int(st[17]) / 1e6, 4), 'slots': int(st[19])},
                    'parallelism': f'row-partition x{world}',
-                   'collective': args.collective if world > 1 else 'none'},
+                   'collective': collective},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),
         'roofline': roofline,
         'gen_seconds': round(t_gen, 2),
@@ -241,7 +351,8 @@ def main():
     }
     if compute_ms is not None:
         # per step: the slowest rank's local SpMV (device events) and what the exchange adds on top
-        out['multi_gpu'] = {'local_spmv_ms_max_over_ranks': round(compute_ms, 4),
+        out['multi_gpu'] = {'exchange': collective, 'y_complete_and_identical_on_every_rank': exchange_ok, 'candidates_ms_per_step': calibration,
+                            'local_spmv_ms_max_over_ranks': round(compute_ms, 4),
                             'exchange_ms': round(ms_per_step - compute_ms, 4),
                             'kernel_only_gflops': round(2.0 * nnz / (compute_ms * 1e-3) / 1e9, 1) if compute_ms > 0 else None}
 
@@ -274,6 +385,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    for hc in op_handles:
+        check(lib.csrk_free(hc))
     check(lib.csrk_free(h))
     if world > 1:
         dist.destroy_process_group()

@@ -17,6 +17,9 @@ step of the path:
              zeroed full-length y and the ranks sum.  Same result (the slices are disjoint, so
              every sum has one non-zero term and is exact), about twice the bytes per link.
 
+PipelinedRowPartitionedSpMV: point-to-point exchange straight into y (no padding, no concatenation) and/or the
+exchange pipelined behind the product (K chunks per rank).
+
 torch is plumbing here (device buffers + the collective); the product kernels run behind
 `local_spmv`, a callable that writes y[r0:r1] = A[r0:r1, :] x into the buffer it is given.
 """
@@ -86,6 +89,114 @@ class RowPartitionedSpMV:
         self._local(x, self.y[self.r0:self.r1])
         dist.all_reduce(self.y, op=dist.ReduceOp.SUM, group=self.group)
         return self.y
+
+
+class PipelinedRowPartitionedSpMV:
+    """
+    The same product with the exchange (a) point-to-point and (b) pipelined behind the product.
+
+    (a) exchange='p2p': every rank computes its rows straight into its slice of y and posts one send of that slice
+        to each peer and one receive per peer into the peer's slice of y (dist.batch_isend_irecv: one grouped
+        RCCL launch).  xGMI is a full mesh of point-to-point links, so the 7 slices leave over 7 links at once,
+        nothing is padded and nothing is copied afterwards (the padded all-gather needs a concatenation kernel:
+        80 MB read + 80 MB written per step).  exchange='allgather' keeps the padded all-gather per chunk.
+    (b) every rank's row range is cut into K chunks (each a handle of its own); chunk c is exchanged
+        asynchronously, on the collective's stream, while chunk c + 1 is being multiplied.  The exchange of the
+        80 MB y is link-bound; what can be hidden is the product, behind it.
+
+    Same result bit for bit (the slices are disjoint and every row is computed by the same kernels' rules).
+    sub_bounds[g] = K + 1 absolute row indices of rank g's chunks (every rank passes the same table);
+    local_spmvs[c](x, out) computes this rank's chunk c into `out`.
+    """
+
+    def __init__(self, sub_bounds, rank, world, local_spmvs, device, exchange='p2p', group=None):
+        K = len(sub_bounds[0]) - 1
+        assert K >= 1 and len(sub_bounds) == world and all(len(b) == K + 1 for b in sub_bounds)
+        assert len(local_spmvs) == K and exchange in ('p2p', 'allgather')
+        for g in range(world - 1):
+            assert sub_bounds[g][-1] == sub_bounds[g + 1][0]
+        self.sub = [[int(v) for v in b] for b in sub_bounds]
+        assert self.sub[0][0] == 0 and all(b[c] <= b[c + 1] for b in self.sub for c in range(K))
+        self.rank, self.world, self.K, self.group, self.exchange = rank, world, K, group, exchange
+        self.local_spmvs = local_spmvs
+        self.nrows = self.sub[-1][-1]
+        self.y = torch.zeros(self.nrows, dtype=torch.float64, device=device)
+        self.timing = False
+        self._ev = []
+        self.lens = [[self.sub[g][c + 1] - self.sub[g][c] for c in range(K)] for g in range(world)]
+        if world > 1 and exchange == 'p2p':
+            # chunk c: my slice to every peer, every peer's slice c into its place in y; peers in ring order from
+            # my own position so that the sends of one chunk do not all start at rank 0's link
+            self.ops = []
+            for c in range(K):
+                ops = []
+                mine = self.y[self.sub[rank][c]:self.sub[rank][c + 1]]
+                for d in range(1, world):
+                    to, frm = (rank + d) % world, (rank - d) % world
+                    if self.lens[rank][c]:
+                        ops.append(dist.P2POp(dist.isend, mine, to, group))
+                    if self.lens[frm][c]:
+                        ops.append(dist.P2POp(dist.irecv, self.y[self.sub[frm][c]:self.sub[frm][c + 1]], frm, group))
+                self.ops.append(ops)
+        elif world > 1:
+            self.maxlen = [max(max(self.lens[g][c] for g in range(world)), 1) for c in range(K)]
+            self.loc = [torch.zeros(self.maxlen[c], dtype=torch.float64, device=device) for c in range(K)]
+            self.gath = [torch.zeros(world * self.maxlen[c], dtype=torch.float64, device=device) for c in range(K)]
+            # y = the slices in (rank, chunk) order
+            self.pieces = [self.gath[c][g * self.maxlen[c]:g * self.maxlen[c] + self.lens[g][c]]
+                           for g in range(world) for c in range(K) if self.lens[g][c]]
+
+    def _local(self, c, x, out):
+        if self.timing and out.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.local_spmvs[c](x, out)
+            e1.record()
+            self._ev.append((e0, e1))
+        else:
+            self.local_spmvs[c](x, out)
+
+    def compute_ms(self):
+        "mean device time per step of the local products (all chunks) over the steps timed so far"
+        if not self._ev:
+            return 0.0
+        ms = sum(a.elapsed_time(b) for a, b in self._ev) * self.K / len(self._ev)
+        self._ev = []
+        return ms
+
+    def step(self, x):
+        "y = A x, complete on every rank; returns the (reused) y tensor"
+        r, works = self.rank, []
+        for c in range(self.K):
+            if self.world == 1 or self.exchange == 'p2p':
+                self._local(c, x, self.y[self.sub[r][c]:self.sub[r][c + 1]])
+                if self.world > 1 and self.ops[c]:
+                    works += dist.batch_isend_irecv(self.ops[c])
+            else:
+                self._local(c, x, self.loc[c][:self.lens[r][c]])
+                works.append(dist.all_gather_into_tensor(self.gath[c], self.loc[c], group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if self.world > 1 and self.exchange == 'allgather' and self.pieces:
+            torch.cat(self.pieces, out=self.y)
+        return self.y
+
+
+def chunk_cuts(rowptrs, K):
+    """
+    K + 1 local row indices cutting a rank's row range into K chunks balanced by nnz - the same rule as the rank
+    boundaries (searchsorted on the row pointers: the primitive of _shard_rows, csr/csr.py:609).
+    rowptrs: this rank's rebased row pointers (tensor or array, rowptrs[0] == 0).
+    """
+    rp = torch.as_tensor(rowptrs)
+    n = rp.numel() - 1
+    total = int(rp[-1])
+    tg = torch.tensor([total * c // K for c in range(1, K)], dtype=rp.dtype, device=rp.device)
+    mid = torch.searchsorted(rp, tg).tolist() if K > 1 else []
+    cuts = [0] + [min(max(int(m), 0), n) for m in mid] + [n]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
 
 
 def hip_local_spmv(handle):

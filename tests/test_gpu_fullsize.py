@@ -173,7 +173,8 @@ def test_transpose_config5_full_size():
         check(lib.csrk_trim_cache())
 
 
-def test_bench_two_ranks_plumbing():
+@pytest.mark.parametrize('collective', ['auto', 'p2p-k2'])
+def test_bench_two_ranks_plumbing(collective):
     """
     bench.py's N > 1 path end to end on ONE GPU: two ranks share cuda:0 over gloo (RCCL refuses two ranks on
     a device; BENCH_TEST_SHARE_GPU is the bench's own test hook).  Covers shard generation, the per-rank
@@ -192,10 +193,16 @@ def test_bench_two_ranks_plumbing():
     env = dict(os.environ, BENCH_TEST_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--scale', '0.05']
+           '--scale', '0.05', '--collective', collective]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'strong'
     assert d['config']['parallelism'] == 'row-partition x2' and 'multi_gpu' in d
+    assert d['multi_gpu']['y_complete_and_identical_on_every_rank'] is True
+    if collective == 'auto':
+        assert d['multi_gpu']['exchange'] in d['multi_gpu']['candidates_ms_per_step']
+    else:
+        # chunk handles (views of the rank's arrays) + point-to-point exchange straight into y
+        assert d['multi_gpu']['exchange'] == collective
