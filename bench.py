@@ -278,8 +278,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 24)()
-    check(lib.csrk_spmv_plan_stats(hp, st, 24))
+    st = (C.c_int64 * 25)()
+    check(lib.csrk_spmv_plan_stats(hp, st, 25))
     if op_handles:
         # the roofline block describes the first chunk's handle (the kernels that were timed)
         i_r, i_c, i_n, i_p, i_v = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int(0), C.c_int(0)
@@ -339,6 +339,7 @@ def main():
                    'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9])},
                    'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
                    'hot_column_cache': {'columns': int(st[16]), 'entry_share_sampled': round(int(st[17]) / 1e6, 4), 'slots': int(st[19])},
+                   'cold_staged_entries': int(st[24]),
                    'parallelism': f'row-partition x{world}',
                    'collective': collective},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),

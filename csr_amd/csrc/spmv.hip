@@ -98,6 +98,11 @@ struct LightStream {
     int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
     unsigned grid = 0;
     DevBuf vals, idx, rowids, tile_base, carry_idx, carry_row, carry_val;
+    // cold staging (build_cold_stage): the x values of the stream's unpacked columns, copied per call into the
+    // order the stream reads them
+    int64_t n_cold = 0;
+    int32_t n_stage_blk = 0, stage_w = 0;
+    DevBuf xg, a_col, a_dst, blk_start;
 };
 
 struct SpmvPlan {
@@ -2286,6 +2291,217 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     return CSRK_OK;
 }
 
+// ---- cold staging ----------------------------------------------------------------------------------------------
+// A gather of x[col] that misses L2 moves a 128-B line over the fabric for 8 useful bytes, and on a power-law
+// matrix the light stream's unpacked ("cold") columns nearly all miss: 1.4 of the 2.2 GB the kernel moved.  The
+// whole SpMV runs at the fabric's rate, so those bytes are its time.  Instead, before each light-stream launch one
+// pass copies the cold entries' x values into `xg`, in an order that is cheap on BOTH sides:
+//   * the stream side reads xg[pos]; the positions of the cold entries of one workgroup round (LS_STAGE_TILES
+//     consecutive tiles = the 16 wavefronts of a workgroup, one tile each) form one contiguous range of xg, so
+//     every line of xg is fetched by one workgroup within one round and used completely;
+//   * the copy side (ls_stage_kernel) walks the cold entries sorted by (column block, position): one workgroup per
+//     block of columns, whose x window it holds in LDS (x crosses the fabric once, coalesced), and its
+//     writes land in runs: inside a round the positions are ordered by column block, so the entries of one
+//     (round, block) bucket are neighbours on both sides and neighbouring blocks fill neighbouring pieces of a line.
+// A cold entry's index word then holds its position in xg instead of its column (flags unchanged) and the stream
+// kernel is given xg as the base of its cold gathers: the kernel itself does not change, nor does any result bit.
+constexpr int LS_STAGE_TILES = LS_THREADS / WAVE;     // tiles per workgroup round
+constexpr int LS_STAGE_WMAX = 9984;                   // columns per block at most: a 78-KiB window of x in LDS, two per CU
+constexpr int LS_STAGE_THREADS = 1024, LS_STAGE_IPT = 8;
+
+__device__ __forceinline__ bool ls_is_cold(uint32_t ix) { return !(ix & LS_HOT_BIT) && (ix & LS_COL_MASK) != LS_PAD; }
+
+// per index word: count into the (round, block) bucket; the old count is the entry's place inside the bucket
+__global__ __launch_bounds__(256) void ls_cold_count_kernel(const uint32_t *__restrict__ sidx, int64_t n_words, int32_t nblk, int32_t W,
+                                                           int32_t *__restrict__ cnt, int32_t *__restrict__ off)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t ix = sidx[w];
+    if (!ls_is_cold(ix)) return;
+    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const int32_t b = (int32_t)((ix & LS_COL_MASK) / (uint32_t)W);
+    off[w] = atomicAdd(&cnt[r * nblk + b], 1);
+}
+
+__global__ void ls_cold_transpose_kernel(const int32_t *__restrict__ cnt, int32_t nround, int32_t nblk, int32_t *__restrict__ cntT)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nround * nblk) return;
+    const int64_t r = i / nblk, b = i % nblk;
+    cntT[b * nround + r] = cnt[i];
+}
+
+// position in xg = bucket base in (round, block) order + place; position in the copy list = bucket base in
+// (block, round) order + place
+__global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
+                                                           int32_t nblk, int32_t W, const int32_t *__restrict__ base_rb,
+                                                           const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
+                                                           int32_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t ix = sidx[w];
+    if (!ls_is_cold(ix)) return;
+    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const uint32_t c = ix & LS_COL_MASK;
+    const int32_t b = (int32_t)(c / (uint32_t)W);
+    const int32_t pos = base_rb[r * nblk + b] + off[w];
+    const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
+    a_col[pa] = (int32_t)c;
+    a_dst[pa] = pos;
+    sidx[w] = (ix & LS_START_BIT) | (uint32_t)pos;
+}
+
+// xg[a_dst[k]] = x[a_col[k]] for the entries of one column block: the block's window of x is copied into LDS with
+// coalesced loads and the gathers are LDS reads (a gather that misses L1 costs the CU ~4 clocks per lane to pull its
+// 128-B line in, wherever the line comes from: as L2 gathers this pass took 78 us for 9 * 10^6 entries).
+// Workgroup i takes block (i % 8) * (blocks / 8) + i / 8: the workgroups of one XCD (i % 8) walk consecutive blocks,
+// so the short runs that neighbouring blocks write into one line of xg meet in one L2 before they are written back.
+__global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double *__restrict__ x, int32_t ncols, int32_t W,
+                                                                   const int32_t *__restrict__ a_col,
+                                                                   const int32_t *__restrict__ a_dst,
+                                                                   const int32_t *__restrict__ blk_start, int32_t nblk,
+                                                                   double *__restrict__ xg)
+{
+    extern __shared__ __align__(16) double s_x[];
+    const int32_t per = (nblk + 7) / 8;
+    const int32_t b = (int32_t)(blockIdx.x % 8) * per + (int32_t)(blockIdx.x / 8);
+    if (b >= nblk) return;
+    const int32_t k0 = blk_start[b], k1 = blk_start[b + 1];
+    if (k0 == k1) return;
+    const int64_t c0 = (int64_t)b * W;
+    // the first batch of (column, position) pairs is requested before the window, so both are in flight together
+    int32_t c[LS_STAGE_IPT], d[LS_STAGE_IPT];
+#pragma unroll
+    for (int q = 0; q < LS_STAGE_IPT; q++) {
+        const int32_t k = k0 + (int32_t)threadIdx.x + q * LS_STAGE_THREADS;
+        c[q] = k < k1 ? __builtin_nontemporal_load(a_col + k) : -1;
+        d[q] = k < k1 ? __builtin_nontemporal_load(a_dst + k) : 0;
+    }
+    for (int i = threadIdx.x; i < W; i += LS_STAGE_THREADS) s_x[i] = c0 + i < ncols ? x[c0 + i] : 0.0;
+    __syncthreads();
+    for (int32_t kb = k0; kb < k1; kb += LS_STAGE_THREADS * LS_STAGE_IPT) {
+        int32_t cn[LS_STAGE_IPT], dn[LS_STAGE_IPT];
+        const int32_t kn = kb + LS_STAGE_THREADS * LS_STAGE_IPT;
+        if (kn < k1) {
+#pragma unroll
+            for (int q = 0; q < LS_STAGE_IPT; q++) {
+                const int32_t k = kn + (int32_t)threadIdx.x + q * LS_STAGE_THREADS;
+                cn[q] = k < k1 ? __builtin_nontemporal_load(a_col + k) : -1;
+                dn[q] = k < k1 ? __builtin_nontemporal_load(a_dst + k) : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < LS_STAGE_IPT; q++)
+            if (c[q] >= 0) xg[d[q]] = s_x[c[q] - (int32_t)c0];
+        if (kn < k1) {
+#pragma unroll
+            for (int q = 0; q < LS_STAGE_IPT; q++) c[q] = cn[q], d[q] = dn[q];
+        }
+    }
+}
+
+__global__ void ls_stage_starts_kernel(const int32_t *__restrict__ base_br, int32_t nround, int32_t nblk, int32_t *__restrict__ blk_start)
+{
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nblk) blk_start[b] = base_br[(int64_t)b * nround];      // base_br has nround * nblk + 1 entries
+}
+
+// The packed columns ride along: slot k of the pack is entry (column hot_cols[k], position n_cold + k) of a virtual
+// last round, so xh = xg + n_cold is filled by the same pass and hot_pack_kernel (10^5.6 gathers of 128 B) goes.
+__global__ void ls_pack_count_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t W, int32_t *__restrict__ cnt_last,
+                                     int32_t *__restrict__ offp)
+{
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_hot) offp[k] = atomicAdd(&cnt_last[hot_cols[k] / W], 1);
+}
+
+__global__ void ls_pack_place_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t W, int32_t nround_all,
+                                     const int32_t *__restrict__ base_br, const int32_t *__restrict__ offp, int32_t n_cold,
+                                     int32_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
+{
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_hot) return;
+    const int32_t c = hot_cols[k];
+    const int32_t pa = base_br[(int64_t)(c / W) * nround_all + (nround_all - 1)] + offp[k];
+    a_col[pa] = c;
+    a_dst[pa] = n_cold + k;
+}
+
+static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols, int32_t n_hot, hipStream_t s)
+{
+    ls->n_cold = 0;
+    const char *env = getenv("CSRK_LS_STAGE");
+    if (env && env[0] == '0') return CSRK_OK;
+    const int64_t n_words = ls->n_tiles * ACC_TILE;
+    const int64_t nround_ls = ceil_div(ls->n_tiles, LS_STAGE_TILES);
+    const int64_t nround = nround_ls + 1;      // + the virtual round of the packed columns
+    // a number of column blocks that fills the chip a whole number of times (two workgroups per CU), each window
+    // at most LS_STAGE_WMAX columns
+    int cus = 0;
+    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    const int64_t wave_of_wgs = 2 * (int64_t)(cus > 0 ? cus : 256);
+    const int64_t nblk_goal = wave_of_wgs * ceil_div((int64_t)m->ncols, wave_of_wgs * LS_STAGE_WMAX);
+    const int64_t W = ceil_div(ceil_div((int64_t)m->ncols, nblk_goal), 16) * 16;
+    const int64_t nblk = ceil_div((int64_t)m->ncols, W);
+    const int64_t nb = nround * nblk;
+    if (nb < 1 || nb > (int64_t)1 << 26 || nround > INT32_MAX) return CSRK_OK;
+    size_t mfree = 0, mtotal = 0;
+    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if ((size_t)n_words * 20 + (size_t)nb * 16 + (64u << 20) > mfree) return CSRK_OK;
+    DevBuf cnt, cntT, off, offp;
+    CSRK_TRY(offp.alloc((size_t)n_hot * 4));
+    CSRK_TRY(cnt.alloc((size_t)(nb + 1) * 4));
+    CSRK_TRY(cntT.alloc((size_t)(nb + 1) * 4));
+    CSRK_TRY(off.alloc((size_t)n_words * 4));
+    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nb + 1) * 4, s));
+    CSRK_HIP(hipMemsetAsync(cntT.p, 0, (size_t)(nb + 1) * 4, s));
+    const unsigned gw = (unsigned)ceil_div(n_words, 256);
+    ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
+                                           off.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
+                                                                       cnt.as<int32_t>() + nround_ls * nblk, offp.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    ls_cold_transpose_kernel<<<(unsigned)ceil_div(nb, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
+                                                                       cntT.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    // the counts are 32-bit: total them in 64 bits before trusting the 32-bit scans
+    DevBuf tot;
+    CSRK_TRY(tot.alloc((size_t)(nb + 1) * 8));
+    CSRK_TRY(exclusive_scan_i32_to_i64(cnt.as<int32_t>(), tot.as<int64_t>(), nb + 1, s));
+    int64_t n_cold = 0;      // = where the virtual round starts
+    CSRK_HIP(hipMemcpyAsync(&n_cold, tot.as<int64_t>() + nround_ls * nblk, 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    const int64_t n_all = n_cold + n_hot;
+    // worth a pass of its own only when the cold columns cannot live in L2 anyway and there are enough of them
+    if (n_cold < 1 || n_all >= (int64_t)LS_PAD || (!(env && env[0] == '1') && n_cold * 16 < n_words)) return CSRK_OK;
+    CSRK_TRY(exclusive_scan_i32(cnt.as<int32_t>(), cnt.as<int32_t>(), nb + 1, s));
+    CSRK_TRY(exclusive_scan_i32(cntT.as<int32_t>(), cntT.as<int32_t>(), nb + 1, s));
+    CSRK_TRY(ls->xg.alloc((size_t)n_all * 8));
+    CSRK_TRY(ls->a_col.alloc((size_t)n_all * 4));
+    CSRK_TRY(ls->a_dst.alloc((size_t)n_all * 4));
+    ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
+                                           cntT.as<int32_t>(), off.as<int32_t>(), ls->a_col.as<int32_t>(),
+                                           ls->a_dst.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
+                                                                       cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
+                                                                       ls->a_col.as<int32_t>(), ls->a_dst.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(ls->blk_start.alloc((size_t)(nblk + 1) * 4));
+    ls_stage_starts_kernel<<<(unsigned)ceil_div(nblk + 1, 256), 256, 0, s>>>(cntT.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
+                                                                            ls->blk_start.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    ls->n_stage_blk = (int32_t)nblk;
+    ls->stage_w = (int32_t)W;
+    CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
+    CSRK_HIP(hipStreamSynchronize(s));      // the temporaries are freed on return
+    ls->n_cold = n_cold;
+    return CSRK_OK;
+}
+
 // Copy the rows of the row-major path (the light view, or the whole matrix when nothing was cut out) into
 // the light stream.  Built with the lazy plan.  Skipped (the tile kernel stays in charge) when ncols needs
 // the two flag bits, when the copy does not fit in device memory, or with CSRK_SPMV_STREAM=0.
@@ -2317,6 +2533,7 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     sg.ent0[0] = 0;
     CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles, nullptr, m->nrows,
                                   slot_map, s)));
+    if (p->ls.on && p->n_hot) CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
     return CSRK_OK;
 }
 
@@ -2595,7 +2812,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_HIP(hipEventRecord(p->ev_fork, s));
             CSRK_HIP(hipStreamWaitEvent(sa, p->ev_fork, 0));
         }
-        if (p->n_hot) {
+        if (p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
             hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, sa>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
                                                                              p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
@@ -2672,9 +2889,19 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             if (p->ls.on) {
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
+                const double *x_cold = d_x, *x_pack = p->xh.as<double>();
+                if (p->ls.n_cold) {      // cold staging: the unpacked columns' x values, in the stream's order
+                    const unsigned gs = (unsigned)(ceil_div(p->ls.n_stage_blk, 8) * 8);
+                    ls_stage_kernel<<<gs, LS_STAGE_THREADS, (size_t)p->ls.stage_w * 8, s>>>(d_x, m->ncols, p->ls.stage_w, p->ls.a_col.as<int32_t>(),
+                                                                   p->ls.a_dst.as<int32_t>(), p->ls.blk_start.as<int32_t>(),
+                                                                   p->ls.n_stage_blk, p->ls.xg.as<double>());
+                    CSRK_LAUNCH_CHECK();
+                    x_cold = p->ls.xg.as<double>();
+                    x_pack = x_cold + p->ls.n_cold;
+                }
+                spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
                     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
-                    p->ls.tile_base.as<int32_t>(), (const int32_t *)nullptr, d_x, p->xh.as<double>(), p->n_hot_lds,
+                    p->ls.tile_base.as<int32_t>(), (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds,
                     p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,
                     p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
                 kl.stop();
@@ -2974,15 +3201,15 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
         a_nb = ap->nb;
     }
     const bool af = !p->acc.empty();
-    const int64_t v[24] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    const int64_t v[25] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
                            af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
-                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid};
-    for (int i = 0; i < n && i < 24; i++) out[i] = v[i];
+                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold};
+    for (int i = 0; i < n && i < 25; i++) out[i] = v[i];
     return CSRK_OK;
 }
 
