@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch (GPU box): cold staging on/off against pack sizes
+# scratch (GPU box): cold staging on/off, order of the staging pass, pack sizes
 O=gpurun_out/stage; mkdir -p $O
 run() { tag=$1; shift; env "$@" python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/$tag.log 2>&1; python - <<PY
 import json
@@ -11,8 +11,8 @@ except Exception as e:
 PY
 }
 run off CSRK_LS_STAGE=0
-run on512k CSRK_LS_STAGE=1
-
-
-run on256k CSRK_LS_STAGE=1 CSRK_HOT_SLOTS=262144
-
+run first CSRK_LS_STAGE=1
+run late CSRK_LS_STAGE=1 CSRK_LS_STAGE_FIRST=0
+run first1m CSRK_LS_STAGE=1 CSRK_HOT_SLOTS=1048576
+run off2 CSRK_LS_STAGE=0
+run first2 CSRK_LS_STAGE=1
