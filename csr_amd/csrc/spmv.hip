@@ -2405,7 +2405,7 @@ __global__ void ls_cold_transpose_kernel(const int32_t *__restrict__ cnt, int32_
 __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
                                                            int32_t nblk, int32_t W, const int32_t *__restrict__ base_rb,
                                                            const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
-                                                           int32_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
+                                                           uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
@@ -2416,7 +2416,7 @@ __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict
     const int32_t b = (int32_t)(c / (uint32_t)W);
     const int32_t pos = base_rb[r * nblk + b] + off[w];
     const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
-    a_col[pa] = (int32_t)c;
+    a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);      // offset inside the block's window
     a_dst[pa] = pos;
     sidx[w] = (ix & LS_START_BIT) | (uint32_t)pos;
 }
@@ -2427,7 +2427,7 @@ __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict
 // Workgroup i takes block (i % 8) * (blocks / 8) + i / 8: the workgroups of one XCD (i % 8) walk consecutive blocks,
 // so the short runs that neighbouring blocks write into one line of xg meet in one L2 before they are written back.
 __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double *__restrict__ x, int32_t ncols, int32_t W,
-                                                                   const int32_t *__restrict__ a_col,
+                                                                   const uint16_t *__restrict__ a_col,
                                                                    const int32_t *__restrict__ a_dst,
                                                                    const int32_t *__restrict__ blk_start, int32_t nblk,
                                                                    double *__restrict__ xg)
@@ -2444,7 +2444,7 @@ __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double
 #pragma unroll
     for (int q = 0; q < LS_STAGE_IPT; q++) {
         const int32_t k = k0 + (int32_t)threadIdx.x + q * LS_STAGE_THREADS;
-        c[q] = k < k1 ? __builtin_nontemporal_load(a_col + k) : -1;
+        c[q] = k < k1 ? (int32_t)__builtin_nontemporal_load(a_col + k) : -1;
         d[q] = k < k1 ? __builtin_nontemporal_load(a_dst + k) : 0;
     }
     for (int i = threadIdx.x; i < W; i += LS_STAGE_THREADS) s_x[i] = c0 + i < ncols ? x[c0 + i] : 0.0;
@@ -2456,13 +2456,13 @@ __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double
 #pragma unroll
             for (int q = 0; q < LS_STAGE_IPT; q++) {
                 const int32_t k = kn + (int32_t)threadIdx.x + q * LS_STAGE_THREADS;
-                cn[q] = k < k1 ? __builtin_nontemporal_load(a_col + k) : -1;
+                cn[q] = k < k1 ? (int32_t)__builtin_nontemporal_load(a_col + k) : -1;
                 dn[q] = k < k1 ? __builtin_nontemporal_load(a_dst + k) : 0;
             }
         }
 #pragma unroll
         for (int q = 0; q < LS_STAGE_IPT; q++)
-            if (c[q] >= 0) xg[d[q]] = s_x[c[q] - (int32_t)c0];
+            if (c[q] >= 0) xg[d[q]] = s_x[c[q]];
         if (kn < k1) {
 #pragma unroll
             for (int q = 0; q < LS_STAGE_IPT; q++) c[q] = cn[q], d[q] = dn[q];
@@ -2487,13 +2487,13 @@ __global__ void ls_pack_count_kernel(const int32_t *__restrict__ hot_cols, int32
 
 __global__ void ls_pack_place_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t W, int32_t nround_all,
                                      const int32_t *__restrict__ base_br, const int32_t *__restrict__ offp, int32_t n_cold,
-                                     int32_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
+                                     uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
 {
     const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_hot) return;
     const int32_t c = hot_cols[k];
     const int32_t pa = base_br[(int64_t)(c / W) * nround_all + (nround_all - 1)] + offp[k];
-    a_col[pa] = c;
+    a_col[pa] = (uint16_t)(c % W);
     a_dst[pa] = n_cold + k;
 }
 
@@ -2548,15 +2548,15 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     CSRK_TRY(exclusive_scan_i32(cnt.as<int32_t>(), cnt.as<int32_t>(), nb + 1, s));
     CSRK_TRY(exclusive_scan_i32(cntT.as<int32_t>(), cntT.as<int32_t>(), nb + 1, s));
     CSRK_TRY(ls->xg.alloc((size_t)n_all * 8));
-    CSRK_TRY(ls->a_col.alloc((size_t)n_all * 4));
+    CSRK_TRY(ls->a_col.alloc((size_t)n_all * 2));
     CSRK_TRY(ls->a_dst.alloc((size_t)n_all * 4));
     ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
-                                           cntT.as<int32_t>(), off.as<int32_t>(), ls->a_col.as<int32_t>(),
+                                           cntT.as<int32_t>(), off.as<int32_t>(), ls->a_col.as<uint16_t>(),
                                            ls->a_dst.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
                                                                        cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
-                                                                       ls->a_col.as<int32_t>(), ls->a_dst.as<int32_t>());
+                                                                       ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->blk_start.alloc((size_t)(nblk + 1) * 4));
     ls_stage_starts_kernel<<<(unsigned)ceil_div(nblk + 1, 256), 256, 0, s>>>(cntT.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
@@ -2887,7 +2887,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             KernelTimer ks(p, s, 3);
             const unsigned gs = (unsigned)(ceil_div(p->ls.n_stage_blk, 8) * 8);
             ls_stage_kernel<<<gs, LS_STAGE_THREADS, (size_t)p->ls.stage_w * 8, s>>>(
-                d_x, m->ncols, p->ls.stage_w, p->ls.a_col.as<int32_t>(), p->ls.a_dst.as<int32_t>(),
+                d_x, m->ncols, p->ls.stage_w, p->ls.a_col.as<uint16_t>(), p->ls.a_dst.as<int32_t>(),
                 p->ls.blk_start.as<int32_t>(), p->ls.n_stage_blk, p->ls.xg.as<double>());
             ks.stop();
             CSRK_LAUNCH_CHECK();

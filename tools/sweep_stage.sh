@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch (GPU box): cold staging on/off, order of the staging pass, pack sizes
+# scratch (GPU box): env sweeps of bench.py
 O=gpurun_out/stage; mkdir -p $O
 run() { tag=$1; shift; env "$@" python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/$tag.log 2>&1; python - <<PY
 import json
@@ -10,9 +10,8 @@ except Exception as e:
     print("$tag FAILED", e); print(open("$O/$tag.log").read()[-1500:])
 PY
 }
-run off CSRK_LS_STAGE=0
-run first CSRK_LS_STAGE=1
-run late CSRK_LS_STAGE=1 CSRK_LS_STAGE_FIRST=0
-run first1m CSRK_LS_STAGE=1 CSRK_HOT_SLOTS=1048576
-run off2 CSRK_LS_STAGE=0
-run first2 CSRK_LS_STAGE=1
+run base A=1
+run lsuc CSRK_LS_UC=1
+run accuc CSRK_ACC_UC=1
+run bothuc CSRK_LS_UC=1 CSRK_ACC_UC=1
+run lsuc1m CSRK_LS_UC=1 CSRK_HOT_SLOTS=1048576
