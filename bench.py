@@ -18,8 +18,8 @@ The matrix is FIXED as N grows ("scaling": "strong").
 One JSON line is printed by rank 0:
   value      whole-job GFLOP/s = 2 * nnz / (max-over-ranks wall time per step), inputs resident
              in HBM before the timed region;
-  roofline   the slowest of the SpMV's streaming kernels (light merge-path kernel, panel tier 0,
-             panel tier 1: DESIGN.md section 4): that kernel's own algorithmic bytes per launch
+  roofline   the slowest of the SpMV's streaming kernels (light stream with its staging pass, accumulator
+             tier 0, panel tier 1: DESIGN.md section 4): that kernel's own algorithmic bytes per launch
              (12 B per entry it processes + its row pointers / partials + x once) divided by its
              mean duration, measured live with hipEvent pairs recorded around that kernel on its
              launch stream during every 5th timed step (csrk_spmv_profile_every/begin/end: a pair
@@ -292,12 +292,19 @@ def main():
     # (column block, row) pair of its tier; each kernel reads x once.
     # st[20]: the short rows run as the light stream (else the merge-path tile kernel); st[18]: tier 0 in
     # accumulator form (st[9] = its rows; one row pointer + one y entry each) or in pair form (st[9] = pairs).
-    light = {'kernel': 'spmv_lstream_kernel', 'role': 'short rows: one wavefront per 512-entry tile of the light stream'} \
-        if int(st[20]) else {'kernel': f'spmv_{algo_name}_kernel', 'role': 'merge-path tiles'}
+    if int(st[20]) and int(st[24]):
+        # timed together: the staging pass exists only to feed the stream kernel (csrk_spmv_profile_end adds them)
+        light = {'kernel': 'ls_stage_kernel + spmv_lstream_kernel',
+                 'role': 'short rows: cold-staging pass (x of the unpacked and packed columns copied into stream order '
+                         'through LDS windows) + one wavefront per 512-entry tile of the light stream'}
+    elif int(st[20]):
+        light = {'kernel': 'spmv_lstream_kernel', 'role': 'short rows: one wavefront per 512-entry tile of the light stream'}
+    else:
+        light = {'kernel': f'spmv_{algo_name}_kernel', 'role': 'merge-path tiles'}
     kernels = [dict(light, ms=k_ms2[0], entries=nnz_path,
                     algorithmic_bytes=nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8)]
     if int(st[10]):
-        t0 = {'kernel': 'spmv_acc_kernel', 'role': 'tier 0 (longest rows): x window + one accumulator per row in LDS'} \
+        t0 = {'kernel': 'spmv_acc_kernel', 'role': 'tier 0 (longest rows): x window + one accumulator per row in LDS, 10-B entries (f64 value + 16-bit column/row-step word)'} \
             if int(st[18]) else {'kernel': 'spmv_panel_kernel<tier0>', 'role': 'tier 0, (block, row) pair form: x window in LDS'}
         kernels.append(dict(t0, ms=k_ms2[1], entries=int(st[10]),
                             algorithmic_bytes=int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8))

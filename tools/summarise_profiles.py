@@ -11,7 +11,6 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = f'gpurun_out/{tag}'
 os.makedirs('profiles', exist_ok=True)
 bench = json.loads(open(f'{src}/bench.json').read().strip().splitlines()[-1])
-shutil.copy(f'{src}/bench.json', f'profiles/{tag}_bench.json')
 # kernel stats: keep our kernels + the total
 rows = list(csv.DictReader(open(newest(f'{src}/kt/*/*_kernel_stats.csv'))))
 with open(f'profiles/{tag}_spmv_kernel_stats.csv', 'w', newline='') as f:
@@ -24,7 +23,7 @@ def pmc(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(f'{src}/{d}/*/*_counter_collection.csv'))):
         if 'csrk::spmv' in r['Kernel_Name'] or 'csrk::panel' in r['Kernel_Name'] or 'csrk::acc_' in r['Kernel_Name'] \
-                or 'csrk::hot_pack' in r['Kernel_Name']:
+                or 'csrk::hot_pack' in r['Kernel_Name'] or 'csrk::ls_stage_kernel' in r['Kernel_Name']:
             full = r['Kernel_Name'].split('csrk::')[1].split('(')[0]
             name = full.split('<')[0]
             if name == 'spmv_panel_kernel':      # two instantiations: tier 0 (LDS window), tier 1 (L2 window)
@@ -43,6 +42,8 @@ traffic = {}
 for (k, c), v in allc.items():
     if c in ('FETCH_SIZE', 'WRITE_SIZE'):
         traffic[k] = traffic.get(k, 0.0) + v * 1024.0 * (2.0 if c == 'FETCH_SIZE' else 1.0)   # KB; 128-B reads tallied as 64 B
+if 'ls_stage_kernel' in traffic and 'spmv_lstream_kernel' in traffic:      # bench.py times the two together
+    traffic['ls_stage_kernel + spmv_lstream_kernel'] = traffic['ls_stage_kernel'] + traffic['spmv_lstream_kernel']
 out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slots), each with '
                  '--kernel-trace only; mean over the recorded launches. '
@@ -50,5 +51,9 @@ out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
                  'requests (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ for these kernels, measured), so read bytes = 2 x '
                  'FETCH_SIZE x 1024 (the correction of MI355X_MICROARCH.md, HBM section); writes = WRITE_SIZE x 1024.'}
 json.dump(out, open(f'profiles/{tag}_spmv_pmc_traffic.json', 'w'), indent=1)
+# the bench line of the same collection run, with the traffic these passes measured for its dominant kernel
+if bench['roofline'].get('traffic') is None and bench['roofline']['kernel'] in traffic:
+    bench['roofline']['traffic'] = traffic[bench['roofline']['kernel']]
+open(f'profiles/{tag}_bench.json', 'w').write(json.dumps(bench) + '\n')
 print(json.dumps(out['hbm_bytes_per_launch']))
 print({k: v for k, v in bench['roofline'].items() if k != 'all_kernels'})
