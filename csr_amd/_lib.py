@@ -68,6 +68,7 @@ SIGNATURES = {
     'csrk_spmv_profile_begin': (_int, [handle_t, _int]),
     'csrk_spmv_profile_every': (_int, [handle_t, _int]),
     'csrk_spmv_profile_end': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
+    'csrk_spmv_profile_end4': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
     'csrk_spgemm_ab': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),

@@ -3234,7 +3234,7 @@ int csrk_spmv_profile_every(csrk_handle_t h, int every_n)
     return CSRK_OK;
 }
 
-int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
+int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean_ms)
 {
     Matrix *m = from_handle(h);
     if (!m) return CSRK_ERR_INVALID;
@@ -3243,7 +3243,7 @@ int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
     SpmvPlan *p = m->spmv_plan;
     CSRK_REQUIRE(p && p->profiling, "profiling was not started on this handle");
     p->profiling = false;
-    double tot[4] = {0.0, 0.0, 0.0, 0.0};      // channel 3: the cold-staging pass, reported with the light stream it feeds
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};      // channel 3: the cold-staging pass
     int cnt[4] = {0, 0, 0, 0};
     int n = p->ev_used / 2;
     for (int i = 0; i < n; i++) {
@@ -3254,10 +3254,17 @@ int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
         cnt[p->ev_chan[i]]++;
     }
     *n_records = cnt[0];
-    mean_ms[0] = cnt[0] ? (float)((tot[0] + tot[3]) / cnt[0]) : 0.f;
-    mean_ms[1] = cnt[1] ? (float)(tot[1] / cnt[1]) : 0.f;
-    mean_ms[2] = cnt[2] ? (float)(tot[2] / cnt[2]) : 0.f;
+    for (int c = 0; c < 4; c++) mean_ms[c] = cnt[c] ? (float)(tot[c] / cnt[c]) : 0.f;
     p->ev_used = 0;
+    return CSRK_OK;
+}
+
+int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms)
+{
+    float ms4[4] = {0.f, 0.f, 0.f, 0.f};
+    CSRK_REQUIRE(n_records && mean_ms, "output is NULL");
+    CSRK_TRY(csrk_spmv_profile_end4(h, n_records, ms4));
+    for (int c = 0; c < 3; c++) mean_ms[c] = ms4[c];
     return CSRK_OK;
 }
 

@@ -141,6 +141,9 @@ CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
  * timed kernels, 3 % of the headline step; call before csrk_spmv_profile_begin. */
 CSRK_API int csrk_spmv_profile_every(csrk_handle_t h, int every_n);
 CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);
+/* The same with mean_ms[4]: [3] = the cold-staging pass that feeds the light stream (ls_stage_kernel; 0 if the plan
+ * has none). */
+CSRK_API int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean_ms);
 
 /* ---- mult_ab / mult_abt: sparse x sparse -> sparse ------------------------------------
  * csr/kernels/numba/multiply.py:13-57; lk_mkl_spmab / lk_mkl_spmabt (mkl_ops.h:30-31).

@@ -42,8 +42,6 @@ traffic = {}
 for (k, c), v in allc.items():
     if c in ('FETCH_SIZE', 'WRITE_SIZE'):
         traffic[k] = traffic.get(k, 0.0) + v * 1024.0 * (2.0 if c == 'FETCH_SIZE' else 1.0)   # KB; 128-B reads tallied as 64 B
-if 'ls_stage_kernel' in traffic and 'spmv_lstream_kernel' in traffic:      # bench.py times the two together
-    traffic['ls_stage_kernel + spmv_lstream_kernel'] = traffic['ls_stage_kernel'] + traffic['spmv_lstream_kernel']
 out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slots), each with '
                  '--kernel-trace only; mean over the recorded launches. '
