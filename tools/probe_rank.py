@@ -7,7 +7,7 @@ dev = 'cuda'
 n = 10_000_000; nnz = 200_000_000
 x = synth.dense_vector(n, device=dev)
 for world in (1, 2, 4, 8):
-    for rank in sorted({0, world - 1}):
+    for rank in sorted({0}):
         sh = synth.powerlaw_csr(n, n, nnz, device=dev, rank=rank, world=world)
         rp, ci, vs = sh['rowptrs'], sh['colinds'], sh['values']
         nl = sh['row_end'] - sh['row_begin']
@@ -18,6 +18,10 @@ for world in (1, 2, 4, 8):
         torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
         for _ in range(30): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
         e1.record(); torch.cuda.synchronize()
-        st = (C.c_int64 * 24)(); check(lib.csrk_spmv_plan_stats(h, st, 24))
-        print(f'world {world} rank {rank}: rows {nl} nnz {int(ci.numel())}: {e0.elapsed_time(e1) / 30:.4f} ms  (tier0 rows {st[9]} entries {st[10]}, tier1 entries {st[13]}, light {st[3]}, pack {st[16]})', flush=True)
+        check(lib.csrk_spmv_profile_every(h, 1)); check(lib.csrk_spmv_profile_begin(h, 10))
+        for _ in range(10): check(lib.csrk_spmv_device(h, x.data_ptr(), y.data_ptr(), None))
+        torch.cuda.synchronize(); nr = C.c_int(0); km = (C.c_float * 4)(); check(lib.csrk_spmv_profile_end4(h, C.byref(nr), km))
+        print('   kernels ms: light %.4f  tier0 %.4f  tier1 %.4f  stage %.4f' % tuple(km), flush=True)
+        st = (C.c_int64 * 25)(); check(lib.csrk_spmv_plan_stats(h, st, 25))
+        print(f'world {world} rank {rank}: rows {nl} nnz {int(ci.numel())}: {e0.elapsed_time(e1) / 30:.4f} ms  (tier0 rows {st[9]} entries {st[10]}, tier1 entries {st[13]}, light {st[3]}, pack {st[16]}, staged {st[24]})', flush=True)
         check(lib.csrk_free(h)); del sh, rp, ci, vs, y

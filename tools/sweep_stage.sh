@@ -5,13 +5,13 @@ run() { tag=$1; shift; env "$@" python bench.py --steps 50 --warmup 5 --no-cpu-b
 import json
 try:
     d=json.loads([l for l in open("$O/$tag.log") if l.startswith("{")][-1])
-    print("$tag", d["ms_per_step"], [(k["kernel"][5:12],k["ms"]) for k in d["roofline"]["all_kernels"]], d["config"].get("cold_staged_entries"), d["config"]["hot_column_cache"]["columns"], flush=True)
+    print("$tag", d["ms_per_step"], [(k["kernel"][5:12],k["ms"]) for k in d["roofline"]["all_kernels"]], flush=True)
 except Exception as e:
     print("$tag FAILED", e); print(open("$O/$tag.log").read()[-1500:])
 PY
 }
-run base A=1
-run lsuc CSRK_LS_UC=1
-run accuc CSRK_ACC_UC=1
-run bothuc CSRK_LS_UC=1 CSRK_ACC_UC=1
-run lsuc1m CSRK_LS_UC=1 CSRK_HOT_SLOTS=1048576
+run t1hot A=1
+run t1off CSRK_T1_HOT=0
+run t1hot_tpw2 CSRK_PANEL_TPW1=2
+run t1hot_tpw4 CSRK_PANEL_TPW1=4
+run t1off_tpw2 CSRK_T1_HOT=0 CSRK_PANEL_TPW1=2
