@@ -386,6 +386,33 @@ def main():
                       f'({t_cpu / reps:.2f} s each)',
             'host_cpus': os.cpu_count(),
         }
+        # two more CPU figures, clearly NOT the reference's kernel: the same row loop shared out
+        # over this process's CPUs with OpenMP (bit-identical result), and SciPy's single-threaded csr_matvec
+        also = {}
+        try:
+            nthr = len(os.sched_getaffinity(0))
+            y_par = O.mult_vec_rows_parallel(nrows, ncols, rp_h, ci_h, vs_h, x_h, nthr)      # warm-up
+            t1 = time.perf_counter()
+            for _ in range(3):
+                O.mult_vec_rows_parallel(nrows, ncols, rp_h, ci_h, vs_h, x_h, nthr)
+            t_par = (time.perf_counter() - t1) / 3
+            also['openmp_row_parallel_port'] = {'value': round(2.0 * nnz / t_par / 1e9, 3), 'unit': 'GFLOP/s', 'cores': nthr,
+                                                'bit_identical_to_port': bool(np.array_equal(y_par, y_cpu))}
+        except Exception as e:
+            also['openmp_row_parallel_port'] = {'error': str(e)[:200]}
+        try:
+            import scipy.sparse as sps
+            A_sp = sps.csr_matrix((vs_h, ci_h, rp_h), shape=(nrows, ncols))
+            A_sp @ x_h
+            t1 = time.perf_counter()
+            y_sp = A_sp @ x_h
+            t_sp = time.perf_counter() - t1
+            also['scipy_csr_matvec'] = {'value': round(2.0 * nnz / t_sp / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1,
+                                        'max_abs_diff_vs_port_over_bound': float(np.max(np.abs(y_sp - y_cpu) / (bound + 1e-300)))}
+            del A_sp
+        except Exception as e:
+            also['scipy_csr_matvec'] = {'error': str(e)[:200]}
+        out['cpu_baseline']['also_not_the_reference'] = also
         out['parity'] = {'max_abs_err_over_sum_abs_terms': worst, 'tolerance': 1e-6, 'ok': bool(worst <= 1e-6),
                          'rows_bit_identical': float(np.mean(y_gpu == y_cpu))}
         if worst > 1e-6:

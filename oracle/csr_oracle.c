@@ -62,6 +62,25 @@ ORC_EXPORT void orc_mult_vec_i32(int32_t nrows, int64_t nnz, const int32_t *rowp
     }
 }
 
+/* NOT the reference: the same per-row arithmetic (products rounded on their own, added in storage order, so the
+ * result is bit-identical to orc_mult_vec_i32) with the rows shared out over OpenMP threads.  The reference's
+ * kernel is single-threaded (@njit(nogil=True), no parallel=True: csr/kernels/numba/__init__.py:55); bench.py
+ * reports this variant next to the port so that the GPU/CPU ratio is not flattered by a one-core baseline
+ * (SURVEY.md section 8d). */
+ORC_EXPORT void orc_mult_vec_i32_rows_omp(int32_t nrows, const int32_t *rowptrs, const int32_t *colinds,
+                                          const double *values, const double *x, double *y, int32_t nthreads)
+{
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(nthreads)
+    for (int32_t r = 0; r < nrows; r++) {
+        double acc = 0.0;
+        for (int64_t i = rowptrs[r]; i < (int64_t)rowptrs[r + 1]; i++) {
+            double a = values ? values[i] : 1.0;
+            acc += x[colinds[i]] * a;
+        }
+        y[r] = acc;
+    }
+}
+
 /* float32 values: the product v[col] * values[i] is taken in float64 when v is float64
  * (NumPy/Numba promotion), which is what every reference test feeds (test_utils.py:22-27). */
 ORC_EXPORT void orc_mult_vec_f32vals(int32_t nrows, int64_t nnz, const int64_t *rowptrs,

@@ -58,6 +58,21 @@ def _ci(colinds):
     return np.ascontiguousarray(colinds, dtype=np.int32)
 
 
+def mult_vec_rows_parallel(nrows, ncols, rowptrs, colinds, values, x, nthreads):
+    """
+    NOT the reference (its kernel is single-threaded): the same per-row loop with the rows shared out over
+    `nthreads` OpenMP threads; int32 row pointers and float64 (or no) values only.  bench.py's second CPU figure.
+    """
+    assert rowptrs.dtype == np.int32 and rowptrs.flags.c_contiguous and x.shape == (ncols,)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(nrows, dtype=np.float64)
+    vs = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+    L = lib()
+    L.orc_mult_vec_i32_rows_omp(C.c_int32(nrows), _p(rowptrs, _i32p), _p(_ci(colinds), _i32p),
+                                None if vs is None else _p(vs, _f64p), _p(x, _f64p), _p(y, _f64p), C.c_int32(int(nthreads)))
+    return y
+
+
 def mult_vec(nrows, ncols, rowptrs, colinds, values, x):
     "csr/kernels/numba/__init__.py:55-67"
     x = np.asarray(x)

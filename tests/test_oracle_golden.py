@@ -226,3 +226,17 @@ def test_pick_rows_golden(golden):
             seen_novals += 1
         seen_repeat += len(set(rows.tolist())) < len(rows)
     assert seen_novals > 3 and seen_f4 > 1 and seen_repeat > 3
+
+
+def test_row_parallel_variant_is_bit_identical_to_the_sequential_port():
+    "bench.py's second CPU figure (OpenMP over rows; NOT the reference's kernel) computes the port's bits"
+    from csr_amd import synth
+    from oracle import oracle as O
+    m = synth.powerlaw_csr(30000, 20000, 400000, device='cpu')
+    rp, ci, vs = m['rowptrs'].numpy(), m['colinds'].numpy(), m['values'].numpy()
+    x = synth.dense_vector(20000, device='cpu').numpy()
+    ref = O.mult_vec(30000, 20000, rp, ci, vs, x)
+    for nthr in (1, 3, 8):
+        assert np.array_equal(O.mult_vec_rows_parallel(30000, 20000, rp, ci, vs, x, nthr), ref)
+    assert np.array_equal(O.mult_vec_rows_parallel(30000, 20000, rp, ci, None, x, 4),
+                          O.mult_vec(30000, 20000, rp, ci, None, x))
