@@ -391,6 +391,13 @@ def main():
         also = {}
         try:
             nthr = len(os.sched_getaffinity(0))
+            try:      # a container's CPU share (cgroup v2 quota), when it is smaller than the affinity mask
+                q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+                if q != 'max':
+                    nthr = max(1, min(nthr, int(int(q) / int(per))))
+            except (OSError, ValueError):
+                pass
+            nthr = min(nthr, int(os.environ.get('BENCH_CPU_THREADS', '16')))      # a GPU box gives one GPU 16 CPUs' worth
             y_par = O.mult_vec_rows_parallel(nrows, ncols, rp_h, ci_h, vs_h, x_h, nthr)      # warm-up
             t1 = time.perf_counter()
             for _ in range(3):
