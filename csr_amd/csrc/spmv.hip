@@ -1012,7 +1012,7 @@ constexpr int ACC_CB = 4096;
 constexpr int ACC_K = 8;                      // consecutive entries per lane
 constexpr int ACC_TILE = WAVE * ACC_K;        // 512
 constexpr int ACC_MAXROWS = 15360;            // heavy rows per group: 120 KiB of accumulators + 32 KiB window + heads <= 160 KiB
-constexpr int ACC_FLOOR = 512;                // tier 0 is never extended to rows shorter than this
+constexpr int ACC_FLOOR = 128;                // tier 0 is never extended to rows shorter than this (512 before the 10-B stream: a rank of an 8-way split ran 0.129 ms, 0.119 with 128)
 constexpr int ACC_SEG_TILES = 256;            // head slots per segment
 constexpr int ACC_THREADS = 1024;
 // index word of the accumulator stream, 16 bits: column - block start in the low 13 (ACC_CB = the zero slot of the
@@ -2126,7 +2126,9 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
             int64_t n_ge = 0;
             for (int32_t c = 0; c < n_cut; c++) n_ge += lens[c] >= thr;
             if (n_ge > ACC_MAXROWS) thr++;
-            thr = thr < ACC_FLOOR ? ACC_FLOOR : thr;
+            int acc_floor = ACC_FLOOR;
+            if (const char *e = getenv("CSRK_ACC_FLOOR")) acc_floor = atoi(e) > 0 ? atoi(e) : acc_floor;
+            thr = thr < acc_floor ? acc_floor : thr;
             if (thr < HEAVY_MIN) HEAVY_MIN = (int)thr;
         }
     }

@@ -46,6 +46,10 @@ def split_mode(request, monkeypatch):
             monkeypatch.setenv('CSRK_SPMV_TIER1', 'stream')
         else:
             monkeypatch.delenv('CSRK_SPMV_TIER1', raising=False)
+    if 'nostream' in request.param:      # ... and with tier 0 not extended below 512 entries: acc tier 0 beside a pair-kernel tier 1
+        monkeypatch.setenv('CSRK_ACC_FLOOR', '512')
+    else:
+        monkeypatch.delenv('CSRK_ACC_FLOOR', raising=False)
     if 'hot' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HOT', '1')
     else:
@@ -326,7 +330,10 @@ def test_plan_stats_and_cache_trim(split_mode):
         st = (C.c_int64 * 20)()
         check(lib.csrk_spmv_plan_stats(h.H, st, 20))
         assert st[2] == 2                      # two rows cut out of the tile path
-        assert st[10] == 4000 and st[13] == 500    # tier-0 / tier-1 entries
+        # tier-0 / tier-1 entries: the accumulator tier takes every cut row down to 128 entries while it has room
+        # (ACC_FLOOR; 512 in the 'nostream' mode), the pair form only rows of 2048 and more
+        t1 = 500 if ('pairs' in split_mode or 'nostream' in split_mode) else 0
+        assert st[10] == 4500 - t1 and st[13] == t1
         assert st[3] == m.nnz - 4500
         if 'hot' in split_mode:
             # columns referenced at least twice by the tile path's rows are packed

@@ -6,7 +6,8 @@ from csr_amd._lib import lib, check, handle_t
 dev = 'cuda'
 n = 10_000_000; nnz = 200_000_000
 x = synth.dense_vector(n, device=dev)
-for world in (1, 2, 4, 8):
+import os
+for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     for rank in sorted({0}):
         sh = synth.powerlaw_csr(n, n, nnz, device=dev, rank=rank, world=world)
         rp, ci, vs = sh['rowptrs'], sh['colinds'], sh['values']
