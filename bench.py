@@ -10,8 +10,8 @@ N = 1 runs in-process; for N > 1 the driver launches one rank per GPU
 row-range partitioned (nnz balanced) with x replicated, and one step = local SpMV + the exchange
 that completes y on every rank.  xGMI is point-to-point and the exchange of the 80 MB y is link-bound, so
 how RCCL drives the links decides the step: before the warm-up the candidates of csr_amd/dist.py (padded
-all-gather; point-to-point sends straight into y; the same pipelined behind the product in 2 / 4 chunks
-per rank) are each timed for 8 steps and the fastest runs the timed region (`multi_gpu.candidates_ms_per_step`;
+all-gather; point-to-point sends straight into y; the same with the slice travelling while the tiers' part of
+the product runs; the same pipelined behind the product in 2 / 4 chunks per rank) are each timed for 8 steps and the fastest runs the timed region (`multi_gpu.candidates_ms_per_step`;
 `--collective allreduce` forces the all-reduce north_star names, `--collective NAME` any other).
 The matrix is FIXED as N grows ("scaling": "strong").
 
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
     ap.add_argument('--collective', default='auto',
-                    choices=['auto', 'allgather', 'allreduce', 'p2p', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
+                    choices=['auto', 'allgather', 'allreduce', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
                     help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
@@ -89,7 +89,8 @@ def main():
 
     from csr_amd import synth
     from csr_amd._lib import lib, check, handle_t, SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR
-    from csr_amd.dist import RowPartitionedSpMV, PipelinedRowPartitionedSpMV, chunk_cuts, hip_local_spmv
+    from csr_amd.dist import (RowPartitionedSpMV, PipelinedRowPartitionedSpMV, SplitPhaseRowPartitionedSpMV, chunk_cuts,
+                              hip_local_spmv, hip_local_spmv_parts)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -181,6 +182,9 @@ def main():
         if world == 1 or name in ('allgather', 'allreduce'):
             return RowPartitionedSpMV(shard['bounds'], rank, world, local, dev,
                                       mode=name if world > 1 else 'allgather'), []
+        if name == 'p2p-split':
+            run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
+            return SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
         exch, _, k = name.partition('-k')
         K = int(k) if k else 1
         if K == 1:
@@ -196,15 +200,28 @@ def main():
         # which a 1-GPU box cannot show.  Every candidate runs 3 untimed steps (its chunk handles build their
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
         calibration, best = {}, None
-        for name in ('allgather', 'p2p', 'p2p-k2', 'p2p-k4'):
+        ref_sum = None
+        for name in ('allgather', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4'):
             cand, hs, err = None, [], None
             try:
                 cand, hs = make_op(name)
                 for _ in range(3):
-                    cand.step(x)
+                    yc = cand.step(x)
                 torch.cuda.synchronize()
+                # every candidate must produce the first one's y: bit for bit when it runs the same plan, to 1e-9 of
+                # max |y| when its chunks have plans of their own (their tiers cut the sums differently)
+                if ref_sum is None:
+                    ref_sum = yc.clone()
+                elif hs:
+                    dmax, ymax = float((yc - ref_sum).abs().max().item()), float(ref_sum.abs().max().item())
+                    if not dmax <= 1e-9 * ymax:
+                        err = f'result differs from the all-gather form: max |dy| = {dmax:.3e}, max |y| = {ymax:.3e}'
+                elif not torch.equal(yc, ref_sum):
+                    err = 'result differs from the all-gather form (same plan: must be identical)'
             except Exception as e:                       # e.g. a backend without this exchange (gloo test hook)
                 err = f'{type(e).__name__}: {e}'[:200]
+            if err:
+                print(f'[bench rank {rank}] exchange candidate {name} dropped: {err}', file=sys.stderr, flush=True)
             bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if bad.item() > 0:
@@ -232,6 +249,7 @@ def main():
         if best is None:
             sys.exit(f'no exchange candidate ran: {calibration}')
         collective, op, op_handles = best
+        del ref_sum
     else:
         collective = args.collective if world > 1 else 'none'
         if collective == 'auto':

@@ -2831,12 +2831,16 @@ static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
 }
 
 template <class P, int VT>
-static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, hipStream_t s)
+static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, hipStream_t s, int part)
 {
     const P *rp = (const P *)m->d_rowptrs;
     if (m->nrows == 0) return CSRK_OK;
     int algo = p->algo;
     if (algo == CSRK_SPMV_MERGE && m->nnz < 2) algo = CSRK_SPMV_SCALAR;   // the tile kernel's pair loads need >= 2 entries
+    // part (csrk_spmv_device_part): bit 0 = the rows of the row-major path (every row gets a value: the rows cut out
+    // for the tiers get 0.0), bit 1 = the tiers' rows (their reduces overwrite those zeros).  1 then 2 = 3.
+    const bool do_light = (part & 1) != 0, do_heavy = (part & 2) != 0;
+    if (algo != CSRK_SPMV_MERGE && !do_light) return CSRK_OK;      // no tiers outside the merge algorithm
     switch (algo) {
     case CSRK_SPMV_MERGE: {
         // Small kernels that do not depend on the big ones' results -- the hot-column pack (needs only x),
@@ -2895,14 +2899,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_LAUNCH_CHECK();
             return CSRK_OK;
         };
-        if (p->ls.on && p->ls.n_cold && stage_first) CSRK_TRY(launch_stage());
-        if (p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
+        if (do_light && p->ls.on && p->ls.n_cold && stage_first) CSRK_TRY(launch_stage());
+        if (do_light && p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
             hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, sa>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
                                                                              p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
             if (aux) CSRK_HIP(hipEventRecord(p->ev_pack, sa));
         }
-        if (p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
+        if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
                 spmv_acc_kernel<ACC_CB, ACC_THREADS><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
@@ -2912,7 +2916,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             }
             kh.stop();
         }
-        for (int q = 0; q < 2 && p->n_heavy; q++) {
+        for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             if (q == 1 && p->t1s.on) {      // tier 1 as a stream of (block, row) runs -> pair partials
@@ -2960,8 +2964,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 CSRK_TRY(add_fix(pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>()));
             }
         }
-        if (aux && p->n_hot) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
-        {
+        if (aux && p->n_hot && do_light) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
+        if (do_light) {
 #define MERGE_ARGS_LIGHT(CI)                                                                                        \
     p->rp_light.as<P>(), CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, p->nnz_light,                \
         p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(), p->cut_pos.as<int64_t>(),  \
@@ -3022,10 +3026,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_HIP(hipStreamWaitEvent(s, p->ev_aux, 0));
         }
         CSRK_TRY(flush_fix());      // the carries of the light stream and of the tiers, one launch
-        if (p->n_heavy && !p->acc.empty())
+        if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
                 CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg));
-        for (int q = 0; q < 2 && p->n_heavy; q++) {
+        for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             // y[row] = sum over column blocks of the (block, row) partials, in block order
@@ -3063,7 +3067,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     return CSRK_OK;
 }
 
-static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s)
+static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s, int part = 3)
 {
     // One SpMV = several kernels that share the plan's carry / partial arrays.  The per-handle lock keeps
     // the launch group together so that concurrent callers (the reference's kernels are nogil) are
@@ -3073,7 +3077,7 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan_locked(m, s, &p, true));
     p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
-#define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s)
+#define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s, part)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
         if (m->val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
@@ -3152,6 +3156,31 @@ int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stre
     if (!m) return CSRK_ERR_INVALID;
     CSRK_REQUIRE((d_x || m->ncols == 0) && (d_y || m->nrows == 0), "x or y is NULL");
     return spmv_dispatch(m, d_x, d_y, (hipStream_t)stream);
+}
+
+int csrk_spmv_device_part(csrk_handle_t h, const double *d_x, double *d_y, void *stream, int part)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE((d_x || m->ncols == 0) && (d_y || m->nrows == 0), "x or y is NULL");
+    CSRK_REQUIRE(part >= 1 && part <= 3, "part must be 1 (row-major path), 2 (tiers) or 3 (both), not %d", part);
+    return spmv_dispatch(m, d_x, d_y, (hipStream_t)stream, part);
+}
+
+int csrk_spmv_cut_rows(csrk_handle_t h, int32_t *d_rows, int64_t capacity, int64_t *n_rows)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(n_rows, "n_rows is NULL");
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));              // a query: builds the split eagerly
+    std::lock_guard<std::mutex> lk(m->mu);
+    const int64_t n = p->algo == CSRK_SPMV_MERGE ? p->n_heavy : 0;
+    *n_rows = n;
+    if (n == 0 || !d_rows) return CSRK_OK;
+    CSRK_REQUIRE(capacity >= n, "the buffer holds %lld rows, the plan cut %lld out", (long long)capacity, (long long)n);
+    CSRK_HIP(hipMemcpy(d_rows, p->heavy_row.p, (size_t)n * 4, hipMemcpyDeviceToDevice));
+    return CSRK_OK;
 }
 
 int csrk_spmv(csrk_handle_t h, const double *x, double *y)

@@ -18,7 +18,8 @@ step of the path:
              every sum has one non-zero term and is exact), about twice the bytes per link.
 
 PipelinedRowPartitionedSpMV: point-to-point exchange straight into y (no padding, no concatenation) and/or the
-exchange pipelined behind the product (K chunks per rank).
+exchange pipelined behind the product (K chunks per rank).  SplitPhaseRowPartitionedSpMV: the exchange hidden
+behind the tiers' part of one product (csrk_spmv_device_part).
 
 torch is plumbing here (device buffers + the collective); the product kernels run behind
 `local_spmv`, a callable that writes y[r0:r1] = A[r0:r1, :] x into the buffer it is given.
@@ -89,6 +90,15 @@ class RowPartitionedSpMV:
         self._local(x, self.y[self.r0:self.r1])
         dist.all_reduce(self.y, op=dist.ReduceOp.SUM, group=self.group)
         return self.y
+
+
+def _sync_if_host_backend(t, group):
+    """
+    gloo (the CPU tests, and bench.py's two-ranks-on-one-GPU test hook) sends device tensors from the host without
+    waiting for the stream that produces them: wait here.  RCCL orders a send after the producing kernels by itself.
+    """
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        torch.cuda.synchronize(t.device)
 
 
 class PipelinedRowPartitionedSpMV:
@@ -171,6 +181,7 @@ class PipelinedRowPartitionedSpMV:
             if self.world == 1 or self.exchange == 'p2p':
                 self._local(c, x, self.y[self.sub[r][c]:self.sub[r][c + 1]])
                 if self.world > 1 and self.ops[c]:
+                    _sync_if_host_backend(self.y, self.group)
                     works += dist.batch_isend_irecv(self.ops[c])
             else:
                 self._local(c, x, self.loc[c][:self.lens[r][c]])
@@ -179,6 +190,101 @@ class PipelinedRowPartitionedSpMV:
             w.wait()
         if self.world > 1 and self.exchange == 'allgather' and self.pieces:
             torch.cat(self.pieces, out=self.y)
+        return self.y
+
+
+class SplitPhaseRowPartitionedSpMV:
+    """
+    The exchange hidden behind the part of the product that touches few rows.  A rank's SpMV has two parts
+    (csrk_spmv_device_part): part 1 computes every row of the row-major path and writes 0.0 into the rows the plan
+    cut out for its tiers -- a few thousand long rows holding most of the entries --, part 2 computes those rows.
+    So: part 1, then the slice is sent to every peer (point to point, straight into y, as in
+    PipelinedRowPartitionedSpMV) WHILE part 2 runs, and afterwards the cut rows' values -- a few KB per rank -- follow
+    in one small all-gather and are written over the stale entries on every rank.  (The big send may read a cut
+    row's entry before or after part 2 stores it; either way the small exchange overwrites it with the final value.)
+    No extra handles, x is read once per kernel as in the plain product.
+
+    local_part(x, out, part): this rank's rows, part 1 / 2 (asynchronous on the current stream);
+    cut_rows: ascending int64 LOCAL row indices part 2 writes (may be empty), on `device`.
+    """
+
+    def __init__(self, bounds, rank, world, local_part, cut_rows, device, group=None):
+        assert len(bounds) == world + 1
+        self.bounds = [int(b) for b in bounds]
+        self.rank, self.world, self.group = rank, world, group
+        self.local_part = local_part
+        self.nrows = self.bounds[-1]
+        self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        self.y = torch.zeros(self.nrows, dtype=torch.float64, device=device)
+        self.timing = False
+        self._ev = []
+        self.ops = []
+        mine = self.y[self.r0:self.r1]
+        for d in range(1, world):
+            to, frm = (rank + d) % world, (rank - d) % world
+            if self.r1 > self.r0:
+                self.ops.append(dist.P2POp(dist.isend, mine, to, group))
+            if self.bounds[frm + 1] > self.bounds[frm]:
+                self.ops.append(dist.P2POp(dist.irecv, self.y[self.bounds[frm]:self.bounds[frm + 1]], frm, group))
+        # the cut rows of every rank, as global row indices: exchanged once
+        cut = cut_rows.to(device=device, dtype=torch.int64) + self.r0
+        n_mine = int(cut.numel())
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        counts[rank] = n_mine
+        if world > 1:
+            dist.all_reduce(counts, group=group)
+        counts = [int(c) for c in counts.tolist()]
+        self.n_mine, self.maxn = n_mine, max(max(counts), 1)
+        self.total_cut = sum(counts)
+        self.my_rows = cut
+        self.hv_loc = torch.zeros(self.maxn, dtype=torch.float64, device=device)
+        self.hv_all = torch.zeros(world * self.maxn, dtype=torch.float64, device=device)
+        if world > 1 and self.total_cut:
+            pad = torch.zeros(self.maxn, dtype=torch.int64, device=device)
+            pad[:n_mine] = cut
+            rows_all = torch.zeros(world * self.maxn, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(rows_all, pad, group=group)
+            src = [torch.arange(g * self.maxn, g * self.maxn + counts[g], device=device) for g in range(world) if g != rank]
+            self.src_pos = torch.cat(src) if src else torch.zeros(0, dtype=torch.int64, device=device)
+            self.dst_rows = rows_all.index_select(0, self.src_pos)
+            self.tmp = torch.zeros(int(self.src_pos.numel()), dtype=torch.float64, device=device)
+
+    def compute_ms(self):
+        "mean device time per step of the two local parts over the steps timed so far"
+        if not self._ev:
+            return 0.0
+        ms = sum(a.elapsed_time(b) for a, b in self._ev) * 2 / len(self._ev)
+        self._ev = []
+        return ms
+
+    def _part(self, x, out, part):
+        if self.timing and out.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.local_part(x, out, part)
+            e1.record()
+            self._ev.append((e0, e1))
+        else:
+            self.local_part(x, out, part)
+
+    def step(self, x):
+        "y = A x, complete on every rank; returns the (reused) y tensor"
+        mine = self.y[self.r0:self.r1]
+        self._part(x, mine, 1)
+        if self.world > 1 and self.ops:
+            _sync_if_host_backend(self.y, self.group)
+        works = dist.batch_isend_irecv(self.ops) if (self.world > 1 and self.ops) else []
+        self._part(x, mine, 2)
+        if self.world > 1 and self.total_cut:
+            if self.n_mine:
+                torch.index_select(self.y, 0, self.my_rows, out=self.hv_loc[:self.n_mine])
+        for w in works:
+            w.wait()
+        if self.world > 1 and self.total_cut:
+            dist.all_gather_into_tensor(self.hv_all, self.hv_loc, group=self.group)
+            if self.tmp.numel():
+                torch.index_select(self.hv_all, 0, self.src_pos, out=self.tmp)
+                self.y.index_copy_(0, self.dst_rows, self.tmp)
         return self.y
 
 
@@ -197,6 +303,27 @@ def chunk_cuts(rowptrs, K):
     for i in range(1, len(cuts)):
         cuts[i] = max(cuts[i], cuts[i - 1])
     return cuts
+
+
+def hip_local_spmv_parts(handle, device):
+    """
+    (local_part, cut_rows) over a libcsrk handle for SplitPhaseRowPartitionedSpMV: csrk_spmv_device_part on torch's
+    current stream, and the plan's cut rows (csrk_spmv_cut_rows: builds the plan) as an int64 tensor on `device`.
+    """
+    import ctypes as C
+    from ._lib import lib, check
+
+    def run(x, out, part):
+        assert x.dtype == torch.float64 and out.dtype == torch.float64 and out.is_contiguous()
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        check(lib.csrk_spmv_device_part(handle, x.data_ptr(), out.data_ptr(), stream, int(part)))
+
+    n = C.c_int64(0)
+    check(lib.csrk_spmv_cut_rows(handle, None, 0, C.byref(n)))
+    rows = torch.zeros(max(n.value, 1), dtype=torch.int32, device=device)
+    if n.value:
+        check(lib.csrk_spmv_cut_rows(handle, rows.data_ptr(), n.value, C.byref(n)))
+    return run, rows[:n.value].to(torch.int64)
 
 
 def hip_local_spmv(handle):

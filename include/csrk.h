@@ -112,6 +112,16 @@ CSRK_API int csrk_device_ptrs(csrk_handle_t h, void **d_rowptrs, void **d_colind
  * Structure-only matrices multiply with implicit 1.0 (csr/csr.py:254-262).            */
 CSRK_API int csrk_spmv(csrk_handle_t h, const double *x, double *y);
 CSRK_API int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stream);
+/* The same product in two parts, for callers that ship y elsewhere while it is being completed (csr_amd/dist.py:
+ * the row-partitioned multi-GPU form of csr/csr.py:584-590, where a rank's slice travels to its peers):
+ *   part 1  every row of the row-major path; rows the plan cut out for its tiers (csrk_spmv_cut_rows) get 0.0
+ *   part 2  the cut rows: their sums overwrite those zeros
+ *   part 3  both (= csrk_spmv_device).
+ * Part 1 then part 2 on one stream give bit for bit what part 3 gives. */
+CSRK_API int csrk_spmv_device_part(csrk_handle_t h, const double *d_x, double *d_y, void *stream, int part);
+/* The rows (ascending indices into this handle's rows) whose y entries part 2 writes: *n_rows of them, copied to the
+ * device buffer d_rows if it is not NULL and holds `capacity` >= *n_rows entries.  Builds the SpMV plan if needed. */
+CSRK_API int csrk_spmv_cut_rows(csrk_handle_t h, int32_t *d_rows, int64_t capacity, int64_t *n_rows);
 CSRK_API int csrk_set_spmv_algo(csrk_handle_t h, int algo);
 /* Name of the kernel the handle's plan resolved to, e.g. "merge" (after first use). */
 CSRK_API const char *csrk_spmv_algo_name(csrk_handle_t h);

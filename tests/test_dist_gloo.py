@@ -126,3 +126,53 @@ def test_pipelined_row_partitioned_spmv_gloo(tmp_path, world, exchange, K):
     ref = O.mult_vec(6000, 5000, full['rowptrs'].numpy(), full['colinds'].numpy(), full['values'].numpy(), x)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f'yc_{r}.npy'), ref)
+
+
+def _worker_split(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from csr_amd import synth
+        from csr_amd.dist import SplitPhaseRowPartitionedSpMV
+        from oracle import oracle as O
+        nrows, ncols, nnz = 6000, 5000, 90000
+        shard = synth.powerlaw_csr(nrows, ncols, nnz, device='cpu', rank=rank, world=world)
+        x = synth.dense_vector(ncols, device='cpu')
+        rp, ci, vs = (shard[k].numpy() for k in ('rowptrs', 'colinds', 'values'))
+        n_loc = shard['row_end'] - shard['row_begin']
+        lens = np.diff(rp)
+        # the stand-in for the plan's tiers: rows of 40 entries and more (rank 1 of 3 keeps none: an empty list must work)
+        cut = np.flatnonzero(lens >= 40) if not (world == 3 and rank == 1) else np.zeros(0, dtype=np.int64)
+        is_cut = np.zeros(n_loc, dtype=bool)
+        is_cut[cut] = True
+
+        def local_part(xt, out, part):
+            full = O.mult_vec(n_loc, ncols, rp, ci, vs, xt.numpy())
+            o = out.numpy()
+            if part == 1:
+                o[:] = np.where(is_cut, 0.0, full)          # the cut rows get 0.0
+            else:
+                o[is_cut] = full[is_cut]                    # ... and are overwritten by part 2
+
+        op = SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, local_part, torch.from_numpy(cut.astype(np.int64)), 'cpu')
+        y1 = op.step(x).clone()
+        y2 = op.step(x).clone()
+        assert torch.equal(y1, y2)
+        np.save(os.path.join(out_dir, f'ys_{rank}.npy'), y1.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_split_phase_row_partitioned_spmv_gloo(tmp_path, world):
+    "the slice travels while the cut rows are computed, their values follow in a small all-gather: the single-process y"
+    from csr_amd import synth
+    from oracle import oracle as O
+    mp.spawn(_worker_split, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    full = synth.powerlaw_csr(6000, 5000, 90000, device='cpu')
+    x = synth.dense_vector(5000, device='cpu').numpy()
+    ref = O.mult_vec(6000, 5000, full['rowptrs'].numpy(), full['colinds'].numpy(), full['values'].numpy(), x)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'ys_{r}.npy'), ref)

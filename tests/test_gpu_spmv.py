@@ -435,3 +435,44 @@ def test_hot_pack_is_bit_identical(monkeypatch, split_mode):
         finally:
             K.release_handle(h)
     assert np.array_equal(out['0'], out['1'])
+
+
+def test_two_part_product_equals_the_whole(split_mode):
+    "csrk_spmv_device_part: part 1 (row-major path, cut rows zeroed) then part 2 (the tiers' rows) = part 3, bit for bit"
+    import ctypes as C
+    import torch
+    from csr_amd._lib import lib, check
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, 12, size=6000)
+    lens[[5, 77, 3000, 5999]] = [5000, 900, 300, 2500]
+    m = _random_csr(rng, 6000, 40000, lens, sort=True)
+    x = rng.uniform(-1, 1, size=m.ncols)
+    h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False))
+    try:
+        xd = torch.from_numpy(x).cuda()
+        whole = torch.empty(m.nrows, dtype=torch.float64, device='cuda')
+        for _ in range(2):      # the second call runs the planned path
+            check(lib.csrk_spmv_device(h.H, xd.data_ptr(), whole.data_ptr(), None))
+        n = C.c_int64(0)
+        check(lib.csrk_spmv_cut_rows(h.H, None, 0, C.byref(n)))
+        parts = torch.full((m.nrows,), 7.0, dtype=torch.float64, device='cuda')
+        check(lib.csrk_spmv_device_part(h.H, xd.data_ptr(), parts.data_ptr(), None, 1))
+        if n.value:
+            rows = torch.zeros(n.value, dtype=torch.int32, device='cuda')
+            check(lib.csrk_spmv_cut_rows(h.H, rows.data_ptr(), n.value, C.byref(n)))
+            rl = rows.cpu().numpy()
+            assert np.all(np.diff(rl) > 0) and set(rl) <= {5, 77, 3000, 5999}
+            after1 = parts.cpu().numpy()
+            assert np.all(after1[rl] == 0.0)                                   # the cut rows hold 0.0 after part 1
+            keep = np.ones(m.nrows, dtype=bool)
+            keep[rl] = False
+            assert np.array_equal(after1[keep], whole.cpu().numpy()[keep])     # every other row is final
+        check(lib.csrk_spmv_device_part(h.H, xd.data_ptr(), parts.data_ptr(), None, 2))
+        torch.cuda.synchronize()
+        assert torch.equal(parts, whole)
+        with pytest.raises(Exception):
+            check(lib.csrk_spmv_device_part(h.H, xd.data_ptr(), parts.data_ptr(), None, 0))
+    finally:
+        K.release_handle(h)
