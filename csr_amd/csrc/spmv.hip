@@ -10,15 +10,19 @@
 //          distribution; one 256-thread workgroup per tile stages products in LDS, one lane per row sums its
 //          row in storage order, rows cut by a tile boundary leave a carry that a tiny kernel adds in tile
 //          order.  From the SECOND call on, a plan built once per handle (see "plan" below and DESIGN.md
-//          section 4) splits the rows three ways, each with a private, pre-decoded 12 B/entry stream:
+//          section 4) splits the rows three ways, each with a private, pre-decoded stream:
 //            tier 0  the (up to 15360) longest rows: column-block-major, x window AND one accumulator per
-//                    row in LDS (spmv_acc_kernel, "long rows, accumulator form");
+//                    row in LDS, 10 B per entry: f64 value + 16-bit (column, row step) word
+//                    (spmv_acc_kernel, "long rows, accumulator form");
 //            tier 1  rows of 128 .. tier-0 threshold: (column block, row) pairs over 1 MiB x windows kept in
 //                    one XCD's L2 (spmv_panel_kernel, "long rows, panel form");
 //            light   everything else: one wavefront per 512-entry tile, hot columns from LDS / a packed,
-//                    L2-resident copy of x, short rows bit-identical to the sequential loop
-//                    (spmv_lstream_kernel, "short rows: the light stream").
+//                    L2-resident copy of x, the x values of the unpacked columns copied beforehand into the
+//                    order the stream reads them (ls_stage_kernel, "cold staging"), short rows bit-identical
+//                    to the sequential loop (spmv_lstream_kernel, "short rows: the light stream").
 //          No float atomics decide an order anywhere: results are bitwise reproducible run to run.
+//          csrk_spmv_device_part runs the light part and the tiers' part separately (multi-GPU exchange
+//          hidden behind the tiers: csr_amd/dist.py).
 //  vector  One wavefront per row segment (rows longer than 4096 entries are split);
 //          coalesced 64-lane strides over colinds/values, __shfl_down reduction, ordered
 //          partial combine.  The classic CSR-vector shape; kept as an A/B baseline.
