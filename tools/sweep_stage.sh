@@ -10,5 +10,6 @@ except Exception as e:
     print("$tag FAILED", e); print(open("$O/$tag.log").read()[-1500:])
 PY
 }
-run wpe5 A=1
-run wpe5_tpw2 CSRK_PANEL_TPW1=2
+run t1hot A=1
+run t1off CSRK_T1_HOT=0
+run t1hot_tpw2 CSRK_PANEL_TPW1=2
