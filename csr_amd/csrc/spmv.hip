@@ -2700,7 +2700,7 @@ static int build_tier1_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     }
     CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1s, src.as<int64_t>(), rpv.as<int64_t>(), (int32_t)pairs,
                                                    pn->ci.as<int32_t>(), pn->vs.p, sg, n_tiles, &phys, (int32_t)pairs,
-                                                   (const int32_t *)nullptr, s)));
+                                                   p->n_hot ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr, s)));
     if (p->t1s.on) {
         // the pair kernel's own arrays are no longer needed (the partials y', the row list and the geometry are)
         pn->rp.release();
@@ -2929,7 +2929,9 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 KernelTimer kh(p, s, 2);
                 spmv_lstream_kernel<<<t.grid, LS_THREADS, t1_lds, s>>>(
                     t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
-                    t.carry_idx.as<int32_t>(), d_x, (const double *)nullptr, 0, t.n_tiles, t.n_runs, t.n_out,
+                    t.carry_idx.as<int32_t>(), d_x,
+                    (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(),
+                    p->n_hot ? p->n_hot_lds : 0, t.n_tiles, t.n_runs, t.n_out,
                     pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>());
                 kh.stop();
                 CSRK_LAUNCH_CHECK();
