@@ -12,4 +12,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/write.log 2>&1
+# matrix-core and L1-fill counters (north_star asks for the SpMM's MFMA utilisation from rocprof: the kernels issue none)
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/mfma -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/mfma.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/tcp -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/tcp.log 2>&1
 grep -c config $OUT/kt.log

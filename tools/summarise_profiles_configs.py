@@ -33,8 +33,16 @@ for d in ('fetch', 'write'):
 traffic = {}
 for (k, c), v in allc.items():
     traffic[k] = traffic.get(k, 0.0) + v * 1024.0 * (2.0 if c == 'FETCH_SIZE' else 1.0)   # KB; 128-B reads tallied as 64 B
+other = {}
+for d in ('mfma', 'tcp'):
+    try:
+        for (k, c), v in pmc(d).items():
+            other.setdefault(k, {})[c] = round(v)
+    except (ValueError, OSError):
+        pass
 json.dump({'workload': 'tools/bench_configs.py all (configs[2] SpMM, configs[4] transpose + A B^T block)',
            'hbm_bytes_per_launch': {k: round(v) for k, v in sorted(traffic.items())},
+           'counters_per_launch': other,
            'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace only; mean per launch; '
                      'read bytes = 2 x FETCH_SIZE x 1024 (128-B requests tallied at 64 B on gfx950), writes = WRITE_SIZE x 1024'},
           open(f'profiles/{tag}_configs_pmc_traffic.json', 'w'), indent=1)
