@@ -111,10 +111,13 @@ def main():
     check(lib.csrk_set_device(dev_index))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            # a collective that does not complete aborts the job after 5 minutes instead of holding the node
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(minutes=5))
 
     nrows = ncols = int(round(10_000_000 * args.scale))
     nnz = int(round(200_000_000 * args.scale))
