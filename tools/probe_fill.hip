@@ -97,6 +97,23 @@ __global__ void k_scalar_g(const double *x, const uint32_t *__restrict__ idx, do
     if (s == 1.2345) out[0] = s;
 }
 
+// L2-resident gathers (a 3.4-MB table: the SpMV's packed columns) with the load's cache-policy bits: does a gather
+// that skips L1 cost the CU less than pulling the whole 128-B line in (~4 clocks per lane)?
+template <int AUX>
+__global__ void k_l2(const double *xh, unsigned bytes, const uint32_t *__restrict__ idx, double *out, int64_t n, uint32_t mask)
+{
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)xh, (short)0, (int)bytes, 0x00020000);
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0;
+#pragma unroll 8
+    for (int64_t i = t; i < n; i += stride) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)((idx[i] & mask) * 8u), 0, AUX);
+        s += __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+    }
+    if (s == 1.2345) out[0] = s;
+}
+
 int main(int argc, char **argv)
 {
     const int64_t ncols = 10000000, n = 1 << 25;
@@ -111,6 +128,25 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const char *names[] = {"vector 8B", "scalar 8B", "atomic 8B", "vector 4B", "scalar x8 2048wg", "scalar x16 2048wg", "scalar x32 2048wg",
                            "scalar x16 1024wg", "scalar x16 4096wg", "scalar x32 1024wg"};
+    {
+        const uint32_t mask = (1u << 19) - 1;      // 524288 doubles = 4 MB... use 434k-ish: 2^19 slots, L2 + MALL resident
+        const char *nm[5] = {"l2 gather default", "l2 gather sc0", "l2 gather nt", "l2 gather sc1", "l2 gather sc0 sc1"};
+        for (int v = 0; v < 5 && which < 0; ++v) {
+            float best = 1e9;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipEventRecord(e0));
+                if (v == 0) k_l2<0><<<2048, 256>>>(x, (mask + 1) * 8, idx, out, n, mask);
+                if (v == 1) k_l2<1><<<2048, 256>>>(x, (mask + 1) * 8, idx, out, n, mask);
+                if (v == 2) k_l2<2><<<2048, 256>>>(x, (mask + 1) * 8, idx, out, n, mask);
+                if (v == 3) k_l2<16><<<2048, 256>>>(x, (mask + 1) * 8, idx, out, n, mask);
+                if (v == 4) k_l2<17><<<2048, 256>>>(x, (mask + 1) * 8, idx, out, n, mask);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            printf("%-18s %8.3f ms  %6.2f ps/gather\n", nm[v], best, best * 1e9 / n);
+        }
+    }
     for (int v = 0; v < 10; ++v) {
         if (which >= 0 && which != v) continue;
         float best = 1e9;
