@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
     ap.add_argument('--collective', default='auto',
-                    choices=['auto', 'allgather', 'allreduce', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
+                    choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
                     help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
@@ -182,7 +182,7 @@ def main():
 
     def make_op(name):
         "-> (operator, handles it owns)"
-        if world == 1 or name in ('allgather', 'allreduce'):
+        if world == 1 or name in ('allgather', 'allgatherv', 'allreduce'):
             return RowPartitionedSpMV(shard['bounds'], rank, world, local, dev,
                                       mode=name if world > 1 else 'allgather'), []
         if name == 'p2p-split':
@@ -204,7 +204,7 @@ def main():
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
         calibration, best = {}, None
         ref_sum = None
-        for name in ('allgather', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4'):
+        for name in ('allgather', 'allgatherv', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4'):
             cand, hs, err = None, [], None
             try:
                 cand, hs = make_op(name)

@@ -13,6 +13,8 @@ step of the path:
              one so a single all_gather_into_tensor moves them (xGMI is point-to-point: the
              7 peers' slices arrive over 7 links concurrently), then unpadded into y by one
              concatenation kernel.
+  allgatherv the slices of y themselves as the output list of one all_gather (RCCL: a group of broadcasts for
+             slices of different lengths): no padding, no concatenation.
   allreduce  the form BASELINE.json's north_star names: each rank writes its slice into a
              zeroed full-length y and the ranks sum.  Same result (the slices are disjoint, so
              every sum has one non-zero term and is exact), about twice the bytes per link.
@@ -35,7 +37,7 @@ class RowPartitionedSpMV:
         local_spmv(x, out): computes this rank's rows into `out` (a float64 tensor of
         bounds[rank+1]-bounds[rank] entries on `device`); asynchronous on the current stream.
         """
-        assert len(bounds) == world + 1 and mode in ('allgather', 'allreduce')
+        assert len(bounds) == world + 1 and mode in ('allgather', 'allgatherv', 'allreduce')
         self.bounds = [int(b) for b in bounds]
         self.rank, self.world, self.mode, self.group = rank, world, mode, group
         self.local_spmv = local_spmv
@@ -52,6 +54,12 @@ class RowPartitionedSpMV:
             # the slices of `gath` that make up y, in rank order: unpadded by ONE concatenation kernel
             self.pieces = [self.gath[g * self.maxlen:g * self.maxlen + self.lens[g]] for g in range(world)
                            if self.lens[g]]
+
+        if world > 1 and mode == 'allgatherv':
+            # every rank's slice of y itself, as the output list of ONE all_gather: with slices of different lengths
+            # RCCL runs it as a group of broadcasts straight into place (nothing padded, nothing concatenated);
+            # gloo only takes equal lengths
+            self.views = [self.y[self.bounds[g]:self.bounds[g + 1]] for g in range(world)]
 
     def _local(self, x, out):
         if self.timing and out.is_cuda:
@@ -81,6 +89,10 @@ class RowPartitionedSpMV:
             dist.all_gather_into_tensor(self.gath, self.loc, group=self.group)
             if self.pieces:
                 torch.cat(self.pieces, out=self.y)
+            return self.y
+        if self.mode == 'allgatherv':
+            self._local(x, self.views[self.rank])
+            dist.all_gather(self.views, self.views[self.rank], group=self.group)
             return self.y
         # allreduce: zero what the previous step left in the other ranks' slices
         if self.r0 > 0:

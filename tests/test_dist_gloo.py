@@ -176,3 +176,41 @@ def test_split_phase_row_partitioned_spmv_gloo(tmp_path, world):
     ref = O.mult_vec(6000, 5000, full['rowptrs'].numpy(), full['colinds'].numpy(), full['values'].numpy(), x)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f'ys_{r}.npy'), ref)
+
+
+def _worker_equal(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from csr_amd import synth
+        from csr_amd.dist import RowPartitionedSpMV
+        from oracle import oracle as O
+        full = synth.powerlaw_csr(6000, 5000, 90000, device='cpu')
+        x = synth.dense_vector(5000, device='cpu')
+        rp, ci, vs = (full[k].numpy() for k in ('rowptrs', 'colinds', 'values'))
+        bounds = [6000 * g // world for g in range(world + 1)]      # equal slices: the only kind gloo's all_gather takes
+        a, b = bounds[rank], bounds[rank + 1]
+
+        def local_spmv(xt, out):
+            out.copy_(torch.from_numpy(O.mult_vec(b - a, 5000, rp[a:b + 1] - rp[a], ci[rp[a]:rp[b]], vs[rp[a]:rp[b]], xt.numpy())))
+
+        op = RowPartitionedSpMV(bounds, rank, world, local_spmv, 'cpu', mode='allgatherv')
+        y1 = op.step(x).clone()
+        assert torch.equal(y1, op.step(x))
+        np.save(os.path.join(out_dir, f'yv_{rank}.npy'), y1.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgatherv_mode_gloo(tmp_path):
+    "the slices of y as the output list of one all_gather (equal slices here: gloo; RCCL also takes unequal ones)"
+    from csr_amd import synth
+    from oracle import oracle as O
+    mp.spawn(_worker_equal, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    full = synth.powerlaw_csr(6000, 5000, 90000, device='cpu')
+    x = synth.dense_vector(5000, device='cpu').numpy()
+    ref = O.mult_vec(6000, 5000, full['rowptrs'].numpy(), full['colinds'].numpy(), full['values'].numpy(), x)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'yv_{r}.npy'), ref)
