@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
     ap.add_argument('--collective', default='auto',
-                    choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
+                    choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p', 'p2p-split', 'ipc-push', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
                     help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
@@ -89,7 +89,8 @@ def main():
 
     from csr_amd import synth
     from csr_amd._lib import lib, check, handle_t, SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR
-    from csr_amd.dist import (RowPartitionedSpMV, PipelinedRowPartitionedSpMV, SplitPhaseRowPartitionedSpMV, chunk_cuts,
+    from csr_amd.dist import (RowPartitionedSpMV, PipelinedRowPartitionedSpMV, SplitPhaseRowPartitionedSpMV,
+                              IpcPushRowPartitionedSpMV, chunk_cuts,
                               hip_local_spmv, hip_local_spmv_parts)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -188,6 +189,9 @@ def main():
         if name == 'p2p-split':
             run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
             return SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
+        if name == 'ipc-push':
+            run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
+            return IpcPushRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
         exch, _, k = name.partition('-k')
         K = int(k) if k else 1
         if K == 1:
@@ -204,7 +208,7 @@ def main():
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
         calibration, best = {}, None
         ref_sum = None
-        for name in ('allgather', 'allgatherv', 'p2p', 'p2p-split', 'p2p-k2', 'p2p-k4'):
+        for name in ('allgather', 'allgatherv', 'p2p', 'p2p-split', 'ipc-push', 'p2p-k2', 'p2p-k4'):
             cand, hs, err = None, [], None
             try:
                 cand, hs = make_op(name)

@@ -21,7 +21,8 @@ step of the path:
 
 PipelinedRowPartitionedSpMV: point-to-point exchange straight into y (no padding, no concatenation) and/or the
 exchange pipelined behind the product (K chunks per rank).  SplitPhaseRowPartitionedSpMV: the exchange hidden
-behind the tiers' part of one product (csrk_spmv_device_part).
+behind the tiers' part of one product (csrk_spmv_device_part).  IpcPushRowPartitionedSpMV: the same with the slices
+pushed into the peers' (IPC-mapped) buffers by device copies over xGMI instead of collective kernels.
 
 torch is plumbing here (device buffers + the collective); the product kernels run behind
 `local_spmv`, a callable that writes y[r0:r1] = A[r0:r1, :] x into the buffer it is given.
@@ -298,6 +299,119 @@ class SplitPhaseRowPartitionedSpMV:
                 torch.index_select(self.hv_all, 0, self.src_pos, out=self.tmp)
                 self.y.index_copy_(0, self.dst_rows, self.tmp)
         return self.y
+
+
+class IpcPushRowPartitionedSpMV:
+    """
+    The bulk of the exchange as point-to-point DEVICE COPIES over xGMI instead of collective kernels.  Every rank
+    maps its peers' y buffers into its own address space once (torch's IPC tensor sharing: hipIpcGetMemHandle /
+    hipIpcOpenMemHandle underneath) and then, per step, PUSHES its slice into each peer's buffer with one asynchronous
+    copy per peer, each on a stream of its own -- the copy engines drive the seven links of the full mesh, no CU is
+    taken from the product, which matters here because the product's persistent workgroups hold nearly all of a CU's
+    LDS and a collective's kernel can find itself waiting for them.  The product is split as in
+    SplitPhaseRowPartitionedSpMV: the pushes start after part 1 and run beside part 2; the cut rows' values follow
+    in one small all-gather, which is also what tells a rank that every peer's push into its buffer has completed
+    (a rank contributes to it only after its own pushes, in stream order, and nobody's all-gather completes without
+    everybody's contribution).  Two y buffers alternate, so a peer one step ahead writes into the buffer its
+    neighbours are not reading; the per-step all-gather keeps ranks within one step of each other.
+    """
+
+    def __init__(self, bounds, rank, world, local_part, cut_rows, device, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        assert len(bounds) == world + 1 and world > 1
+        self.bounds = [int(b) for b in bounds]
+        self.rank, self.world, self.group = rank, world, group
+        self.local_part = local_part
+        self.nrows = self.bounds[-1]
+        self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        self.ys = [torch.zeros(self.nrows, dtype=torch.float64, device=device) for _ in range(2)]
+        self.k = 0
+        self.timing = False
+        self._ev = []
+        # the peers' buffers: handles travel as pickled (rebuild function, arguments) pairs
+        metas = [reduce_tensor(y) for y in self.ys]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, metas, group=group)
+        self.peer = [[None] * world for _ in range(2)]
+        err = None
+        try:
+            for g in range(world):
+                if g != rank:
+                    for b in range(2):
+                        fn, args = gathered[g][b]
+                        t = fn(*args)
+                        assert t.numel() == self.nrows and t.dtype == torch.float64
+                        self.peer[b][g] = t
+        except Exception as e:                # every rank must learn of it before anyone enters a collective alone
+            err = e
+        bad = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if bad.item() > 0:
+            raise RuntimeError(f'peer buffers could not be mapped: {err!r}')
+        self.peers = [(rank + d) % world for d in range(1, world)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in self.peers]
+        # the cut rows of every rank (global indices), as in SplitPhaseRowPartitionedSpMV
+        cut = cut_rows.to(device=device, dtype=torch.int64) + self.r0
+        n_mine = int(cut.numel())
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        counts[rank] = n_mine
+        dist.all_reduce(counts, group=group)
+        counts = [int(c) for c in counts.tolist()]
+        self.n_mine, self.maxn = n_mine, max(max(counts), 1)
+        self.my_rows = cut
+        self.hv_loc = torch.zeros(self.maxn, dtype=torch.float64, device=device)
+        self.hv_all = torch.zeros(world * self.maxn, dtype=torch.float64, device=device)
+        pad = torch.zeros(self.maxn, dtype=torch.int64, device=device)
+        pad[:n_mine] = cut
+        rows_all = torch.zeros(world * self.maxn, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(rows_all, pad, group=group)
+        src = [torch.arange(g * self.maxn, g * self.maxn + counts[g], device=device) for g in range(world) if g != rank]
+        self.src_pos = torch.cat(src)
+        self.dst_rows = rows_all.index_select(0, self.src_pos)
+        self.tmp = torch.zeros(int(self.src_pos.numel()), dtype=torch.float64, device=device)
+
+    def compute_ms(self):
+        if not self._ev:
+            return 0.0
+        ms = sum(a.elapsed_time(b) for a, b in self._ev) * 2 / len(self._ev)
+        self._ev = []
+        return ms
+
+    def _part(self, x, out, part):
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.local_part(x, out, part)
+            e1.record()
+            self._ev.append((e0, e1))
+        else:
+            self.local_part(x, out, part)
+
+    def step(self, x):
+        "y = A x, complete on every rank; returns this step's y buffer (the two buffers alternate)"
+        b = self.k & 1
+        self.k += 1
+        y = self.ys[b]
+        mine = y[self.r0:self.r1]
+        cur = torch.cuda.current_stream(y.device)
+        self._part(x, mine, 1)
+        if self.r1 > self.r0:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            for st, g in zip(self.streams, self.peers):
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    self.peer[b][g][self.r0:self.r1].copy_(mine, non_blocking=True)
+        self._part(x, mine, 2)
+        if self.n_mine:
+            torch.index_select(y, 0, self.my_rows, out=self.hv_loc[:self.n_mine])
+        for st in self.streams:
+            cur.wait_stream(st)
+        dist.all_gather_into_tensor(self.hv_all, self.hv_loc, group=self.group)      # values + "my pushes are done"
+        if self.tmp.numel():
+            torch.index_select(self.hv_all, 0, self.src_pos, out=self.tmp)
+            y.index_copy_(0, self.dst_rows, self.tmp)
+        return y
 
 
 def chunk_cuts(rowptrs, K):

@@ -173,7 +173,7 @@ def test_transpose_config5_full_size():
         check(lib.csrk_trim_cache())
 
 
-@pytest.mark.parametrize('collective', ['auto', 'p2p-k2', 'p2p-split'])
+@pytest.mark.parametrize('collective', ['auto', 'p2p-k2', 'p2p-split', 'ipc-push'])
 def test_bench_two_ranks_plumbing(collective):
     """
     bench.py's N > 1 path end to end on ONE GPU: two ranks share cuda:0 over gloo (RCCL refuses two ranks on
