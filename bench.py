@@ -48,8 +48,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=500)      # 0.3 s of SpMVs: the first ~50 run 2 % slower (clocks, caches)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the matrix (testing only; INVALID as a result)')
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
@@ -271,8 +271,9 @@ def main():
         barrier()
         # kernel event pairs on every 5th step (they cost ~20 us per timed SpMV: 0.713 vs 0.693 ms with / without)
         if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-            check(lib.csrk_spmv_profile_every(hp, 5 if args.steps >= 10 else 1))
-            check(lib.csrk_spmv_profile_begin(hp, args.steps))
+            every = 5 if args.steps >= 10 else 1
+            check(lib.csrk_spmv_profile_every(hp, every))
+            check(lib.csrk_spmv_profile_begin(hp, args.steps // every + 2))
         op.timing = world > 1
         t0 = time.perf_counter()
         for _ in range(args.steps):

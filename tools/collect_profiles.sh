@@ -6,8 +6,8 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/kt.log 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $OUT/tcc -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/tcc.log 2>&1
