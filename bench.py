@@ -22,8 +22,8 @@ One JSON line is printed by rank 0:
              tier 0, panel tier 1: DESIGN.md section 4): that kernel's own algorithmic bytes per launch
              (12 B per entry it processes + its row pointers / partials + x once) divided by its
              mean duration, measured live with hipEvent pairs recorded around that kernel on its
-             launch stream during every 5th timed step (csrk_spmv_profile_every/begin/end: a pair
-             costs ~3 us on the stream, six per step would add 3 % to the step); `all_kernels`
+             launch stream during every 10th timed step (csrk_spmv_profile_every/begin/end4: a pair
+             costs ~3 us on the stream, eight per step would add 4 % to the step); `all_kernels`
              lists every kernel, `whole_spmv` the same fraction for the whole 2.60 GB,
              `hbm_gbs_end_to_end` is 2.60 GB / step time;
              peak = 8000 GB/s (HBM3E spec); traffic = per-launch HBM bytes from the committed
@@ -269,9 +269,9 @@ def main():
         for _ in range(args.warmup):
             op.step(x)
         barrier()
-        # kernel event pairs on every 5th step (they cost ~20 us per timed SpMV: 0.713 vs 0.693 ms with / without)
+        # kernel event pairs on every 10th step of a long run (recorded on every step they cost ~25 us per SpMV)
         if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-            every = 5 if args.steps >= 10 else 1
+            every = 10 if args.steps >= 100 else (5 if args.steps >= 10 else 1)
             check(lib.csrk_spmv_profile_every(hp, every))
             check(lib.csrk_spmv_profile_begin(hp, args.steps // every + 2))
         op.timing = world > 1
