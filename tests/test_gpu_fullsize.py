@@ -206,3 +206,42 @@ def test_bench_two_ranks_plumbing(collective):
     else:
         # chunk handles (views of the rank's arrays) + point-to-point exchange straight into y
         assert d['multi_gpu']['exchange'] == collective
+
+
+def test_cold_staging_and_stream_forms_are_bit_neutral(monkeypatch):
+    """
+    The staging pass only changes WHERE the light stream reads an x value from (xg instead of x / the pack), and
+    the 16-bit accumulator stream only how a heavy row's index is stored: with staging off the result must be
+    the same bit for bit, on a matrix large enough for every part of the plan (tiers, pack, staging) to exist.
+    Also the two-part product (csrk_spmv_device_part 1 then 2) at this size.
+    """
+    import torch
+    from csr_amd import synth
+    from csr_amd._lib import lib, check
+    dev = 'cuda'
+    n, nnz = 3_000_000, 60_000_000
+    m = synth.powerlaw_csr(n, n, nnz, device=dev)
+    x = synth.dense_vector(n, device=dev, stream=3)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CSRK_LS_STAGE', mode)
+        h = _handle(m, n, n)
+        try:
+            y = torch.empty(n, dtype=torch.float64, device=dev)
+            for _ in range(3):
+                _spmv(h, x, y)
+            torch.cuda.synchronize()
+            st = (C.c_int64 * 25)()
+            check(lib.csrk_spmv_plan_stats(h, st, 25))
+            assert st[2] > 0 and st[16] > 0 and st[20] == 1      # tiers, pack, light stream
+            assert (st[24] > 0) == (mode == '1')                 # staged entries only with staging on
+            out[mode] = y.clone()
+            if mode == '1':
+                yp = torch.full((n,), 3.0, dtype=torch.float64, device=dev)
+                check(lib.csrk_spmv_device_part(h, x.data_ptr(), yp.data_ptr(), None, 1))
+                check(lib.csrk_spmv_device_part(h, x.data_ptr(), yp.data_ptr(), None, 2))
+                torch.cuda.synchronize()
+                assert torch.equal(yp, y)
+        finally:
+            check(lib.csrk_free(h))
+    assert torch.equal(out['1'], out['0'])
