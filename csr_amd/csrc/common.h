@@ -53,7 +53,8 @@ void set_error(const char *fmt, ...);
 // served by the smallest cached block of [n, 1.5 n] bytes on the same device, freed blocks go back to
 // the pool, and the pool is trimmed above 16 GiB or by csrk_trim_cache().  All pooled memory is used
 // in stream order on the default stream, so a recycled block is never touched by an earlier kernel
-// that is still running.
+// that is still running; launches on a caller's stream mark their handle (Matrix::used_user_stream) and the
+// handle's blocks are returned only after a device-wide synchronisation.
 hipError_t pool_alloc(void **p, size_t n);
 void pool_free(void *p);
 
@@ -115,6 +116,10 @@ struct Matrix {
     int spmv_algo = CSRK_SPMV_AUTO;
     int spmv_calls = 0;            // SpMV launches on this handle (the long-row split is built on the 2nd)
     SpmmPlan *spmm_plan = nullptr;
+    // A launch was issued on a caller's stream: the caching allocator recycles blocks in default-stream order only,
+    // and a non-blocking stream is not ordered with the default one, so the handle's memory (arrays, plans, scratch)
+    // goes back to the pool only after the device has drained (csrk_free, plan invalidation, scratch growth).
+    bool used_user_stream = false;
 
     size_t ptr_bytes() const { return ptr64 ? 8 : 4; }
     size_t val_bytes() const { return val_type == CSRK_VAL_F64 ? 8 : (val_type == CSRK_VAL_F32 ? 4 : 0); }
@@ -129,6 +134,8 @@ void free_spmm_plan(SpmmPlan *p);
 // that changes the matrix in place -- unit_rows, center_rows, order_columns -- must call this).  Waits for the
 // device first: a launch may still be reading the plan.  Caller holds m->mu.
 void invalidate_plans(Matrix *m);
+// Wait for every stream of the device if a caller's stream ever launched on this handle (before its memory is recycled).
+void drain_user_streams(Matrix *m);
 
 // Create an owning matrix with freshly allocated (uninitialised) device arrays.
 int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_type, Matrix **out);

@@ -138,6 +138,13 @@ Matrix *from_handle(csrk_handle_t h)
     return m;
 }
 
+void drain_user_streams(Matrix *m)
+{
+    if (!m->used_user_stream) return;
+    (void)hipDeviceSynchronize();
+    m->used_user_stream = false;
+}
+
 void invalidate_plans(Matrix *m)
 {
     if (!m->spmv_plan && !m->spmm_plan) return;
@@ -312,6 +319,9 @@ int csrk_free(csrk_handle_t h)
     if (h == 0) return CSRK_OK;
     Matrix *m = from_handle(h);
     if (!m) return CSRK_ERR_INVALID;
+    // launches on a caller's (possibly non-blocking) stream may still be reading the arrays and plans that
+    // ~Matrix hands back to the caching allocator, whose next user runs in default-stream order
+    drain_user_streams(m);
     delete m;
     return CSRK_OK;
 }

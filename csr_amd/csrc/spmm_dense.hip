@@ -265,34 +265,40 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     // heavy-row blocking pays when the B rows a block needs fit in L2 but B as a whole does not
     if (!(env && env[0] == '0') && !m->spmm_plan && ((int64_t)m->ncols * k * 8 > (64ll << 20) || (env && env[0] == '1')))
         CSRK_TRY(spmv_tier0_view(m, &hv));
-    {
-        std::lock_guard<std::mutex> lk(m->mu);
-        if (!m->spmm_plan) {
-            SpmmPlan *np = new (std::nothrow) SpmmPlan();
-            CSRK_REQUIRE(np, "out of host memory");
-            if (hv.on && hv.pairs * (int64_t)k * 8 <= (4ll << 30)) np->heavy = hv;
-            // default stream + completion before use: see the caching allocator's contract (common.h)
-            int rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
-            if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
-            if (rc != CSRK_OK) {
-                delete np;
-                return rc;
-            }
-            m->spmm_plan = np;
+    // The launch group below shares the plan's partial-panel buffers (hpart, part): the per-handle lock is held
+    // across it, as spmv_dispatch does, so that concurrent callers are ordered by the stream instead of interleaving
+    // (csrk.h: calls on the same handle serialise).
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (s) m->used_user_stream = true;
+    if (!m->spmm_plan) {
+        SpmmPlan *np = new (std::nothrow) SpmmPlan();
+        CSRK_REQUIRE(np, "out of host memory");
+        if (hv.on && hv.pairs * (int64_t)k * 8 <= (4ll << 30)) np->heavy = hv;
+        // default stream + completion before use: see the caching allocator's contract (common.h)
+        int rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
+        if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
+        if (rc != CSRK_OK) {
+            delete np;
+            return rc;
         }
-        p = m->spmm_plan;
-        if (p->heavy.on && p->hpart_k < k) {
-            if (p->heavy.pairs * (int64_t)k * 8 > (4ll << 30)) {
-                set_error("panel width %d too large for the heavy-row partial buffer of this plan", k);
-                return CSRK_ERR_UNSUPPORTED;
-            }
-            CSRK_TRY(p->hpart.alloc((size_t)p->heavy.pairs * k * 8));
-            p->hpart_k = k;
+        m->spmm_plan = np;
+    }
+    p = m->spmm_plan;
+    // a wider panel than any before needs larger partial buffers: earlier launches (any stream) may still be using the
+    // old blocks, which DevBuf::alloc returns to the pool at once -- wait for the device first
+    const bool grow_h = p->heavy.on && p->hpart_k < k, grow_p = p->n_multi > 0 && p->part_k < k;
+    if ((grow_h && p->hpart.p) || (grow_p && p->part.p)) CSRK_HIP(hipDeviceSynchronize());
+    if (grow_h) {
+        if (p->heavy.pairs * (int64_t)k * 8 > (4ll << 30)) {
+            set_error("panel width %d too large for the heavy-row partial buffer of this plan", k);
+            return CSRK_ERR_UNSUPPORTED;
         }
-        if (p->n_multi > 0 && p->part_k < k) {           // some row is split: partial panels needed
-            CSRK_TRY(p->part.alloc((size_t)p->n_multi * k * 8));
-            p->part_k = k;
-        }
+        CSRK_TRY(p->hpart.alloc((size_t)p->heavy.pairs * k * 8));
+        p->hpart_k = k;
+    }
+    if (grow_p) {           // some row is split: partial panels needed
+        CSRK_TRY(p->part.alloc((size_t)p->n_multi * k * 8));
+        p->part_k = k;
     }
     if (p->heavy.on) {
         const Tier0View &hvw = p->heavy;

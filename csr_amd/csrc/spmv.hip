@@ -3082,7 +3082,10 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     std::lock_guard<std::mutex> lk(m->mu);
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan_locked(m, s, &p, true));
-    p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
+    if (s) m->used_user_stream = true;
+    // every n-th PRODUCT is timed: a product issued in two parts (part 1, then part 2) is one step, so part 2 keeps
+    // the decision taken for its part 1 instead of counting as a call of its own
+    if (part != 2) p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
 #define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s, part)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);

@@ -173,3 +173,20 @@ def uniform_csr(nrows, ncols, nnz, seed=20261003, device='cpu'):
     vals = hash_uniform(torch.arange(nnz, device=device, dtype=torch.int64), seed, 2) * 2.0 - 1.0
     return dict(nrows_total=nrows, ncols=ncols, nnz_total=nnz, row_begin=0, row_end=nrows,
                 rowptrs=rowptr.to(torch.int32), colinds=cols, values=vals)
+
+
+ML25M_SHAPE = (162_541, 59_047, 25_000_095)
+
+
+def movielens_like(device='cpu', values=True):
+    """
+    BASELINE.json configs[4]: a MovieLens-25M-shaped ratings matrix -- 162 541 users x
+    59 047 items, nnz 25 000 095, user activity and item popularity both power-law, values in {0.5, 1.0, .. 5.0}.
+    Returns the powerlaw_csr dict plus nrows.
+    """
+    nr, nc, nnz = ML25M_SHAPE
+    m = powerlaw_csr(nr, nc, nnz, device=device, alpha=0.9, max_degree=7000, values=values)
+    if values:
+        m['values'] = (torch.floor((m['values'] + 1.0) * 5.0).clamp_(0, 9) + 1.0) * 0.5
+    m['nrows'] = nr
+    return m

@@ -438,6 +438,36 @@ ORC_EXPORT void orc_spmm_dense(int32_t nrows, const int64_t *rp, const int32_t *
 }
 
 /* ---------------------------------------------------------------------------------
+ * from_coo: csr/structure.py:11-32 (_from_coo_structure), :35-58 (_from_coo_values), the
+ * ingest behind CSR.from_coo (csr/csr.py:138-169).  Counting sort by row: histogram
+ * (:15-17), running sum into rowptrs (:19-21), then one pass over the entries IN INPUT
+ * ORDER with a per-row cursor (:23-30) -- so the entries of a row keep their input order
+ * (stable), duplicates included.  Values are copied bit for bit whatever their element
+ * size `vsize` (vs == NULL: structure only).  rowptrs come out int64 here, as in the
+ * reference (:19); the CSR constructor then narrows them to int32 when nnz fits
+ * (csr/csr.py:88-93) -- the Python wrapper does the same.
+ * ------------------------------------------------------------------------------- */
+ORC_EXPORT int orc_from_coo(int32_t nrows, int64_t nnz, const int32_t *rows, const int32_t *cols, const void *vs,
+                            int32_t vsize, int64_t *rowptrs, int32_t *out_cols, void *out_vs)
+{
+    int64_t *rpos = (int64_t *)calloc((size_t)nrows + 1, sizeof(int64_t));
+    if (!rpos) return -1;
+    for (int64_t i = 0; i <= nrows; i++) rowptrs[i] = 0;
+    for (int64_t i = 0; i < nnz; i++) rowptrs[rows[i] + 1] += 1;                 /* counts[r] += 1 */
+    for (int32_t i = 0; i < nrows; i++) rowptrs[i + 1] += rowptrs[i];            /* rowptrs[i+1] = rowptrs[i] + counts[i] */
+    for (int32_t i = 0; i < nrows; i++) rpos[i] = rowptrs[i];
+    for (int64_t i = 0; i < nnz; i++) {
+        const int32_t row = rows[i];
+        const int64_t pos = rpos[row];
+        out_cols[pos] = cols[i];
+        if (vs) memcpy((char *)out_vs + (size_t)pos * vsize, (const char *)vs + (size_t)i * vsize, (size_t)vsize);
+        rpos[row] += 1;
+    }
+    free(rpos);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------
  * pick_rows: csr/structure.py:84-117 (_pick_rows_nvs) and :120-149 (_pick_rows).
  * First pass sums the picked rows' lengths (:89-94 / :125-130); second pass copies each
  * picked row's colinds (and values, any element size `vsize`; vs == NULL: structure

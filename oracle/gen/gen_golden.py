@@ -252,6 +252,66 @@ def gen_pick(n=40):
     np.savez_compressed(os.path.join(OUT, 'pick.npz'), **d)
 
 
+def gen_coo(n=36):
+    """
+    CSR.from_coo (csr/csr.py:138-169 -> csr/structure.py:11-67): the COO INPUTS and the reference's CSR.  Unlike
+    draw_csr's unique coordinates these draws repeat (i, j) pairs and come in arbitrary order, so the stable
+    counting sort's order (entries of a row keep their input order, structure.py:24-31 / :49-56) is observable.
+    """
+    rng = np.random.default_rng(60061)
+    d = {'n': np.array(n)}
+    for c in range(n):
+        nrows, ncols = int(rng.integers(1, 81)), int(rng.integers(1, 81))
+        nnz = int(rng.integers(0, 4 * max(nrows, ncols) + 1))
+        if c == 0:
+            nnz = 0                                           # nothing at all
+        if c == 1:
+            nrows, nnz = 1, 17                                # every entry in one row
+        rows = rng.integers(0, nrows, size=nnz).astype(np.int32)          # duplicates, unsorted
+        cols = rng.integers(0, ncols, size=nnz).astype(np.int32)
+        if c % 5 == 2 and nnz:                                # sorted by row already, columns descending
+            o = np.lexsort((-cols, rows))
+            rows, cols = rows[o], cols[o]
+        kind = c % 3                                          # f8 / f4 / structure only
+        vals = None if kind == 2 else rng.uniform(-1.0e3, 1.0e3, size=nnz).astype('f8' if kind == 0 else 'f4')
+        shape = None if (c % 7 == 3 and nnz) else (nrows, ncols)         # inferred shape (csr.py:160-161)
+        m = CSR.from_coo(rows, cols, vals, shape)
+        d[f'c{c}_rows'], d[f'c{c}_cols'] = rows, cols
+        if vals is not None:
+            d[f'c{c}_vals'] = vals
+        d[f'c{c}_shape_given'] = np.array(shape is not None)
+        put(d, f'c{c}_out_', m)
+    np.savez_compressed(os.path.join(OUT, 'coo.npz'), **d)
+
+
+def gen_spmm_dense(n=12):
+    """
+    The dense-panel product of BASELINE.json configs[2] through the reference's own entry point: B [ncols x k] handed to
+    K.mult_ab as a fully populated CSR (csr/kernels/numba/multiply.py:13-38; numeric recurrence :110-122), the raw
+    product (explicit zeros kept) densified.  k in {1, 7, 64}.
+    """
+    rng = np.random.default_rng(64064)
+    d = {'n': np.array(n)}
+    for c in range(n):
+        k = (1, 7, 64)[c % 3]
+        A = draw_csr(rng, values=True, dtype='f4' if c % 4 == 3 else 'f8')
+        B = rng.uniform(-1.0, 1.0, size=(A.ncols, k))
+        if c == 5:
+            B[rng.integers(0, A.ncols), :] = 0.0              # a zero row of B: explicit zeros in the product
+        Bc = CSR(A.ncols, k, A.ncols * k, np.arange(A.ncols + 1, dtype=np.int32) * k,
+                 np.tile(np.arange(k, dtype=np.int32), A.ncols), B.reshape(-1).copy())
+        raw = K.mult_ab(K.to_handle(A), K.to_handle(Bc))
+        Cd = np.zeros((A.nrows, k))
+        rp, ci, vs = np.asarray(raw.rowptrs), np.asarray(raw.colinds), np.asarray(raw.values)
+        for i in range(A.nrows):
+            Cd[i, ci[rp[i]:rp[i + 1]]] = vs[rp[i]:rp[i + 1]]
+        put(d, f'c{c}_a_', A)
+        d[f'c{c}_B'] = B
+        d[f'c{c}_C'] = Cd
+        d[f'c{c}_raw_nnz'] = np.array(raw.nnz)
+    np.savez_compressed(os.path.join(OUT, 'spmm_dense.npz'), **d)
+
+
 if __name__ == '__main__':
     gen_kat()
     gen_spmv()
@@ -261,5 +321,7 @@ if __name__ == '__main__':
     gen_spgemm()
     gen_shard()
     gen_pick()
+    gen_coo()
+    gen_spmm_dense()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -256,6 +256,29 @@ def pick_rows(rowptrs, colinds, values, rows, include_values=True):
     return orp.astype(np.int32), oci, ovs
 
 
+def from_coo(nrows, rows, cols, values=None):
+    """
+    csr/structure.py:11-67 as reached from CSR.from_coo (csr/csr.py:138-169): -> (rowptrs, colinds, values-or-None).
+    Entries of a row keep their input order; values keep their dtype; rowptrs are int32 unless nnz > INT32_MAX
+    (the CSR constructor's narrowing, csr/csr.py:88-93).
+    """
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    nnz = len(rows)
+    assert len(cols) == nnz and (values is None or len(values) == nnz)
+    vs = None if values is None else np.ascontiguousarray(values)
+    rp = np.empty(nrows + 1, dtype=np.int64)
+    oci = np.empty(nnz, dtype=np.int32)
+    ovs = None if vs is None else np.empty(nnz, dtype=vs.dtype)
+    rc = lib().orc_from_coo(C.c_int32(nrows), C.c_int64(nnz), _p(rows, _i32p), _p(cols, _i32p),
+                            None if vs is None else vs.ctypes.data_as(C.c_void_p),
+                            C.c_int32(0 if vs is None else vs.dtype.itemsize), _p(rp, _i64p), _p(oci, _i32p),
+                            None if ovs is None else ovs.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise MemoryError('oracle from_coo')
+    return (rp.astype(np.int32) if nnz <= np.iinfo(np.int32).max else rp), oci, ovs
+
+
 def spmm_dense(nrows, rowptrs, colinds, values, B):
     "C = A @ B for dense row-major B (restates multiply.py:110-122 with B fully populated)."
     rp = _rp64(rowptrs)

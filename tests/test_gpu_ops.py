@@ -279,6 +279,48 @@ def test_spgemm_vs_oracle(case):
     assert np.all(np.abs(C.values - rvs) <= 1e-12 * bsorted + 1e-300)
 
 
+def test_mult_abt_movielens_shape_blocks():
+    """
+    BASELINE.json configs[4], the mult_abt half, on its own workload shape: row blocks of a MovieLens-25M-shaped
+    matrix (162 541 x 59 047, both degree distributions power-law, values in {0.5 .. 5.0}) multiplied as
+    A[block] . B[block]^T through csrk_spgemm_abt (csr/kernels/numba/multiply.py:41-57 = mult_ab(A, transpose(B))),
+    blocks because the product's row pointers are int32 (multiply.py:28).  Against the oracle's own
+    transpose + SMMP: row pointers bit-equal, column sets equal (ascending here, reverse-discovery there),
+    values to 1e-12 of sum |a||b|.
+    """
+    from oracle import oracle as O
+    from csr_amd import CSR, synth
+    from csr_amd.kernels import hip as K
+    m = synth.movielens_like(device='cpu')
+    M = CSR(m['nrows'], m['ncols'], int(m['colinds'].numel()), m['rowptrs'].numpy(), m['colinds'].numpy(),
+            m['values'].numpy(), _cast=False)
+    assert (M.nrows, M.ncols) == (162541, 59047)
+    for a0, a1, b0, b1 in ((0, 2000, 0, 20000), (90000, 90300, 40000, 46000)):
+        A, B = M.subset_rows(a0, a1), M.subset_rows(b0, b1)
+        ah, bh = K.to_handle(A), K.to_handle(B)
+        try:
+            ch = K.mult_abt(ah, bh)
+            Cm = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(ah)
+            K.release_handle(bh)
+        bt = O.transpose(B.nrows, B.ncols, B.rowptrs, B.colinds, B.values)
+        nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
+        assert (Cm.nrows, Cm.ncols) == (A.nrows, B.nrows) == (nr, nc)
+        assert Cm.rowptrs.dtype == np.int32 and np.array_equal(Cm.rowptrs, crp)
+        rci, rvs = sort_within_rows(crp, cci, cvs)
+        assert np.array_equal(Cm.colinds, rci)
+        _, _, _, _, babs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values)),
+                                     (bt[0], bt[1], bt[2], bt[3], np.abs(bt[4])))
+        _, bsorted = sort_within_rows(crp, cci, babs)
+        assert np.all(np.abs(Cm.values - rvs) <= 1e-12 * bsorted + 1e-300)
+        # the caller's path (csr/csr.py:524-567): same product after _filter_zeros
+        P = A.multiply(B, transpose=True)
+        keep = rvs != 0.0
+        assert P.nnz == int(keep.sum()) and np.array_equal(P.colinds, rci[keep])
+
+
 def test_multiply_sharded(golden):
     "csr/csr.py:558-567: row sharding above max_nnz + _assemble_shards (tests/test_mkl.py:82-91)"
     from csr_amd.kernels import hip as K
@@ -442,6 +484,27 @@ def test_in_place_ops_invalidate_the_spmv_plan(monkeypatch):
 
 # ---- dense-panel SpMM ------------------------------------------------------------------------------------
 
+def test_spmm_dense_golden(golden):
+    """
+    csrk_spmm_dense against the reference's own mult_ab(A, CSR(B)) with B fully populated
+    (csr/kernels/numba/multiply.py:13-38, :110-122), densified: k in {1, 7, 64}, f8 and f4 A.  fp64: 1e-6 of the
+    summed magnitudes (north_star), asserted at 1e-12.
+    """
+    from csr_amd.kernels import hip as K
+    g = golden('spmm_dense')
+    for c in range(int(g['n'])):
+        a = Mat(g, f'c{c}_a_')
+        B, Cref = g[f'c{c}_B'], g[f'c{c}_C']
+        h = K.to_handle(_csr(a))
+        try:
+            Cm = K.mult_dense(h, B)
+        finally:
+            K.release_handle(h)
+        bound = np.abs(a.dense()) @ np.abs(B)
+        assert Cm.shape == Cref.shape
+        assert np.all(np.abs(Cm - Cref) <= 1e-12 * bound + 1e-300), c
+
+
 @pytest.mark.parametrize('k', [64, 7, 130])
 def test_spmm_dense(k):
     from oracle import oracle as O
@@ -464,8 +527,31 @@ def test_spmm_dense(k):
 
 # ---- COO ingest on the device ----------------------------------------------------------------------------
 
+def test_from_coo_golden(golden):
+    "csrk_from_coo against the reference's CSR.from_coo outputs (csr/csr.py:138-169), duplicates / unsorted / f4 / None: bit-exact"
+    from csr_amd.kernels import hip as K
+    g = golden('coo')
+    for c in range(int(g['n'])):
+        rows, cols = g[f'c{c}_rows'], g[f'c{c}_cols']
+        vals = g[f'c{c}_vals'] if f'c{c}_vals' in g else None
+        out = Mat(g, f'c{c}_out_')
+        h = K.from_coo(rows, cols, vals, (out.nrows, out.ncols))
+        try:
+            m = K.from_handle(h)
+        finally:
+            K.release_handle(h)
+        assert (m.nrows, m.ncols, m.nnz) == (out.nrows, out.ncols, out.nnz)
+        assert m.rowptrs.dtype == out.rowptrs.dtype and np.array_equal(m.rowptrs, out.rowptrs), c
+        assert np.array_equal(m.colinds, out.colinds), c
+        if vals is None:
+            assert m.values is None
+        else:
+            assert m.values.dtype == out.values.dtype and np.array_equal(m.values, out.values), c
+
+
 def test_from_coo_device(golden):
-    "csr/structure.py:11-67: stable by row (entries keep input order), dtype kept; vs the host ingest and the KAT"
+    "csr/structure.py:11-67 at sizes the goldens do not reach: vs the oracle's restatement (orc_from_coo, pinned) and the KAT"
+    from oracle import oracle as O
     from csr_amd import CSR
     from csr_amd.kernels import hip as K
     g = golden('kat')
@@ -479,22 +565,24 @@ def test_from_coo_device(golden):
     assert np.array_equal(c.values, a.values)
     rng = np.random.default_rng(12)
     for nrows, ncols, nnz, dt in ((300, 200, 5000, np.float64), (70000, 1000, 200000, np.float32),
-                                  (5, 5, 0, np.float64), (100000, 70000, 300000, None)):
+                                  (5, 5, 0, np.float64), (100000, 70000, 300000, None), (3, 2_000_000, 400000, np.float64)):
         rows = rng.integers(0, nrows, size=nnz).astype(np.int32)      # duplicates allowed, unsorted
         cols = rng.integers(0, ncols, size=nnz).astype(np.int32)
         vals = None if dt is None else rng.uniform(-1, 1, size=nnz).astype(dt)
-        ref = CSR.from_coo(rows, cols, vals, (nrows, ncols))           # host: stable numpy argsort by row
+        rp, ci, vs = O.from_coo(nrows, rows, cols, vals)
+        host = CSR.from_coo(rows, cols, vals, (nrows, ncols))          # the package's own host ingest agrees too
+        assert np.array_equal(host.rowptrs, rp) and np.array_equal(host.colinds, ci)
         h = K.from_coo(rows, cols, vals, (nrows, ncols))
         try:
             c = K.from_handle(h)
         finally:
             K.release_handle(h)
         assert (c.nrows, c.ncols, c.nnz) == (nrows, ncols, nnz)
-        assert np.array_equal(c.rowptrs, ref.rowptrs) and np.array_equal(c.colinds, ref.colinds)
+        assert np.array_equal(c.rowptrs, rp) and np.array_equal(c.colinds, ci)
         if dt is None:
             assert c.values is None
         else:
-            assert c.values.dtype == dt and np.array_equal(c.values, ref.values)
+            assert c.values.dtype == dt and np.array_equal(c.values, vs) and np.array_equal(host.values, vs)
     with pytest.raises(ValueError):
         K.from_coo(np.array([5]), np.array([0]), None, (3, 3))
 

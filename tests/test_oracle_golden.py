@@ -192,7 +192,28 @@ def test_shard_golden(golden):
         O.shard_splits(np.array([0, 600, 700]), 500)
 
 
-def test_spmm_dense_matches_spgemm_semantics():
+def test_spmm_dense_golden(golden):
+    """
+    orc_spmm_dense is pinned to the reference itself: K.mult_ab(A, CSR(B)) with B a fully populated CSR
+    (csr/kernels/numba/multiply.py:13-38, numeric recurrence :110-122), densified by oracle/gen/gen_golden.py.
+    Same additions in the same order (work[k] += a * b over A's row in storage order): bit for bit.
+    """
+    g = golden('spmm_dense')
+    ks, f4 = set(), 0
+    for c in range(int(g['n'])):
+        a = Mat(g, f'c{c}_a_')
+        B, Cref = g[f'c{c}_B'], g[f'c{c}_C']
+        assert B.shape[0] == a.ncols and Cref.shape == (a.nrows, B.shape[1])
+        Cm = O.spmm_dense(a.nrows, a.rowptrs, a.colinds, a.values, B)
+        assert np.array_equal(Cm, Cref), c
+        # the raw product keeps explicit zeros: one stored entry per (non-empty row of A, column of B)
+        assert int(g[f'c{c}_raw_nnz']) == int(np.count_nonzero(np.diff(a.rowptrs))) * B.shape[1]
+        ks.add(B.shape[1])
+        f4 += a.values.dtype == np.float32
+    assert ks == {1, 7, 64} and f4 >= 2
+
+
+def test_spmm_dense_matches_dense_product():
     rng = np.random.default_rng(3)
     nr, nc, k = 37, 23, 5
     dense = rng.uniform(-1, 1, (nr, nc)) * (rng.uniform(size=(nr, nc)) < 0.2)
@@ -206,6 +227,35 @@ def test_spmm_dense_matches_spgemm_semantics():
     B = rng.uniform(-1, 1, (nc, k))
     Cm = O.spmm_dense(nr, rp, np.array(ci, dtype=np.int32), np.array(vs), B)
     assert Cm == pytest.approx(dense @ B, rel=1e-12, abs=1e-14)
+
+
+def test_from_coo_golden(golden):
+    """
+    orc_from_coo against the reference's CSR.from_coo (csr/csr.py:138-169 -> csr/structure.py:11-67) on COO inputs
+    with repeated coordinates in arbitrary order: row pointers, column order inside rows (input order kept) and the
+    values' bits and dtype.
+    """
+    g = golden('coo')
+    kinds, dups, inferred, empty = set(), 0, 0, 0
+    for c in range(int(g['n'])):
+        rows, cols = g[f'c{c}_rows'], g[f'c{c}_cols']
+        vals = g[f'c{c}_vals'] if f'c{c}_vals' in g else None
+        out = Mat(g, f'c{c}_out_')
+        assert out.nnz == len(rows)
+        if not bool(g[f'c{c}_shape_given']):
+            assert out.nrows == int(rows.max()) + 1 and out.ncols == int(cols.max()) + 1      # csr/csr.py:160-161
+            inferred += 1
+        rp, ci, vs = O.from_coo(out.nrows, rows, cols, vals)
+        assert rp.dtype == out.rowptrs.dtype and np.array_equal(rp, out.rowptrs), c
+        assert np.array_equal(ci, out.colinds), c
+        if vals is None:
+            assert vs is None and out.values is None
+        else:
+            assert vs.dtype == out.values.dtype == vals.dtype and np.array_equal(vs, out.values), c
+        kinds.add(None if vals is None else vals.dtype.str)
+        dups += len(set(zip(rows.tolist(), cols.tolist()))) < len(rows)
+        empty += len(rows) == 0
+    assert kinds == {None, '<f4', '<f8'} and dups > 10 and inferred >= 3 and empty >= 1
 
 
 def test_pick_rows_golden(golden):
