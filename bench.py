@@ -6,13 +6,17 @@ on a 10M x 10M power-law CSR with nnz = 2e8, through the libcsrk C ABI on MI355X
     python bench.py --gpus N --steps K --warmup W
 
 N = 1 runs in-process; for N > 1 the driver launches one rank per GPU
-(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`), the matrix is
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) -- or, started plainly as
+`python bench.py --gpus N`, bench.py starts that launcher itself as a child process before touching the GPU -- the matrix is
 row-range partitioned (nnz balanced) with x replicated, and one step = local SpMV + the exchange
 that completes y on every rank.  xGMI is point-to-point and the exchange of the 80 MB y is link-bound, so
 how RCCL drives the links decides the step: before the warm-up the candidates of csr_amd/dist.py (padded
-all-gather; point-to-point sends straight into y; the same with the slice travelling while the tiers' part of
-the product runs; the same pipelined behind the product in 2 / 4 chunks per rank) are each timed for 8 steps and the fastest runs the timed region (`multi_gpu.candidates_ms_per_step`;
-`--collective allreduce` forces the all-reduce north_star names, `--collective NAME` any other).
+all-gather; the unpadded all-gather; point-to-point sends straight into y with the slice travelling while the tiers'
+part of the product runs; with --calibrate-all also plain point-to-point, IPC pushes, and the exchange pipelined behind
+the product in 2 / 4 chunks per rank) are each timed for 8 steps and the fastest runs the timed region
+(`multi_gpu.candidates_ms_per_step`; a candidate that fails, disagrees or exceeds --calibrate-seconds is dropped and the
+padded all-gather is the fallback; `--collective allreduce` forces the all-reduce north_star names, `--collective NAME`
+any other).
 The matrix is FIXED as N grows ("scaling": "strong").
 
 One JSON line is printed by rank 0:
@@ -56,6 +60,11 @@ def parse():
     ap.add_argument('--collective', default='auto',
                     choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p', 'p2p-split', 'ipc-push', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
                     help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
+    ap.add_argument('--calibrate-all', action='store_true',
+                    help='N > 1, --collective auto: also time the chunked (p2p-k2, p2p-k4), plain p2p and IPC-push exchanges '
+                         '(each builds extra per-chunk plans); default: allgather, allgatherv, p2p-split')
+    ap.add_argument('--calibrate-seconds', type=float, default=20.0,
+                    help='N > 1: a candidate whose build + 3 untimed steps take longer than this is dropped')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
@@ -81,8 +90,58 @@ def load_traffic(path, workload, kernel):
     return None
 
 
+def _visible_gpus():
+    "GPUs this process could use, counted WITHOUT touching the HIP runtime (sysfs KFD topology); None if unknown"
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(',') if t.strip() != ''])
+    if not os.path.exists('/dev/kfd'):
+        return 0
+    top = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(top):
+            with open(os.path.join(top, node, 'properties')) as f:
+                for line in f:
+                    k, _, v = line.partition(' ')
+                    if k == 'simd_count' and int(v) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def self_launch(args):
+    """
+    `python bench.py --gpus N` with N > 1 and no launcher around it: start the one-rank-per-GPU job as a CHILD process
+    (python -m torch.distributed.run ... bench.py <same flags>) before this process has imported torch or touched the
+    GPU -- a process that has initialised HIP must never exec -- relay its output and exit with its code.
+    """
+    import socket
+    import subprocess
+    have = _visible_gpus()
+    need = 1 if os.environ.get('BENCH_TEST_SHARE_GPU') == '1' else args.gpus      # (test hook: all ranks on GPU 0)
+    if have is not None and have < need:
+        sys.exit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this host '
+                 f'(the product has no CPU fallback; N > 1 needs one MI355X per rank)')
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    print(f'[bench] --gpus {args.gpus} without a launcher: starting {" ".join(cmd[1:7])} ... as a child process',
+          file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                             # does not return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -97,9 +156,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs the torch.distributed launcher '
-                     f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...)')
         sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: no GPU is visible (the product has no CPU fallback)')
@@ -208,16 +264,28 @@ def main():
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
         calibration, best = {}, None
         ref_sum = None
-        for name in ('allgather', 'allgatherv', 'p2p', 'p2p-split', 'ipc-push', 'p2p-k2', 'p2p-k4'):
+        # Bounded by default: the padded all-gather (the safe fallback, always first), the unpadded all-gather and the
+        # split-phase point-to-point form, none of which builds another plan.  --calibrate-all adds the forms that
+        # hold extra per-chunk handles (2.4 GB of plan each on the headline matrix) or IPC mappings.
+        names = ('allgather', 'allgatherv', 'p2p-split')
+        if args.calibrate_all:
+            names += ('p2p', 'ipc-push', 'p2p-k2', 'p2p-k4')
+        for name in names:
             cand, hs, err = None, [], None
             try:
+                t_build = time.perf_counter()
                 cand, hs = make_op(name)
                 for _ in range(3):
                     yc = cand.step(x)
                 torch.cuda.synchronize()
+                t_build = time.perf_counter() - t_build
+                if t_build > args.calibrate_seconds and name != 'allgather':
+                    err = f'build + 3 steps took {t_build:.1f} s (budget {args.calibrate_seconds:.0f} s)'
                 # every candidate must produce the first one's y: bit for bit when it runs the same plan, to 1e-9 of
                 # max |y| when its chunks have plans of their own (their tiers cut the sums differently)
-                if ref_sum is None:
+                if err:
+                    pass
+                elif ref_sum is None:
                     ref_sum = yc.clone()
                 elif hs:
                     dmax, ymax = float((yc - ref_sum).abs().max().item()), float(ref_sum.abs().max().item())

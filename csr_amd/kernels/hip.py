@@ -12,8 +12,26 @@ center_rows, filter_zeros, pick_rows, mult_dense.
 A handle owns a copy of the matrix in HBM, like the MKL kernel's handle
 (csr/kernels/mkl/handle.py:47-70).  There is no CPU fallback: without a GPU every call
 raises csr_amd._lib.CsrkError.
+
+Handle cache.  The reference's callers make a handle per operation (CSR.mult_vec: to_handle -> mult_vec ->
+release_handle, csr/csr.py:580-583); for a matrix in HBM that is a PCIe copy of the whole matrix per product, and
+libcsrk's planned kernels (built on a handle's second product) are never reached.  docs/kernels.rst:69-80 lets a
+kernel copy in to_handle and obliges the caller to release explicitly, so `to_handle` here keeps the device copy of
+a released handle alive and hands it out again when the SAME CSR object comes back with the SAME arrays:
+  * key: id(csr) + shape + nnz + the three arrays' data pointers and dtypes; the entry dies with the CSR object
+    (weakref.finalize), so a recycled id or address can never hit;
+  * a sampled fingerprint of the arrays (first / last 32 + 2048 strided elements each) is compared on every hit, which
+    catches the whole-array in-place transforms the reference's API performs (normalize_rows, fill_values,
+    sort_rows, _filter_zeros); a single element poked into `A.values` between two products is NOT seen -- call
+    `invalidate(A)` (or set CSRK_HANDLE_CACHE=0) when doing that;
+  * idle device copies are evicted least-recently-used beyond CSRK_HANDLE_CACHE_BYTES (default 16 GiB of matrix
+    bytes) and on a device out-of-memory error;
+  * the in-place protocol operations (order_columns, unit_rows, center_rows) detach their handle from the cache.
 """
 import ctypes as C
+import os
+import threading
+import weakref
 
 import numpy as np
 
@@ -29,7 +47,7 @@ _VAL_CODES = {None: _lib.VAL_NONE, np.dtype('f4'): _lib.VAL_F32, np.dtype('f8'):
 
 class hip_h:
     "Opaque handle (cf. mkl_h, csr/kernels/mkl/handle.py:30-43): H is the csrk_handle_t."
-    __slots__ = ('H', 'nrows', 'ncols', 'nnz', 'csr_ref')
+    __slots__ = ('H', 'nrows', 'ncols', 'nnz', 'csr_ref', '_entry')
 
     def __init__(self, H, nrows, ncols, nnz, csr_ref=None):
         self.H = H
@@ -37,6 +55,7 @@ class hip_h:
         self.ncols = ncols
         self.nnz = nnz
         self.csr_ref = csr_ref
+        self._entry = None          # the handle cache's record when the device copy is shared (module docstring)
 
     def __repr__(self):
         return f'<hip_h {self.nrows}x{self.ncols} ({self.nnz} nnz) H={self.H:#x}>'
@@ -48,12 +67,108 @@ def _live(h):
     return h.H
 
 
+# ---- handle cache ------------------------------------------------------------------------------------------
+class _Entry:
+    __slots__ = ('H', 'refs', 'bytes', 'key', 'finger', 'tick', 'cached', 'fin')
+
+
+_cache_lock = threading.RLock()
+_cache = {}                     # key -> _Entry (live or idle device copies that may be handed out again)
+_tick = 0
+_SAMPLE = 2048
+
+
+def _cache_enabled():
+    return os.environ.get('CSRK_HANDLE_CACHE', '1') not in ('0', 'off', 'false')
+
+
+def _cache_budget():
+    return int(os.environ.get('CSRK_HANDLE_CACHE_BYTES', str(16 << 30)))
+
+
+def _arr_key(a):
+    return (0, '') if a is None else (a.ctypes.data, a.dtype.str)
+
+
+def _sample(a):
+    if a is None or a.size == 0:
+        return b''
+    n = a.size
+    if n <= 4 * _SAMPLE:
+        return a.tobytes()
+    step = n // _SAMPLE
+    return a[:32].tobytes() + a[::step].tobytes() + a[-32:].tobytes()
+
+
+def _fingerprint(rps, cis, vs):
+    return hash((_sample(rps), _sample(cis), _sample(vs)))
+
+
+def _drop_entry(e):
+    "remove from the index; free the device copy once nobody holds it (caller holds the lock)"
+    if e.cached:
+        e.cached = False
+        if _cache.get(e.key) is e:
+            del _cache[e.key]
+    if e.refs == 0 and e.H:
+        H, e.H = e.H, 0
+        check(lib.csrk_free(H))
+
+
+def _on_csr_collected(key):
+    with _cache_lock:
+        e = _cache.get(key)
+        if e is not None:
+            _drop_entry(e)
+
+
+def _evict_idle(budget):
+    "free idle cached copies, least recently used first, until the idle ones fit `budget` bytes"
+    with _cache_lock:
+        idle = sorted((e for e in _cache.values() if e.refs == 0), key=lambda e: e.tick)
+        total = sum(e.bytes for e in idle)
+        for e in idle:
+            if total <= budget:
+                break
+            total -= e.bytes
+            _drop_entry(e)
+
+
+def flush_handle_cache():
+    "free every idle cached device copy (live handles are untouched)"
+    _evict_idle(0)
+
+
+def invalidate(csr):
+    "forget the cached device copy of `csr` (after editing its arrays in place); the next to_handle copies afresh"
+    with _cache_lock:
+        for e in [e for e in _cache.values() if e.key[0] == id(csr)]:
+            _drop_entry(e)
+
+
+def _create(csr, rps, cis, vs):
+    out = handle_t(0)
+    args = (int(csr.nrows), int(csr.ncols), int(csr.nnz), ptr(rps), int(rps.dtype == np.dtype('i8')), ptr(cis), ptr(vs),
+            _VAL_CODES[None if vs is None else vs.dtype], C.byref(out))
+    try:
+        check(lib.csrk_create(*args))
+    except _lib.CsrkError:
+        if not any(e.refs == 0 for e in _cache.values()):
+            raise
+        flush_handle_cache()            # device memory may be held by idle cached copies: give it back and retry once
+        check(lib.csrk_trim_cache())
+        check(lib.csrk_create(*args))
+    return out.value
+
+
 def to_handle(csr):
     """
     csr/kernels/numba/__init__.py:16-27; csr/kernels/mkl/handle.py:61-70.  Copies the
-    matrix to HBM.  Accepts f4/f8/absent values and int32/int64 row pointers; other value
+    matrix to HBM -- or hands out the cached copy made for this same CSR object and arrays (module docstring).
+    Accepts f4/f8/absent values and int32/int64 row pointers; other value
     dtypes are widened to f8 (the reference's results are f8 whatever the storage dtype).
     """
+    global _tick
     if csr.nnz > max_nnz:
         raise ValueError('CSR size {} exceeds max nnz {}'.format(csr.nnz, max_nnz))
     rps = np.ascontiguousarray(csr.rowptrs)
@@ -65,11 +180,58 @@ def to_handle(csr):
         vs = np.ascontiguousarray(vs)
         if vs.dtype not in (np.dtype('f4'), np.dtype('f8')):
             vs = vs.astype(np.float64)
-    out = handle_t(0)
-    check(lib.csrk_create(int(csr.nrows), int(csr.ncols), int(csr.nnz), ptr(rps),
-                          int(rps.dtype == np.dtype('i8')), ptr(cis), ptr(vs),
-                          _VAL_CODES[None if vs is None else vs.dtype], C.byref(out)))
-    return hip_h(out.value, int(csr.nrows), int(csr.ncols), int(csr.nnz), csr)
+    nr, nc, nnz = int(csr.nrows), int(csr.ncols), int(csr.nnz)
+    # small matrices are cheaper to copy than to look up; arrays that had to be converted are temporaries whose
+    # addresses mean nothing on the next call
+    def own(a, orig):
+        return (a is None and orig is None) or (isinstance(orig, np.ndarray) and a.ctypes.data == orig.ctypes.data)
+    cacheable = (_cache_enabled() and nnz >= 4096 and own(rps, csr.rowptrs) and own(cis, csr.colinds)
+                 and own(vs, csr.values))
+    if cacheable:
+        key = (id(csr), nr, nc, nnz, _arr_key(rps), _arr_key(cis), _arr_key(vs))
+        finger = _fingerprint(rps, cis, vs)
+        with _cache_lock:
+            _tick += 1
+            e = _cache.get(key)
+            if e is not None and e.finger != finger:      # same arrays, different contents: edited in place
+                _drop_entry(e)
+                e = None
+            if e is not None:
+                e.refs += 1
+                e.tick = _tick
+                h = hip_h(e.H, nr, nc, nnz, csr)
+                h._entry = e
+                return h
+    H = _create(csr, rps, cis, vs)
+    h = hip_h(H, nr, nc, nnz, csr)
+    if cacheable:
+        try:
+            fin = weakref.finalize(csr, _on_csr_collected, key)
+        except TypeError:                                  # a CSR type without weak references (Numba structref proxy)
+            return h
+        fin.atexit = False
+        e = _Entry()
+        e.H, e.refs, e.key, e.finger, e.cached, e.fin = H, 1, key, finger, True, fin
+        e.bytes = rps.nbytes + cis.nbytes + (0 if vs is None else vs.nbytes)
+        with _cache_lock:
+            old = _cache.get(key)
+            if old is not None:                            # another thread cached the same matrix meanwhile
+                _drop_entry(old)
+            e.tick = _tick
+            _cache[key] = e
+        h._entry = e
+    return h
+
+
+def _detach(h):
+    "an in-place operation is about to change this handle's device copy: it must not be handed out as `csr` again"
+    e = h._entry
+    if e is not None:
+        with _cache_lock:
+            if e.cached:
+                e.cached = False
+                if _cache.get(e.key) is e:
+                    del _cache[e.key]
 
 
 def _info(H):
@@ -99,15 +261,29 @@ def from_handle(h):
 
 
 def release_handle(h):
-    "csr/kernels/numba/__init__.py:39-44; idempotent like mkl/handle.py:144-148"
-    if h.H:
-        check(lib.csrk_free(h.H))
-    h.H = 0
+    """
+    csr/kernels/numba/__init__.py:39-44; idempotent like mkl/handle.py:144-148.  A cached device copy stays in HBM
+    (idle) for the next to_handle of the same CSR; the others are freed here.
+    """
+    e, h._entry = h._entry, None
+    H, h.H = h.H, 0
     h.csr_ref = None
+    if not H:
+        return
+    if e is None:
+        check(lib.csrk_free(H))
+        return
+    with _cache_lock:
+        e.refs -= 1
+        if e.refs == 0 and not e.cached:
+            _drop_entry(e)
+    if e.cached:
+        _evict_idle(_cache_budget())
 
 
 def order_columns(h):
     "csr/kernels/numba/__init__.py:47-52: sort each row by column, in place on the handle"
+    _detach(h)
     check(lib.csrk_order_columns(_live(h)))
 
 
@@ -191,6 +367,7 @@ def _row_stat(fn, h):
     _, _, _, _, vt = _info(_live(h))
     if vt == _lib.VAL_NONE:
         raise ValueError('matrix has no values')
+    _detach(h)                     # unit_rows / center_rows rewrite the device copy's values
     out = np.empty(h.nrows, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
     check(fn(h.H, ptr(out)))
     return out

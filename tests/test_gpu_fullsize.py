@@ -173,27 +173,24 @@ def test_transpose_config5_full_size():
         check(lib.csrk_trim_cache())
 
 
-@pytest.mark.parametrize('collective', ['auto', 'p2p-k2', 'p2p-split', 'ipc-push'])
+@pytest.mark.parametrize('collective', ['auto', 'auto-all', 'p2p-k2', 'p2p-split', 'ipc-push'])
 def test_bench_two_ranks_plumbing(collective):
     """
-    bench.py's N > 1 path end to end on ONE GPU: two ranks share cuda:0 over gloo (RCCL refuses two ranks on
-    a device; BENCH_TEST_SHARE_GPU is the bench's own test hook).  Covers shard generation, the per-rank
-    plans, the row-partitioned step with its exchange, the max-over-ranks timing and rank 0's JSON line.
+    bench.py's N > 1 path end to end on ONE GPU, started the way the driver starts N = 1 -- plain
+    `python bench.py --gpus 2 ...`, no launcher: bench.py starts its own one-rank-per-GPU job as a child process.  Two
+    ranks share cuda:0 over gloo (RCCL refuses two ranks on a device; BENCH_TEST_SHARE_GPU is the bench's own test
+    hook).  Covers the self-launch, shard generation, the per-rank plans, the row-partitioned step with its exchange,
+    the (bounded) calibration, the max-over-ranks timing and rank 0's JSON line.
     """
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, BENCH_TEST_SHARE_GPU='1', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-           '--scale', '0.05', '--collective', collective]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['BENCH_TEST_SHARE_GPU'] = '1'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.05']
+    cmd += ['--collective', 'auto', '--calibrate-all'] if collective == 'auto-all' else ['--collective', collective]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
@@ -201,11 +198,26 @@ def test_bench_two_ranks_plumbing(collective):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'strong'
     assert d['config']['parallelism'] == 'row-partition x2' and 'multi_gpu' in d
     assert d['multi_gpu']['y_complete_and_identical_on_every_rank'] is True
-    if collective == 'auto':
-        assert d['multi_gpu']['exchange'] in d['multi_gpu']['candidates_ms_per_step']
+    assert d['multi_gpu']['kernel_only_gflops'] > 0
+    if collective.startswith('auto'):
+        cands = d['multi_gpu']['candidates_ms_per_step']
+        assert d['multi_gpu']['exchange'] in cands
+        assert ('p2p-k2' in cands) == (collective == 'auto-all') and 'allgather' in cands and 'p2p-split' in cands
     else:
         # chunk handles (views of the rank's arrays) + point-to-point exchange straight into y
         assert d['multi_gpu']['exchange'] == collective
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    "`python bench.py --gpus 8` on a box with fewer GPUs: a clear message and a non-zero exit, before anything is launched"
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BENCH_TEST_SHARE_GPU')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '1', '--warmup', '0'],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and 'GPU(s) visible' in out.stderr
 
 
 def test_cold_staging_and_stream_forms_are_bit_neutral(monkeypatch):

@@ -1,0 +1,174 @@
+"""
+The handle cache of csr_amd/kernels/hip.py (host logic only: libcsrk's create / free are replaced by counters, so this
+runs without a GPU).  The reference's callers make a handle per operation (csr/csr.py:580-583: to_handle -> mult_vec ->
+release_handle); the cache keeps the released device copy for the next to_handle of the same CSR object and arrays.
+"""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+
+class FakeLib:
+    "counts csrk_create / csrk_free; handles are 1, 2, 3, ..."
+
+    def __init__(self):
+        self.created, self.freed, self.live, self.fail_next = 0, [], set(), 0
+
+    def csrk_create(self, nr, nc, nnz, rp, p64, ci, vs, vt, out):
+        if self.fail_next:
+            self.fail_next -= 1
+            return -2
+        self.created += 1
+        out._obj.value = self.created
+        self.live.add(self.created)
+        return 0
+
+    def csrk_free(self, H):
+        H = getattr(H, 'value', H)
+        assert H in self.live, f'double free of {H}'
+        self.live.discard(H)
+        self.freed.append(H)
+        return 0
+
+    def csrk_trim_cache(self):
+        return 0
+
+    def csrk_last_error(self):
+        return b'hipMalloc failed: out of memory'
+
+
+@pytest.fixture
+def K(monkeypatch):
+    import csr_amd.kernels.hip as hip
+    fake = FakeLib()
+    monkeypatch.setattr(hip, 'lib', fake)
+    import csr_amd._lib as _lib
+    monkeypatch.setattr(_lib, 'lib', fake)
+    hip.flush_handle_cache()
+    hip._cache.clear()
+    yield hip
+    hip._cache.clear()
+
+
+def _mat(n=6000, seed=0, vals=True):
+    from csr_amd import CSR
+    rng = np.random.default_rng(seed)
+    rp = np.arange(n + 1, dtype=np.int32)
+    return CSR(n, n, n, rp, rng.integers(0, n, n).astype(np.int32), rng.uniform(-1, 1, n) if vals else None, _cast=False)
+
+
+def test_same_csr_reuses_the_device_copy(K):
+    A = _mat()
+    h1 = K.to_handle(A)
+    assert K.lib.created == 1
+    K.release_handle(h1)
+    assert h1.H == 0 and K.lib.freed == []            # idle, still in HBM
+    K.release_handle(h1)                              # idempotent (csr/kernels/mkl/handle.py:144-148)
+    h2 = K.to_handle(A)
+    h3 = K.to_handle(A)                               # two live handles share the copy
+    assert K.lib.created == 1 and h2.H == h3.H == 1
+    K.release_handle(h2)
+    K.release_handle(h3)
+    assert K.lib.freed == []
+    B = _mat(seed=1)                                  # another matrix: its own copy
+    hb = K.to_handle(B)
+    assert K.lib.created == 2 and hb.H == 2
+    K.release_handle(hb)
+    K.flush_handle_cache()
+    assert sorted(K.lib.freed) == [1, 2] and not K.lib.live
+
+
+def test_entry_dies_with_the_csr_object(K):
+    A = _mat()
+    K.release_handle(K.to_handle(A))
+    assert K.lib.live == {1}
+    del A
+    gc.collect()
+    assert not K.lib.live and not K._cache
+    # a live handle keeps its matrix alive (csr_ref); the copy goes when the handle is released and the CSR collected
+    A = _mat()
+    h = K.to_handle(A)
+    del A
+    gc.collect()
+    assert K.lib.live == {2}
+    K.release_handle(h)
+    gc.collect()
+    assert not K.lib.live
+
+
+def test_in_place_edits_are_seen(K):
+    A = _mat()
+    K.release_handle(K.to_handle(A))
+    A.values[:] *= 2.0                                # a whole-array transform (normalize_rows, fill_values ...)
+    h = K.to_handle(A)
+    assert K.lib.created == 2 and K.lib.freed == [1]  # fingerprint mismatch: fresh copy, stale one freed
+    K.release_handle(h)
+    A.values[4001] = 7.0                              # a single poke is not sampled ...
+    K.invalidate(A)                                   # ... so the caller says so
+    h = K.to_handle(A)
+    assert K.lib.created == 3 and K.lib.freed == [1, 2]
+    K.release_handle(h)
+    A.colinds = A.colinds.copy()                      # new arrays on the same object: different key
+    h = K.to_handle(A)
+    assert K.lib.created == 4
+    K.release_handle(h)
+
+
+def test_in_place_protocol_operations_detach(K, monkeypatch):
+    A = _mat()
+    h = K.to_handle(A)
+    monkeypatch.setattr(K.lib, 'csrk_order_columns', lambda H: 0, raising=False)
+    K.order_columns(h)                                # the device copy no longer equals A
+    h2 = K.to_handle(A)
+    assert h2.H != h.H and K.lib.created == 2
+    K.release_handle(h)
+    assert K.lib.freed == [1]                         # detached copies are freed on release
+    K.release_handle(h2)
+
+
+def test_budget_evicts_least_recently_used(K, monkeypatch):
+    mats = [_mat(seed=s) for s in range(4)]
+    per = mats[0].rowptrs.nbytes + mats[0].colinds.nbytes + mats[0].values.nbytes
+    monkeypatch.setenv('CSRK_HANDLE_CACHE_BYTES', str(2 * per))
+    for m in mats:
+        K.release_handle(K.to_handle(m))
+    assert K.lib.freed == [1, 2] and K.lib.live == {3, 4}
+    K.release_handle(K.to_handle(mats[2]))            # touch 3: 4 is now the oldest
+    K.release_handle(K.to_handle(mats[0]))
+    assert K.lib.freed == [1, 2, 4]
+    monkeypatch.setenv('CSRK_HANDLE_CACHE', '0')
+    n = K.lib.created
+    h = K.to_handle(mats[2])
+    assert K.lib.created == n + 1                     # cache off: always a fresh copy, freed on release
+    K.release_handle(h)
+    assert K.lib.freed[-1] == h.H or K.lib.freed[-1] == n + 1
+
+
+def test_out_of_memory_flushes_idle_copies_and_retries(K):
+    A, B = _mat(seed=0), _mat(seed=1)
+    K.release_handle(K.to_handle(A))
+    K.lib.fail_next = 1
+    h = K.to_handle(B)
+    assert K.lib.freed == [1] and h.H == 2
+    K.release_handle(h)
+    K.lib.fail_next = 2                               # nothing idle left to give back... (B's copy is, once)
+    with pytest.raises(Exception):
+        K.to_handle(_mat(seed=2))
+
+
+def test_small_and_converted_matrices_are_not_cached(K):
+    from csr_amd import CSR
+    S = CSR(3, 3, 2, np.array([0, 1, 2, 2], dtype=np.int32), np.array([0, 1], dtype=np.int32), np.ones(2), _cast=False)
+    for _ in range(2):
+        K.release_handle(K.to_handle(S))
+    assert K.lib.created == 2 and K.lib.freed == [1, 2]
+    A = _mat()
+    A.colinds = A.colinds.astype(np.int64)            # converted to int32 on every call: a new array each time
+    for _ in range(2):
+        K.release_handle(K.to_handle(A))
+    gc.collect()
+    assert K.lib.created == 4
+    K.flush_handle_cache()
+    assert not K.lib.live

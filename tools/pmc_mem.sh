@@ -20,7 +20,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob('$OUT/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'csrk::spmv' not in n: continue
+        if 'csrk::' not in n or not any(t in n for t in ('spmv', 'ls_stage', 'acc_reduce')): continue
         k = n.split('csrk::')[1].split('(')[0][:40]
         agg[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
 ks = sorted(set(k for k, _ in agg))
