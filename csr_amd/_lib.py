@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcsrk.so')
+# CSRK_LIBRARY: load another build of the same sources (kernel experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get('CSRK_LIBRARY') or os.path.join(_HERE, 'libcsrk.so')
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_OVERFLOW = -1, -2, -3, -4

@@ -32,6 +32,7 @@
 // (float32 values are widened on load; structure-only matrices multiply by 1.0,
 // csr/csr.py:254-262).
 #include "common.h"
+#include "wave.h"
 
 #include <algorithm>
 #include <vector>
@@ -107,6 +108,9 @@ struct LightStream {
     int64_t n_cold = 0;
     int32_t n_stage_blk = 0, stage_w = 0;
     DevBuf xg, a_col, a_dst, blk_start;
+    // tile-major staging (build_cold_stage, default): the staged values of tile t are xg[tile_cold[t] .. tile_cold[t + 1]),
+    // and a cold entry's index word holds its offset inside that range; empty: positions are absolute (round-major form)
+    DevBuf tile_cold;
 };
 
 struct SpmvPlan {
@@ -1165,24 +1169,7 @@ __global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict_
     }
 }
 
-__device__ __forceinline__ int wave_exscan_i32(int v, int lane);
-
-// Inclusive segmented sum over the lanes of a wavefront: a lane with `reset` set does not take the
-// running sum of the lanes below it.
-__device__ __forceinline__ double wave_segscan(double v, bool reset, int lane)
-{
-    int f = reset ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const double vp = __shfl_up(v, d, WAVE);
-        const int fp = __shfl_up(f, d, WAVE);
-        if (lane >= d && !f) {
-            v += vp;
-            f = fp;
-        }
-    }
-    return v;
-}
+// (wave_exscan_i32 / wave_segscan: wave.h)
 
 template <int CB, int PT>
 __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__ pvals, const uint16_t *__restrict__ pidx,
@@ -1294,14 +1281,14 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
             const double ts = acc;
             if (!nb) hs = acc;
             // join the runs that cross lanes
-            const int tr_prev = __shfl_up(tr, 1, WAVE);
+            const int tr_prev = wave_up1_i32(tr, -1);
             const bool ne = lane > 0 && tr_prev != hr;           // a run ends between lane - 1 and this lane
             const double T = wave_segscan(ts, nb || ne, lane);    // running sum of this lane's tail run
-            const double T_prev = __shfl_up(T, 1, WAVE);
+            const double T_prev = wave_up1_f64(T, 0.0);
             const double X = (lane > 0 && !ne) ? T_prev : 0.0;    // what earlier lanes carry into this lane's head
             const unsigned long long m_nb = __ballot(nb), m_ne = __ballot(ne);
             const bool before = ((m_nb & below) | (m_ne & upto)) != 0;   // some run ended before this lane's head
-            const int ne_next = __shfl_down((int)ne, 1, WAVE);
+            const int ne_next = wave_down1_i32((int)ne, 1);
             const bool tail_done = lane == WAVE - 1 || ne_next != 0;
             if (nb) {                                            // the head run ends inside this lane
                 const double hv = hs + X;
@@ -1335,9 +1322,9 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
                 const bool ok = i < nt;
                 const int row = ok ? s_hrow[i] : -1 - lane;
                 const double val = ok ? s_hval[i] : 0.0;
-                const int row_prev = __shfl_up(row, 1, WAVE);
+                const int row_prev = wave_up1_i32(row, -2 - WAVE);
                 const double S = wave_segscan(val, lane == 0 || row_prev != row, lane);
-                const int row_next = __shfl_down(row, 1, WAVE);
+                const int row_next = wave_down1_i32(row, -2 - WAVE);
                 if (ok && (lane == WAVE - 1 || row_next != row)) atomicAdd(&s_acc[row], S);
             }
         }
@@ -1437,7 +1424,10 @@ __global__ __launch_bounds__(1024) void acc_reduce_multi_kernel(RedJobs jobs, do
 constexpr int LS_THREADS = 1024;            // one persistent workgroup per CU
 constexpr int LS_HOT_LDS = 8192;            // packed columns kept in LDS (64 KiB)
 constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile
-constexpr int LS_SEQ = 3;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
+#ifndef CSRK_LS_SEQ
+#define CSRK_LS_SEQ 3
+#endif
+constexpr int LS_SEQ = CSRK_LS_SEQ;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
 constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
 constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
 
@@ -1537,24 +1527,37 @@ __global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, con
     if (carry_idx) carry_idx[t] = (int32_t)lt;
 }
 
-__device__ __forceinline__ int wave_exscan_i32(int v, int lane)
-{
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const int up = __shfl_up(inc, d, WAVE);
-        if (lane >= d) inc += up;
-    }
-    return inc - v;
-}
-
 // LDS: [0, LS_HOT_LDS) the x values of the most popular packed columns (slots below n_lds are read from
 // here instead of gathered), then one staging buffer of ACC_TILE + 2 run sums per wavefront.
+// Diagnostic build only (-DCSRK_LS_STAMPS, tools/build_variant.sh): per-wavefront cycle totals of the phases of the
+// stream kernel's tile loop, stamped with s_memtime and read back by csrk_debug_ls_stamps.  The stamps go to a buffer of
+// their own and no output is computed from them; the shipped library contains none of this.
+#ifdef CSRK_LS_STAMPS
+constexpr int LS_NSTAMP = 8;
+__device__ unsigned long long g_ls_stamps[4096 * LS_NSTAMP];
+#define LS_STAMP(I)                                                       \
+    {                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        stamp_acc[I] += now_ - stamp_last;                                \
+        stamp_last = now_;                                                \
+    }
+#else
+#define LS_STAMP(I)
+#endif
+
+// XGT (tile-major cold staging): `x` is xg and `tile_cold[t]` the start of tile t's staged values in it; the wavefront
+// copies that range (at most 512 values, on average ~a quarter of the tile) into its LDS staging buffer with coalesced
+// 512-B loads and a cold entry reads LDS at the offset its index word holds -- one L1 line fill per 16 staged values
+// instead of one per value (a gather lane that misses L1 costs its CU ~4 clocks of line fill wherever the line comes
+// from).  The buffer is the run-sum staging buffer s_out: the gathers of a tile are over before
+// its run sums are written, and a wavefront's LDS operations complete in order.
+template <bool XGT>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
     const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
-    double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val)
+    double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
+    const int32_t *__restrict__ tile_cold)
 {
     // No FMA contraction in this kernel: the reference rounds every product before adding it.  (HIP's rounding
     // intrinsics for multiply and add are plain * and + inside inline functions compiled with
@@ -1563,7 +1566,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // wave-uniform: tile numbers and bases stay scalar
     double *s_out = s_hot + LS_HOT_LDS + wv * (ACC_TILE + 2);
     for (int i = threadIdx.x; i < n_lds; i += LS_THREADS) s_hot[i] = xh[i];
     __syncthreads();
@@ -1573,7 +1577,12 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     f64x2_t v[4], vn[4];
     u32x4_t ix[2], ixn[2];
     int32_t tb = 0, tbn = 0;
+    int32_t cb = 0, cn = 0, cbn = 0, cnn = 0;      // XGT: this tile's range of xg (start, length), and the next tile's
     int64_t t = wave0;
+#ifdef CSRK_LS_STAMPS
+    unsigned long long stamp_acc[LS_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     if (t < n_tiles) {
         const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
         const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
@@ -1581,34 +1590,53 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
 #pragma unroll
         for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
-        tb = tile_base[t];
+        tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
+        if (XGT) {
+            cb = __builtin_amdgcn_readfirstlane(tile_cold[t]);
+            cn = __builtin_amdgcn_readfirstlane(tile_cold[t + 1]) - cb;
+        }
     }
     for (; t < n_tiles; t += n_waves) {
         const bool more = t + n_waves < n_tiles;
-        if (more) {      // next tile's stream loads are in flight while this one is gathered and reduced
-            const f64x2_t *vp = (const f64x2_t *)(svals + (t + n_waves) * ACC_TILE);
-            const u32x4_t *ip = (const u32x4_t *)(sidx + (t + n_waves) * ACC_TILE);
-#pragma unroll
-            for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
-#pragma unroll
-            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
-            tbn = tile_base[t + n_waves];
-        }
         const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
         const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
-        // x values: the most popular packed columns from LDS, the others gathered (lanes served from LDS
-        // are masked out of the gather, which is what the texture path charges for); all eight in flight
+        // Issue order matters: vmcnt retires loads in issue order, so whatever is requested BEFORE the loads this tile
+        // waits for is waited for too.  This tile's own loads (staged values / gathers, row ids) therefore go first and
+        // the next tile's stream loads -- HBM latency -- are requested after them and stay in flight across the whole
+        // tile.  (Requested first, as they used to be, every tile waited for the next tile's HBM loads before its first
+        // multiply.)
+        // XGT: the tile's staged x values, coalesced: lane k of load q takes the value pair 2 (64 q + k), so four 16-B
+        // loads cover the 512 values a tile can have at most (pairs past the tile's count re-read its first pair: one
+        // line, no traffic; an odd count's last pair reads one value into the next tile's range or the array's padding)
+        f64x2_t xr[4];
         double gv[ACC_K], lv[ACC_K];
         bool inl[ACC_K];
+        if (XGT) {
 #pragma unroll
-        for (int j = 0; j < ACC_K; j++) {
-            const uint32_t c = e[j] & LS_COL_MASK;
-            const bool hot = (e[j] & LS_HOT_BIT) != 0;
-            inl[j] = hot && (int32_t)c < n_lds;
-            gv[j] = 0.0;
-            const double *g = hot ? xh + c : x + c;
-            if (!inl[j] && e[j] != LS_PAD) gv[j] = *g;          // padding slots gather nothing and multiply 0 * 0
-            lv[j] = s_hot[inl[j] ? c : 0];
+            for (int q = 0; q < 4; q++) {
+                const int k = 2 * (q * WAVE + lane);
+                xr[q] = *(const F64x2 *)(x + cb + (k < cn ? k : 0));
+            }
+            // packed columns beyond the LDS slots: gathered from the pack
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const uint32_t c = e[j] & LS_COL_MASK;
+                const bool hot = (e[j] & LS_HOT_BIT) != 0;
+                gv[j] = 0.0;
+                if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
+            }
+        } else {
+            // x values: the most popular packed columns from LDS, the others gathered (lanes served from LDS
+            // are masked out of the gather, which is what the texture path charges for); all eight in flight
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const uint32_t c = e[j] & LS_COL_MASK;
+                const bool hot = (e[j] & LS_HOT_BIT) != 0;
+                inl[j] = hot && (int32_t)c < n_lds;
+                gv[j] = 0.0;
+                const double *g = hot ? xh + c : x + c;
+                if (!inl[j] && e[j] != LS_PAD) gv[j] = *g;          // padding slots gather nothing and multiply 0 * 0
+            }
         }
         // row ids of the tile's first run slots (slot k <-> run tb - 1 + k): requested now, used at the end
         int32_t rid[LS_RID];
@@ -1617,13 +1645,52 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             const int run = tb - 1 + lane + i * WAVE;
             rid[i] = rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)];
         }
-        // row starts: bit j of st = entry j opens a row
+        asm volatile("" ::: "memory");      // (compiler-level: keep the two groups of loads in this order)
+        {
+            // The next tile's stream loads stay in flight while this one is gathered and reduced.  UNCONDITIONAL (the
+            // last tile re-requests itself): behind an `if (more)` the compiler cannot count the loads in flight at the
+            // join and waits for all of them (s_waitcnt vmcnt(0)) before this tile's first multiply.
+            const int64_t tn = more ? t + n_waves : t;
+            const f64x2_t *vp = (const f64x2_t *)(svals + tn * ACC_TILE);
+            const u32x4_t *ip = (const u32x4_t *)(sidx + tn * ACC_TILE);
+            // (index words first: the next tile's gathers need them at its very top, the values only at its multiplies)
+#pragma unroll
+            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+#pragma unroll
+            for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+            tbn = tile_base[tn];
+            if (XGT) {
+                cbn = tile_cold[tn];
+                cnn = tile_cold[tn + 1] - cbn;
+            }
+        }
+        asm volatile("" ::: "memory");
+        LS_STAMP(0)
+        // row starts: bit j of st = entry j opens a row (index words only: this runs while the tile's x values arrive)
         uint32_t st = 0;
 #pragma unroll
         for (int j = 0; j < ACC_K; j++) st |= ((e[j] >> 30) & 1u) << j;
         const int cnt = __popc(st);
         const int S = wave_exscan_i32(cnt, lane);          // row starts in the lanes below
-        const int total = __shfl(S + cnt, WAVE - 1, WAVE);   // row starts in the tile
+        const int total = wave_last_i32(S + cnt);            // row starts in the tile
+        LS_STAMP(1)
+        if (XGT) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) ((f64x2_t *)s_out)[q * WAVE + lane] = xr[q];
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const uint32_t c = e[j] & LS_COL_MASK;
+                const bool hot = (e[j] & LS_HOT_BIT) != 0;
+                const bool lds_hot = hot && (int32_t)c < n_lds;
+                const bool cold = !hot && e[j] != LS_PAD;
+                inl[j] = lds_hot || cold;                       // served from LDS: the hot slots or the staged range
+                const double *src = cold ? s_out + c : s_hot + (lds_hot ? c : 0);
+                lv[j] = *src;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) lv[j] = s_hot[inl[j] ? (e[j] & LS_COL_MASK) : 0];
+        }
         // products, rounded on their own like the reference's `v * x` (contraction is off in this kernel:
         // short rows are to come out bit-identical to the sequential loop)
         double pr[ACC_K];
@@ -1631,6 +1698,11 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         for (int j = 0; j < ACC_K; j++) {
             pr[j] = a[j] * (inl[j] ? lv[j] : gv[j]);
         }
+#ifdef CSRK_LS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7]));
+#endif
+        LS_STAMP(2)
         // Run sums go to the wavefront's staging buffer: slot 0 = the tile's leading run (the part of a row
         // begun in an earlier tile; 0.0 if the tile opens a row), slot k = the run opened by the tile's k-th
         // row start.  Lane-local pass: runs that start and end inside the lane.
@@ -1654,8 +1726,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         const double ts = acc;                                   // the lane's last run so far
         // runs that cross lanes, tree order (any length)
         const double T = wave_segscan(ts, has_start, lane);
-        const double T_prev = __shfl_up(T, 1, WAVE);
-        const double X = lane > 0 ? T_prev : 0.0;               // what the lanes below carry into this lane's head
+        const double X = wave_up1_f64(T, 0.0);               // what the lanes below carry into this lane's head
         // ... and in the reference's own order for runs over at most LS_SEQ + 1 lanes: round k hands the
         // exact running sum of the lane below to a lane that has not got its carry yet, which then re-adds
         // its head entries one by one on top of it
@@ -1664,8 +1735,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         bool okq = has_start || lane == 0, hok = lane == 0;
 #pragma unroll
         for (int it = 0; it < LS_SEQ; it++) {
-            const double Xq = __shfl_up(Tq, 1, WAVE);
-            const int xok = __shfl_up((int)okq, 1, WAVE);
+            const double Xq = wave_up1_f64(Tq, 0.0);
+            const int xok = wave_up1_i32((int)okq, 0);
             const bool take = lane > 0 && xok && !hok;
             double sum = Xq;
 #pragma unroll
@@ -1679,6 +1750,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         }
         if (has_start) s_out[S] = hok ? Hq : hs + X;             // the head run ends in this lane
         if (lane == WAVE - 1) s_out[S + cnt] = okq ? Tq : T;     // the tile's last run (continued by the next tile's slot 0)
+        LS_STAMP(3)
         // out: slot k -> the row of run tile_base - 1 + k; consecutive lanes write ascending (mostly
         // consecutive) rows.  LDS operations of one wavefront complete in order: no barrier needed.
         // Rows without a run -- empty rows, rows served by the tiers (their reduce kernels overwrite y later
@@ -1687,20 +1759,16 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         // (The row ids of the first LS_RID * 64 slots were requested with the gathers -- the dependent
         // rowids -> store round trips per 64 runs were a third of a tile's latency; the id of the previous run's
         // row is the lane below's.)
+        // The batches whose row ids are in registers run as straight-line code with NO load inside: a load in this
+        // loop (the row ids of batch LS_RID and beyond, a tile with more than LS_RID * 64 runs) makes the compiler drain
+        // the wavefront's memory queue -- every y store of the batch before, s_waitcnt vmcnt(0) -- once per batch
+        // (measured with in-kernel stamps: a third of a tile's cycles went there).
         int32_t r_last = -1;                                   // row of the slot before this batch of 64
-#pragma unroll 1
-        for (int k0 = 0, it = 0; k0 <= total; k0 += WAVE, it++) {
+        auto out_batch = [&](const int k0, const int32_t r) {
             const int k = k0 + lane;
             const int run = tb - 1 + k;
-            int32_t r;
-            if (it < LS_RID) {
-                r = it == 0 ? rid[0] : (it == 1 ? rid[1] : (it == 2 ? rid[2] : rid[3]));
-            } else {
-                r = rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)];
-            }
-            int32_t r_prev = __shfl_up(r, 1, WAVE);
-            if (lane == 0) r_prev = r_last;
-            r_last = __shfl(r, WAVE - 1, WAVE);
+            const int32_t r_prev = wave_up1_i32(r, r_last);
+            r_last = wave_last_i32(r);
             int64_t g0 = 0, g1 = 0;                             // rows [g0, g1) to clear
             if (k <= total) {
                 const double val = s_out[k];
@@ -1727,18 +1795,38 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 const int64_t b0 = __shfl(g0, src, WAVE), b1 = __shfl(g1, src, WAVE);
                 for (int64_t q = b0 + lane; q < b1; q += WAVE) y[q] = 0.0;
             }
+        };
+#pragma unroll
+        for (int it = 0; it < LS_RID; it++)
+            if (it * WAVE <= total) out_batch(it * WAVE, rid[it]);
+#pragma unroll 1
+        for (int k0 = LS_RID * WAVE; k0 <= total; k0 += WAVE) {
+            const int run = tb - 1 + k0 + lane;
+            out_batch(k0, rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)]);
         }
         if (total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
             for (int64_t q = (int64_t)rowids[n_runs - 1] + 1 + lane; q < nrows; q += WAVE) y[q] = 0.0;
         }
-        if (more) {
+        LS_STAMP(4)
+#ifdef CSRK_LS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // [5] = what the stores (and the prefetch) still needed
+        LS_STAMP(5)
+        stamp_acc[7] += 1;
+#endif
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = vn[q];
+        for (int q = 0; q < 4; q++) v[q] = vn[q];
 #pragma unroll
-            for (int q = 0; q < 2; q++) ix[q] = ixn[q];
-            tb = tbn;
+        for (int q = 0; q < 2; q++) ix[q] = ixn[q];
+        tb = __builtin_amdgcn_readfirstlane(tbn);
+        if (XGT) {
+            cb = __builtin_amdgcn_readfirstlane(cbn);
+            cn = __builtin_amdgcn_readfirstlane(cnn);
         }
     }
+#ifdef CSRK_LS_STAMPS
+    if (lane == 0 && wave0 < 4096)
+        for (int i = 0; i < LS_NSTAMP; i++) g_ls_stamps[wave0 * LS_NSTAMP + i] = stamp_acc[i];
+#endif
 }
 
 // One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
@@ -2352,7 +2440,9 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
     int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
     const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
@@ -2379,7 +2469,10 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
 //     (round, block) bucket are neighbours on both sides and neighbouring blocks fill neighbouring pieces of a line.
 // A cold entry's index word then holds its position in xg instead of its column (flags unchanged) and the stream
 // kernel is given xg as the base of its cold gathers: the kernel itself does not change, nor does any result bit.
-constexpr int LS_STAGE_TILES = LS_THREADS / WAVE;     // tiles per workgroup round
+#ifndef CSRK_STAGE_TILES
+#define CSRK_STAGE_TILES (LS_THREADS / WAVE)
+#endif
+constexpr int LS_STAGE_TILES = CSRK_STAGE_TILES;     // tiles per workgroup round
 constexpr int LS_STAGE_WMAX = 9984;                   // columns per block at most: a 78-KiB window of x in LDS, two per CU
 constexpr int LS_STAGE_THREADS = 1024, LS_STAGE_IPT = 8;
 
@@ -2425,6 +2518,65 @@ __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict
     a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);      // offset inside the block's window
     a_dst[pa] = pos;
     sidx[w] = (ix & LS_START_BIT) | (uint32_t)pos;
+}
+
+// Tile-major staging.  The positions above put the staged values of one workgroup ROUND (16 tiles) side by side, ordered
+// by column block: cheap for the copy pass, but a wavefront's ~113 cold entries then lie scattered over the round's 14 KB
+// and each of its gather lanes pulls its own 128-B line into L1 (9 * 10^6 line fills per SpMV at ~4 CU clocks each).
+// Here the staged values of one TILE are contiguous instead -- xg[tile_cold[t] .. tile_cold[t + 1]) -- so the stream
+// kernel fetches them with coalesced loads (spmv_lstream_kernel<true>), and inside a tile they are ordered by the XCD
+// that copies them (octant = column block / blocks per XCD, the copy pass's own assignment), so that what one XCD's
+// workgroups write into a tile's range is one contiguous piece and still merges into whole lines in that XCD's L2.
+// One wavefront per tile: rank[w] = offset of index word w's value inside its tile's range (octant-major, inside an
+// octant in physical word order: deterministic), tile_cnt[t] = staged values of the tile.
+__global__ __launch_bounds__(256) void ls_cold_rank_kernel(const uint32_t *__restrict__ sidx, int64_t n_tiles, int32_t W,
+                                                          int32_t blk_per_oct, uint16_t *__restrict__ rank,
+                                                          int32_t *__restrict__ tile_cnt)
+{
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (t >= n_tiles) return;
+    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
+    int oct[ACC_K], r[ACC_K];
+#pragma unroll
+    for (int u = 0; u < ACC_K; u++) {
+        const uint32_t ix = sidx[t * ACC_TILE + u * WAVE + lane];
+        int o = (int)((ix & LS_COL_MASK) / (uint32_t)W) / blk_per_oct;
+        oct[u] = ls_is_cold(ix) ? (o < 7 ? o : 7) : 8;
+        r[u] = 0;
+    }
+    int start = 0;
+    for (int o = 0; o < 8; o++) {
+#pragma unroll
+        for (int u = 0; u < ACC_K; u++) {
+            const unsigned long long m = __ballot(oct[u] == o);
+            if (oct[u] == o) r[u] = start + __popcll(m & below);
+            start += __popcll(m);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < ACC_K; u++) rank[t * ACC_TILE + u * WAVE + lane] = (uint16_t)r[u];
+    if (lane == 0) tile_cnt[t] = start;
+}
+
+// tile-major form of ls_cold_place_kernel: position = the tile's start + the rank; the index word keeps the rank
+__global__ __launch_bounds__(256) void ls_cold_place_tile_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
+                                                                int32_t W, const int32_t *__restrict__ tile_cold,
+                                                                const uint16_t *__restrict__ rank,
+                                                                const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
+                                                                uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t ix = sidx[w];
+    if (!ls_is_cold(ix)) return;
+    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const uint32_t c = ix & LS_COL_MASK;
+    const int32_t b = (int32_t)(c / (uint32_t)W);
+    const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
+    a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);
+    a_dst[pa] = tile_cold[w / ACC_TILE] + (int32_t)rank[w];
+    sidx[w] = (ix & LS_START_BIT) | (uint32_t)rank[w];
 }
 
 // xg[a_dst[k]] = x[a_col[k]] for the entries of one column block: the block's window of x is copied into LDS with
@@ -2553,13 +2705,35 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     if (n_cold < 1 || n_all >= (int64_t)LS_PAD || (!(env && env[0] == '1') && n_cold * 16 < n_words)) return CSRK_OK;
     CSRK_TRY(exclusive_scan_i32(cnt.as<int32_t>(), cnt.as<int32_t>(), nb + 1, s));
     CSRK_TRY(exclusive_scan_i32(cntT.as<int32_t>(), cntT.as<int32_t>(), nb + 1, s));
-    CSRK_TRY(ls->xg.alloc((size_t)n_all * 8));
+    CSRK_TRY(ls->xg.alloc((size_t)(n_all + WAVE) * 8));      // (+ padding: the stream kernel's last pair of an odd count)
     CSRK_TRY(ls->a_col.alloc((size_t)n_all * 2));
     CSRK_TRY(ls->a_dst.alloc((size_t)n_all * 4));
+    // Measured on the headline matrix (tools/sweep_inproc.py): the tile-major form takes the stream kernel from 0.214 to
+    // 0.178 ms (its cold gathers were a fifth of its L1 line fills) but the copy pass from 0.064 to 0.125 ms -- every value
+    // it writes is then a store transaction of its own (~13 ps each chip-wide; the round-major form averages 0.55 per
+    // value) -- so it stays opt-in (CSRK_LS_XGT=1) until the copy is done in two coalesced passes.
+    const char *xgt_env = getenv("CSRK_LS_XGT");
+    if (xgt_env && xgt_env[0] == '1') {
+        // tile-major positions (see ls_cold_rank_kernel); the copy list keeps its (block, round) order
+        DevBuf rank;
+        CSRK_TRY(rank.alloc((size_t)n_words * 2));
+        CSRK_TRY(ls->tile_cold.alloc((size_t)(ls->n_tiles + 2) * 4));
+        ls_cold_rank_kernel<<<(unsigned)ceil_div(ls->n_tiles * WAVE, 256), 256, 0, s>>>(
+            ls->idx.as<uint32_t>(), ls->n_tiles, (int32_t)W, (int32_t)ceil_div(nblk, 8), rank.as<uint16_t>(),
+            ls->tile_cold.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_TRY(exclusive_scan_i32(ls->tile_cold.as<int32_t>(), ls->tile_cold.as<int32_t>(), ls->n_tiles, s));
+        ls_cold_place_tile_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)W,
+                                                    ls->tile_cold.as<int32_t>(), rank.as<uint16_t>(), cntT.as<int32_t>(),
+                                                    off.as<int32_t>(), ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipStreamSynchronize(s));      // `rank` is freed here
+    } else {
     ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
                                            cntT.as<int32_t>(), off.as<int32_t>(), ls->a_col.as<uint16_t>(),
                                            ls->a_dst.as<int32_t>());
     CSRK_LAUNCH_CHECK();
+    }
     ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
                                                                        cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
                                                                        ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
@@ -2927,12 +3101,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 constexpr size_t t1_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                 LightStream &t = p->t1s;
                 KernelTimer kh(p, s, 2);
-                spmv_lstream_kernel<<<t.grid, LS_THREADS, t1_lds, s>>>(
+                spmv_lstream_kernel<false><<<t.grid, LS_THREADS, t1_lds, s>>>(
                     t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
                     t.carry_idx.as<int32_t>(), d_x,
                     (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(),
                     p->n_hot ? p->n_hot_lds : 0, t.n_tiles, t.n_runs, t.n_out,
-                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>());
+                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr);
                 kh.stop();
                 CSRK_LAUNCH_CHECK();
                 if (aux) {
@@ -2989,11 +3163,15 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                     x_cold = p->ls.xg.as<double>();
                     x_pack = x_cold + p->ls.n_cold;
                 }
-                spmv_lstream_kernel<<<p->ls.grid, LS_THREADS, ls_lds, s>>>(
-                    p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(),
-                    p->ls.tile_base.as<int32_t>(), (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds,
-                    p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,
-                    p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>());
+#define LS_ARGS                                                                                                       \
+    p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),      \
+        (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
+        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.tile_cold.as<int32_t>()
+                if (p->ls.n_cold && p->ls.tile_cold.p)
+                    spmv_lstream_kernel<true><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS);
+                else
+                    spmv_lstream_kernel<false><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS);
+#undef LS_ARGS
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
                 if (p->n_heavy) {
@@ -3337,6 +3515,15 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     for (int i = 0; i < n && i < 25; i++) out[i] = v[i];
     return CSRK_OK;
 }
+
+#ifdef CSRK_LS_STAMPS
+CSRK_API int csrk_debug_ls_stamps(unsigned long long *out, int n)
+{
+    CSRK_HIP(hipDeviceSynchronize());
+    CSRK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_stamps), (size_t)n * 8));
+    return CSRK_OK;
+}
+#endif
 
 int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items)
 {
