@@ -11,18 +11,41 @@
 // nothing to offer (a sparse row shares no B rows with its neighbours, so a 16x16x4 tile
 // would be 1/16 populated).  DESIGN.md section "SpMM" has the numbers.
 //
-// One wavefront per row segment (rows longer than 256 entries are split so the 10^5-entry
-// rows of a power-law matrix do not serialise on one wave); segment partial panels are
-// combined in segment order by a second kernel -- no float atomics, bitwise reproducible.
+// Sixteen lanes per row segment, four segments per wavefront (rows longer than 64 entries are split so the
+// 10^5-entry rows of a power-law matrix do not serialise on one wave): a lane owns four consecutive panel
+// columns (two 16-B loads per B row), so a wavefront has four DIFFERENT rows' gathers in flight -- the average
+// row of the BASELINE matrix has 13 entries, and with one wavefront per row the kernel was a chain of dependent
+// round trips (segment -> row pointer -> entries -> B rows -> store) that only wavefront count hid.  Segment
+// partial panels are combined in segment order by a second kernel -- no float atomics, bitwise reproducible.
 #include "common.h"
+
+#include <algorithm>
+#include <vector>
 
 namespace csrk {
 
-constexpr int MM_SEG = 256;
+constexpr int MM_SEG = 64;       // entries per segment (light rows)
+constexpr int MM_G = 16;         // lanes per unit (segment or row slice): 16 lanes x 4 columns = a 64-column chunk of the panel
+constexpr int MM_CHUNK = 64;     // panel columns per pass over a unit's entries
+
+// one segment of a light row: entries [start, start + n) of the CSR arrays; the result goes to row `row` of C
+// (part < 0) or to partial panel `part` (split rows)
+struct SegDesc {
+    int64_t start;
+    int32_t n;
+    int32_t row;
+    int64_t part;
+};
 
 struct SpmmPlan {
     Tier0View heavy;           // heavy rows come from the SpMV plan's column-block-major panel (or .on == false)
-    DevBuf hpart;              // double[pairs * k]: per-(block, row) partial panels
+    // heavy rows: a row of L entries is cut into ceil(L / slice) parallel SLICES; slice p of P takes the p-th P-th of
+    // every (column block, row) pair's entries, so all slices have about the same work in every block
+    DevBuf slice;              // HeavySlice[n_slices]
+    DevBuf slice_first;        // int32[n_rows + 1]: first slice of each heavy row
+    int64_t n_slices = 0;
+    int32_t n_wg = 0;          // persistent workgroups per XCD stream (CUs / 8)
+    DevBuf hpart;              // double[n_slices * MM_STREAMS * k]: one partial panel per (slice, XCD stream)
     int32_t hpart_k = 0;
     int64_t n_segs = 0;
     int64_t n_multi = 0;       // segments belonging to split rows (need a partial panel)
@@ -30,7 +53,7 @@ struct SpmmPlan {
     DevBuf split_rows;         // int32[n_split]: rows with more than one segment
     int32_t n_split = 0;
     DevBuf seg_off;            // int64[nrows + 1]
-    DevBuf seg_row;            // int32[n_segs]
+    DevBuf seg;                // SegDesc[n_segs]
     DevBuf part;               // double[n_segs * k] (allocated on demand)
     int32_t part_k = 0;
 };
@@ -46,39 +69,80 @@ __device__ __forceinline__ double mm_val(const void *v, int64_t k)
 }
 
 
-// acc += sum over entries [s, e) of val * B[col, c].  The wavefront first loads 64 entries' (col, val)
-// with one coalesced load per array, then walks them 8 at a time with the indices broadcast by
-// shuffles, so 8 independent B-row loads are in flight per wavefront.  (Loading an index, then its B
-// row, then the next index made both SpMM kernels latency-bound: ~100 ps per entry.)  `live` = this lane
-// owns a panel column; dead lanes still take part in the shuffles.
-constexpr int MM_UNROLL = 8;
-template <int VT>
-__device__ __forceinline__ double mm_accumulate(const int32_t *__restrict__ ci, const void *__restrict__ vs, int64_t s,
-                                                int64_t e, const double *__restrict__ B, int64_t ldb, int32_t c,
-                                                bool live, int lane)
+typedef double mm_f64x2 __attribute__((ext_vector_type(2)));
+typedef mm_f64x2 MMF64x2 __attribute__((aligned(8)));
+
+__device__ __forceinline__ int mm_wave_max4(int n)      // n is uniform inside each group of 16 lanes
 {
-    double acc = 0.0;
-    for (int64_t base = s; base < e; base += WAVE) {
-        const int n = (int)(e - base < WAVE ? e - base : WAVE);
-        const int32_t mycol = lane < n ? ci[base + lane] : 0;
-        const double myval = lane < n ? mm_val<VT>(vs, base + lane) : 0.0;
-        for (int j = 0; j < n; j += MM_UNROLL) {
-            double bv[MM_UNROLL], av[MM_UNROLL];
+    const int a = __builtin_amdgcn_readlane(n, 0), b = __builtin_amdgcn_readlane(n, 16);
+    const int c = __builtin_amdgcn_readlane(n, 32), d = __builtin_amdgcn_readlane(n, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+// acc[i] += sum over the unit's entries [s, s + n) of val * B[col, c + i], i < 4, in storage order.  The 16 lanes of
+// the unit load 16 entries' (col, val) with one coalesced load per array and walk them 4 at a time with the indices
+// broadcast inside the group, so 4 B rows (x 4 units) are in flight per wavefront; `nmax` is the wavefront's longest
+// unit (uniform trip counts keep the cross-lane broadcasts legal); entries past this unit's n re-read B row 0 / the
+// unit's own rows and are selected away AFTER the multiply (0 * inf).  FULL4: k is a multiple of 4, so a live lane
+// owns four whole columns and fetches them with two 16-B loads; otherwise column by column.
+constexpr int MM_UNROLL = 4;
+template <int VT, bool FULL4>
+__device__ __forceinline__ void mm_unit(const int32_t *__restrict__ ci, const void *__restrict__ vs, int64_t s, int n,
+                                        int nmax, const double *__restrict__ B, int64_t ldb, int32_t c, int32_t k,
+                                        int sub, double acc[4])
+{
+    const int nv = c >= k ? 0 : (FULL4 ? 4 : (k - c < 4 ? k - c : 4));      // panel columns this lane owns
+    for (int base = 0; base < nmax; base += MM_G) {
+        const int idx = base + sub;
+        const int32_t mycol = idx < n ? ci[s + idx] : 0;
+        const double myval = idx < n ? mm_val<VT>(vs, s + idx) : 0.0;
+        const int nb = nmax - base < MM_G ? nmax - base : MM_G;
+        for (int j = 0; j < nb; j += MM_UNROLL) {
+            double b[MM_UNROLL][4], av[MM_UNROLL];
 #pragma unroll
             for (int u = 0; u < MM_UNROLL; u++) {
-                const int src = j + u < n ? j + u : n - 1;          // clamped: every load is a real entry's row
-                const int32_t cu = __shfl(mycol, src, WAVE);
-                av[u] = __shfl(myval, src, WAVE);
-                bv[u] = live ? B[(int64_t)cu * ldb + c] : 0.0;
+                const int32_t cu = __shfl(mycol, j + u, MM_G);
+                av[u] = __shfl(myval, j + u, MM_G);
+                const double *p = B + (int64_t)cu * ldb + c;
+                if (FULL4) {
+                    mm_f64x2 t0 = {0.0, 0.0}, t1 = {0.0, 0.0};
+                    if (nv) {
+                        t0 = *(const MMF64x2 *)p;
+                        t1 = *(const MMF64x2 *)(p + 2);
+                    }
+                    b[u][0] = t0.x, b[u][1] = t0.y, b[u][2] = t1.x, b[u][3] = t1.y;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) b[u][i] = i < nv ? p[i] : 0.0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < MM_UNROLL; u++) {
-                const double t = av[u] * bv[u];
-                acc += j + u < n ? t : 0.0;                          // masked after the multiply (0 * inf)
+                const bool ok = base + j + u < n;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double t = av[u] * b[u][i];
+                    acc[i] += ok ? t : 0.0;                      // masked after the multiply (0 * inf)
+                }
             }
         }
     }
-    return acc;
+}
+
+template <bool FULL4>
+__device__ __forceinline__ void mm_store4(double *__restrict__ dst, int32_t c, int32_t k, const double acc[4])
+{
+    if (c >= k) return;
+    if (FULL4) {
+        mm_f64x2 t0 = {acc[0], acc[1]}, t1 = {acc[2], acc[3]};
+        *(MMF64x2 *)(dst + c) = t0;
+        *(MMF64x2 *)(dst + c + 2) = t1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (c + i < k) dst[c + i] = acc[i];
+    }
 }
 
 // heavy_min > 0: rows with at least that many entries are served by the heavy-row kernels (0 segments here)
@@ -99,91 +163,156 @@ __global__ void mm_count_kernel(const P *__restrict__ rp, int32_t nrows, int64_t
 // HBM stream (B does not fit the Infinity Cache).  The SpMV plan already holds the heavy rows re-sorted
 // into (column block, row) pairs of 4096 columns; per block the B rows it needs are 4096 * k * 8 B = 2 MiB
 // at k = 64, which stays in an XCD's L2 when the block is served by one XCD (workgroups with
-// blockIdx % 8 == block % 8; a speed assumption only).  One wavefront per pair, lane = panel column,
-// partial panels per pair, summed per row in block order: deterministic.
+// blockIdx % 8 == block % 8; a speed assumption only).
+//
+// Block-synchronous slices.  The first version ran one wavefront per pair and wrote a partial panel per pair
+// (1.5 * 10^6 pairs of ~16 entries on the BASELINE matrix: 0.75 GB written and read again, and the window shared L2
+// with that stream: 73 % hit rate, the kernel bound by L1 line fills and partial traffic).  Now a heavy row of L
+// entries is cut into ceil(L / slice) SLICES (slice p of P takes the p-th P-th of every pair of the row, so every slice
+// has about the same number of entries in every block), and one persistent 1024-thread workgroup per CU -- 32 per XCD
+// stream g -- holds MM_R slices per 16-lane unit with their four panel columns per lane in REGISTERS and walks the
+// stream's blocks g, g + 8, ... with a workgroup barrier per block.  A workgroup's slices are a uniform sample of all
+// slices (slice s goes to workgroup s mod 32), so the workgroups of a stream do the same amount of work per block to
+// within a few per cent and move through the blocks together with no synchronisation between them: the B rows of the
+// block they are at are what their XCD's L2 holds (a speed assumption only: any placement computes the same bits).
+// One partial per (slice, stream) is written at the end and the reduce kernel adds a row's partials in order.
+// (Units that walk the blocks on their own, without the barrier, drift apart by several blocks and lose the window:
+// 22 % L2 hit rate, 12.5 GB of fabric reads -- measured; with it 91 % and 1.4 GB.)
 constexpr int MM_STREAMS = 8;
+constexpr int MM_R = 4;                      // slices per unit (their accumulators: 4 x 4 doubles per lane)
+constexpr int MM_HEAVY_THREADS = 1024;
+constexpr int MM_HEAVY_UNITS = MM_HEAVY_THREADS / MM_G;      // 64
+#ifndef CSRK_MM_SLICE
+#define CSRK_MM_SLICE 2048
+#endif
+constexpr int MM_SLICE = CSRK_MM_SLICE;     // smallest slice; doubled until the slices fit the persistent grid
 
-template <class PP>
-__global__ __launch_bounds__(256) void spmm_heavy_kernel(const PP *__restrict__ prp, const int32_t *__restrict__ pci,
-                                                        const double *__restrict__ pvs, const double *__restrict__ B,
-                                                        int32_t k, int64_t ldb, int32_t n_rows, int32_t n_blocks,
-                                                        double *__restrict__ part)
+struct HeavySlice {
+    int32_t h;       // heavy-row index
+    int32_t p, P;    // slice p of P
+};
+
+template <class PP, bool FULL4>
+__global__ __launch_bounds__(MM_HEAVY_THREADS) void spmm_heavy_kernel(
+    const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
+    const double *__restrict__ B, int32_t k, int64_t ldb, int32_t n_rows, int32_t n_blocks,
+    const HeavySlice *__restrict__ slice, int64_t n_slices, int32_t n_wg, double *__restrict__ part)
 {
     const int g = blockIdx.x % MM_STREAMS;
-    const int64_t j = (int64_t)(blockIdx.x / MM_STREAMS) * (256 / WAVE) + threadIdx.x / WAVE;   // pair index inside the stream
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t b = g + (int64_t)MM_STREAMS * (j / n_rows);
-    if (b >= n_blocks) return;
-    const int64_t q = b * n_rows + j % n_rows;
-    const int64_t s = prp[q], e = prp[q + 1];
-    if (s == e) return;                                  // empty pair: the reduce skips it too
-    for (int32_t c0 = 0; c0 < k; c0 += WAVE) {
-        const int32_t c = c0 + lane;
-        const bool live = c < k;
-        const double acc = mm_accumulate<CSRK_VAL_F64>(pci, pvs, s, e, B, ldb, live ? c : 0, live, lane);
-        if (live) part[q * (int64_t)k + c] = acc;
+    const int wg = blockIdx.x / MM_STREAMS;
+    const int unit = threadIdx.x / MM_G, sub = threadIdx.x & (MM_G - 1);
+    // slice r of this unit: s = wg + n_wg * (unit + 64 r); (row, p, P) packed in two registers per slice
+    const int64_t sid0 = wg + (int64_t)n_wg * unit, sstep = (int64_t)n_wg * MM_HEAVY_UNITS;
+    int32_t sh[MM_R];
+    uint32_t spP[MM_R];      // p in the low 16 bits, P in the high 16
+#pragma unroll
+    for (int r = 0; r < MM_R; r++) {
+        sh[r] = 0, spP[r] = 1u << 16;
+        if (sid0 + sstep * r < n_slices) {
+            const HeavySlice t = slice[sid0 + sstep * r];
+            sh[r] = t.h;
+            spP[r] = (uint32_t)t.p | ((uint32_t)t.P << 16);
+        }
+    }
+    for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
+        const int32_t c = c0 + 4 * sub;
+        double acc[MM_R][4];
+#pragma unroll
+        for (int r = 0; r < MM_R; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[r][i] = 0.0;
+        for (int64_t b = g; b < n_blocks; b += MM_STREAMS) {
+            int32_t a0[MM_R], n0[MM_R];
+#pragma unroll
+            for (int r = 0; r < MM_R; r++) {                       // all pair ranges first: independent loads
+                const int64_t q = b * n_rows + sh[r];
+                const bool in = sid0 + sstep * r < n_slices;
+                const int64_t t0 = in ? (int64_t)prp[q] : 0;
+                n0[r] = in ? (int32_t)((int64_t)prp[q + 1] - t0) : 0;
+                a0[r] = (int32_t)(t0 - (int64_t)prp[b * n_rows]);      // relative to the block's first entry (fits 32 bits)
+            }
+            const int64_t blk0 = (int64_t)prp[b * n_rows];
+#pragma unroll
+            for (int r = 0; r < MM_R; r++) {
+                const int64_t p_ = spP[r] & 0xffffu, P_ = spP[r] >> 16;
+                const int64_t lo = (int64_t)n0[r] * p_ / P_, hi = (int64_t)n0[r] * (p_ + 1) / P_;
+                const int n = (int)(hi - lo);
+                const int nmax = mm_wave_max4(n);
+                if (nmax) mm_unit<CSRK_VAL_F64, FULL4>(pci, pvs, blk0 + a0[r] + lo, n, nmax, B, ldb, c, k, sub, acc[r]);
+            }
+            __syncthreads();      // the workgroup's 64 units enter the next block together
+        }
+#pragma unroll
+        for (int r = 0; r < MM_R; r++)
+            if (sid0 + sstep * r < n_slices)
+                mm_store4<FULL4>(part + ((sid0 + sstep * r) * MM_STREAMS + g) * (int64_t)k, c, k, acc[r]);
     }
 }
 
-template <class PP>
-__global__ __launch_bounds__(256) void spmm_heavy_reduce_kernel(const PP *__restrict__ prp, const int32_t *__restrict__ row_list,
-                                                               int32_t n_rows, int32_t n_blocks, int32_t k,
-                                                               const double *__restrict__ part, double *__restrict__ C,
-                                                               int64_t ldc)
+// C[row] = sum of the row's partials, slices in order, streams in order inside a slice: one wavefront per heavy row
+__global__ __launch_bounds__(256) void spmm_heavy_reduce_kernel(const int32_t *__restrict__ slice_first,
+                                                               const int32_t *__restrict__ row_list, int32_t n_rows,
+                                                               int32_t k, const double *__restrict__ part,
+                                                               double *__restrict__ C, int64_t ldc)
 {
     const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     if (h >= n_rows) return;
     const int64_t r = row_list[h];
+    const int64_t p0 = (int64_t)slice_first[h] * MM_STREAMS, p1 = (int64_t)slice_first[h + 1] * MM_STREAMS;
     for (int32_t c = lane; c < k; c += WAVE) {
         double acc = 0.0;
-        for (int64_t b0 = 0; b0 < n_blocks; b0 += MM_UNROLL) {
-            double v[MM_UNROLL];
+        int64_t q = p0;
+        for (; q + 8 <= p1; q += 8) {                                 // 8 partial rows in flight, added in order
+            double v[8];
 #pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {                 // 8 partial rows in flight, added in block order
-                const int64_t b = b0 + u < n_blocks ? b0 + u : n_blocks - 1;
-                const int64_t q = b * n_rows + h;
-                const bool have = b0 + u < n_blocks && prp[q] != prp[q + 1];
-                const double t = part[q * (int64_t)k + c];        // unconditional load (valid memory), select after
-                v[u] = have ? t : 0.0;
-            }
+            for (int t = 0; t < 8; t++) v[t] = part[(q + t) * (int64_t)k + c];
 #pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) acc += v[u];
+            for (int t = 0; t < 8; t++) acc += v[t];
         }
+        for (; q < p1; q++) acc += part[q * (int64_t)k + c];
         C[r * ldc + c] = acc;
     }
 }
 
-__global__ void mm_fill_kernel(const int64_t *__restrict__ seg_off, int32_t nrows, int32_t *__restrict__ seg_row)
+// one thread per row: descriptors of its segments (plan time)
+template <class P>
+__global__ void mm_fill_kernel(const P *__restrict__ rp, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ part_off,
+                               int32_t nrows, SegDesc *__restrict__ seg)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
-    for (int64_t q = seg_off[r]; q < seg_off[r + 1]; q++) seg_row[q] = (int32_t)r;
+    const int64_t q0 = seg_off[r], nseg = seg_off[r + 1] - q0;
+    const int64_t s = rp[r], e = rp[r + 1];
+    for (int64_t i = 0; i < nseg; i++) {
+        SegDesc d;
+        d.start = s + i * MM_SEG;
+        d.n = (int32_t)((e - d.start) < MM_SEG ? (e - d.start) : MM_SEG);
+        d.row = (int32_t)r;
+        d.part = nseg == 1 ? -1 : part_off[r] + i;
+        seg[q0 + i] = d;
+    }
 }
 
-// One wavefront per row segment of the rows that are not served by the heavy-row kernels.
-template <class P, int VT>
-__global__ __launch_bounds__(256) void spmm_seg_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                      const void *__restrict__ vs, const double *__restrict__ B,
-                                                      int32_t k, int64_t ldb, double *__restrict__ C, int64_t ldc,
-                                                      const int64_t *__restrict__ seg_off,
-                                                      const int32_t *__restrict__ seg_row, int64_t n_segs,
-                                                      const int64_t *__restrict__ part_off, double *__restrict__ part)
+// Sixteen lanes per row segment of the rows that are not served by the heavy-row kernels.
+template <int VT, bool FULL4>
+__global__ __launch_bounds__(256) void spmm_seg_kernel(const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                      const double *__restrict__ B, int32_t k, int64_t ldb,
+                                                      double *__restrict__ C, int64_t ldc, const SegDesc *__restrict__ seg,
+                                                      int64_t n_segs, double *__restrict__ part)
 {
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (q >= n_segs) return;
-    const int32_t r = seg_row[q];
-    const int64_t first = seg_off[r], nseg = seg_off[r + 1] - first;
-    const int64_t s = (int64_t)rp[r] + (q - first) * MM_SEG;
-    int64_t e = (int64_t)rp[r + 1];
-    if (nseg > 1 && e > s + MM_SEG) e = s + MM_SEG;
-    double *dst = nseg == 1 ? C + (int64_t)r * ldc : part + (part_off[r] + (q - first)) * (int64_t)k;
-    for (int32_t c0 = 0; c0 < k; c0 += WAVE) {
-        const int32_t c = c0 + lane;
-        const bool live = c < k;
-        const double acc = mm_accumulate<VT>(ci, vs, s, e, B, ldb, live ? c : 0, live, lane);
-        if (live) dst[c] = acc;
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MM_G;
+    const int sub = threadIdx.x & (MM_G - 1);
+    SegDesc d;
+    d.start = 0, d.n = 0, d.row = 0, d.part = -1;
+    if (q < n_segs) d = seg[q];
+    const int nmax = mm_wave_max4(d.n);
+    double *dst = d.part < 0 ? C + (int64_t)d.row * ldc : part + d.part * (int64_t)k;
+    for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
+        const int32_t c = c0 + 4 * sub;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        mm_unit<VT, FULL4>(ci, vs, d.start, d.n, nmax, B, ldb, c, k, sub, acc);
+        if (q < n_segs) mm_store4<FULL4>(dst, c, k, acc);      // (an empty row's single segment stores its zeros)
     }
 }
 
@@ -246,12 +375,72 @@ static int build_mm_plan(Matrix *m, SpmmPlan *p, hipStream_t s)
         CSRK_HIP(hipMemcpyAsync(&p->n_split, cnt.p, 4, hipMemcpyDeviceToHost, s));
         CSRK_HIP(hipStreamSynchronize(s));
     }
-    CSRK_TRY(p->seg_row.alloc((size_t)n * 4));
+    CSRK_TRY(p->seg.alloc((size_t)n * sizeof(SegDesc)));
     if (m->nrows > 0) {
-        mm_fill_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(p->seg_off.as<int64_t>(), m->nrows,
-                                                                        p->seg_row.as<int32_t>());
+        mm_fill_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>((const P *)m->d_rowptrs, p->seg_off.as<int64_t>(),
+                                                                           p->part_off.as<int64_t>(), m->nrows,
+                                                                           p->seg.as<SegDesc>());
         CSRK_LAUNCH_CHECK();
     }
+    return CSRK_OK;
+}
+
+// the slice table of the heavy rows (host: a few thousand rows)
+template <class P>
+__global__ void mm_heavy_len_kernel(const P *__restrict__ rp, const int32_t *__restrict__ row_list, int32_t n_rows,
+                                    int64_t *__restrict__ len)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n_rows) len[h] = (int64_t)rp[row_list[h] + 1] - (int64_t)rp[row_list[h]];
+}
+
+static int build_heavy_slices(Matrix *m, SpmmPlan *p, hipStream_t s)
+{
+    const Tier0View &hv = p->heavy;
+    DevBuf dlen;
+    CSRK_TRY(dlen.alloc((size_t)hv.n_rows * 8));
+    const unsigned g = (unsigned)ceil_div(hv.n_rows, 256);
+    if (m->ptr64)
+        mm_heavy_len_kernel<int64_t><<<g, 256, 0, s>>>((const int64_t *)m->d_rowptrs, hv.row_list, hv.n_rows, dlen.as<int64_t>());
+    else
+        mm_heavy_len_kernel<int32_t><<<g, 256, 0, s>>>((const int32_t *)m->d_rowptrs, hv.row_list, hv.n_rows, dlen.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    std::vector<int64_t> len((size_t)hv.n_rows);
+    CSRK_HIP(hipMemcpyAsync(len.data(), dlen.p, (size_t)hv.n_rows * 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    int cus = 0;
+    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    p->n_wg = (cus > 0 ? cus : 256) / MM_STREAMS;
+    if (p->n_wg < 1) p->n_wg = 1;
+    const int64_t cap = (int64_t)p->n_wg * MM_HEAVY_UNITS * MM_R;      // slices the persistent grid holds per stream
+    if (hv.n_rows > cap) {      // more heavy rows than accumulators: the pair panel is not used
+        p->heavy.on = false;
+        return CSRK_OK;
+    }
+    int64_t slice_len = MM_SLICE;
+    for (;; slice_len *= 2) {
+        int64_t cnt = 0, pmax = 0;
+        for (int32_t h = 0; h < hv.n_rows; h++) {
+            const int64_t P = len[(size_t)h] > slice_len ? ceil_div(len[(size_t)h], slice_len) : 1;
+            cnt += P;
+            pmax = std::max(pmax, P);
+        }
+        if ((cnt <= cap && pmax < 65536) || slice_len > (1ll << 40)) break;
+    }
+    std::vector<HeavySlice> sl;
+    std::vector<int32_t> first((size_t)hv.n_rows + 1);
+    for (int32_t h = 0; h < hv.n_rows; h++) {
+        first[(size_t)h] = (int32_t)sl.size();
+        const int32_t P = (int32_t)(len[(size_t)h] > slice_len ? ceil_div(len[(size_t)h], slice_len) : 1);
+        for (int32_t q = 0; q < P; q++) sl.push_back(HeavySlice{h, q, P});
+    }
+    first[(size_t)hv.n_rows] = (int32_t)sl.size();
+    p->n_slices = (int64_t)sl.size();
+    CSRK_TRY(p->slice.alloc(sl.size() * sizeof(HeavySlice)));
+    CSRK_TRY(p->slice_first.alloc(first.size() * 4));
+    CSRK_HIP(hipMemcpyAsync(p->slice.p, sl.data(), sl.size() * sizeof(HeavySlice), hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(p->slice_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipStreamSynchronize(s));      // `sl`, `first` are host temporaries
     return CSRK_OK;
 }
 
@@ -273,9 +462,11 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     if (!m->spmm_plan) {
         SpmmPlan *np = new (std::nothrow) SpmmPlan();
         CSRK_REQUIRE(np, "out of host memory");
-        if (hv.on && hv.pairs * (int64_t)k * 8 <= (4ll << 30)) np->heavy = hv;
+        if (hv.on) np->heavy = hv;
         // default stream + completion before use: see the caching allocator's contract (common.h)
-        int rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
+        int rc = CSRK_OK;
+        if (np->heavy.on) rc = build_heavy_slices(m, np, nullptr);      // (may turn the heavy path off: before the segment count)
+        if (rc == CSRK_OK) rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
         if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
         if (rc != CSRK_OK) {
             delete np;
@@ -289,49 +480,48 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     const bool grow_h = p->heavy.on && p->hpart_k < k, grow_p = p->n_multi > 0 && p->part_k < k;
     if ((grow_h && p->hpart.p) || (grow_p && p->part.p)) CSRK_HIP(hipDeviceSynchronize());
     if (grow_h) {
-        if (p->heavy.pairs * (int64_t)k * 8 > (4ll << 30)) {
-            set_error("panel width %d too large for the heavy-row partial buffer of this plan", k);
-            return CSRK_ERR_UNSUPPORTED;
-        }
-        CSRK_TRY(p->hpart.alloc((size_t)p->heavy.pairs * k * 8));
+        CSRK_TRY(p->hpart.alloc((size_t)p->n_slices * MM_STREAMS * k * 8));
         p->hpart_k = k;
     }
     if (grow_p) {           // some row is split: partial panels needed
         CSRK_TRY(p->part.alloc((size_t)p->n_multi * k * 8));
         p->part_k = k;
     }
+    const bool full4 = (k % 4) == 0;
     if (p->heavy.on) {
         const Tier0View &hvw = p->heavy;
-        const int64_t per_stream_blocks = ceil_div(hvw.n_blocks, MM_STREAMS);
-        const int64_t wgs = MM_STREAMS * ceil_div(per_stream_blocks * hvw.n_rows, 256 / WAVE);
+        const unsigned wgs = (unsigned)(MM_STREAMS * p->n_wg);
         const unsigned rgrid = (unsigned)ceil_div((int64_t)hvw.n_rows * WAVE, 256);
+#define HEAVY(PP, F4)                                                                                                  \
+    spmm_heavy_kernel<PP, F4><<<wgs, MM_HEAVY_THREADS, 0, s>>>((const PP *)hvw.rp, hvw.ci, hvw.vs, dB, k, ldb,         \
+                                                              hvw.n_rows, hvw.n_blocks, p->slice.as<HeavySlice>(),     \
+                                                              p->n_slices, p->n_wg, p->hpart.as<double>())
         if (hvw.p64) {
-            spmm_heavy_kernel<int64_t><<<(unsigned)wgs, 256, 0, s>>>((const int64_t *)hvw.rp, hvw.ci, hvw.vs, dB, k, ldb,
-                                                                    hvw.n_rows, hvw.n_blocks, p->hpart.as<double>());
-            spmm_heavy_reduce_kernel<int64_t><<<rgrid, 256, 0, s>>>((const int64_t *)hvw.rp, hvw.row_list, hvw.n_rows,
-                                                                   hvw.n_blocks, k, p->hpart.as<double>(), dC, ldc);
+            if (full4) HEAVY(int64_t, true);
+            else HEAVY(int64_t, false);
         } else {
-            spmm_heavy_kernel<int32_t><<<(unsigned)wgs, 256, 0, s>>>((const int32_t *)hvw.rp, hvw.ci, hvw.vs, dB, k, ldb,
-                                                                    hvw.n_rows, hvw.n_blocks, p->hpart.as<double>());
-            spmm_heavy_reduce_kernel<int32_t><<<rgrid, 256, 0, s>>>((const int32_t *)hvw.rp, hvw.row_list, hvw.n_rows,
-                                                                   hvw.n_blocks, k, p->hpart.as<double>(), dC, ldc);
+            if (full4) HEAVY(int32_t, true);
+            else HEAVY(int32_t, false);
         }
+#undef HEAVY
+        spmm_heavy_reduce_kernel<<<rgrid, 256, 0, s>>>(p->slice_first.as<int32_t>(), hvw.row_list, hvw.n_rows, k,
+                                                      p->hpart.as<double>(), dC, ldc);
         CSRK_LAUNCH_CHECK();
     }
     if (p->n_segs == 0) return CSRK_OK;
-    const unsigned grid = (unsigned)ceil_div(p->n_segs * WAVE, 256);
-#define GO(P, VT)                                                                                                     \
-    spmm_seg_kernel<P, VT><<<grid, 256, 0, s>>>((const P *)m->d_rowptrs, m->d_colinds, m->d_values, dB, k, ldb, dC, ldc, \
-                                                p->seg_off.as<int64_t>(), p->seg_row.as<int32_t>(), p->n_segs,         \
-                                                p->part_off.as<int64_t>(), p->part.as<double>())
-    if (m->ptr64) {
-        if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
-        else if (m->val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
-        else GO(int64_t, CSRK_VAL_NONE);
+    const unsigned grid = (unsigned)ceil_div(p->n_segs * MM_G, 256);
+#define GO(VT, F4)                                                                                                     \
+    spmm_seg_kernel<VT, F4><<<grid, 256, 0, s>>>(m->d_colinds, m->d_values, dB, k, ldb, dC, ldc, p->seg.as<SegDesc>(),   \
+                                                 p->n_segs, p->part.as<double>())
+    if (m->val_type == CSRK_VAL_F64) {
+        if (full4) GO(CSRK_VAL_F64, true);
+        else GO(CSRK_VAL_F64, false);
+    } else if (m->val_type == CSRK_VAL_F32) {
+        if (full4) GO(CSRK_VAL_F32, true);
+        else GO(CSRK_VAL_F32, false);
     } else {
-        if (m->val_type == CSRK_VAL_F64) GO(int32_t, CSRK_VAL_F64);
-        else if (m->val_type == CSRK_VAL_F32) GO(int32_t, CSRK_VAL_F32);
-        else GO(int32_t, CSRK_VAL_NONE);
+        if (full4) GO(CSRK_VAL_NONE, true);
+        else GO(CSRK_VAL_NONE, false);
     }
 #undef GO
     CSRK_LAUNCH_CHECK();

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_spmm
 rm -rf $OUT; mkdir -p $OUT
 i=0
-for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   PYTHONPATH=$GRAFT_REPO_ROOT rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/tools/bench_configs.py spmm > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
 done
