@@ -20,6 +20,14 @@
 //   + 4 (hist) + 16 (read) + 12 (write) = 64; structure only: 32.
 // Output rowptrs are read off the sorted keys (= the reference's histogram + running sum,
 // structure.py:180-188), which avoids a contended global-atomic histogram.
+//
+// Two-pass sorts (257 .. 65536 keys -- the MovieLens-shaped transpose of BASELINE configs[4]) with payloads below 2^24
+// take a leaner route, 56 instead of 72 bytes per record: pass 1 writes 12-byte records -- the float64 value and ONE
+// word holding the key's high digit (bits 31..24) and the payload (bits 23..0) -- pass 2 reads that word for its
+// histogram and its ranking and writes payload + value only, and its chunks are aligned to the runs pass 1 produced
+// (a chunk never spans two low digits), so the exclusive scan of the pass-2 digit table IS the output row pointers:
+// rowptr[hi * 256 + lo] = (records of smaller high digits) + (records of high digit hi in the chunks before low digit
+// lo's run).  No sorted-key array is written or read.
 #include "common.h"
 
 namespace csrk {
@@ -76,13 +84,20 @@ __device__ __forceinline__ int64_t rx_chunk_of(int64_t b, int64_t n_chunks)
 }
 
 // ---- radix pass: histogram ----------------------------------------------------------------
+// (cstart / ccnt: optional chunk descriptors -- first record and record count of every chunk -- for a pass whose chunks
+// are aligned to the previous pass's runs; without them chunk c is records [c * RX_CHUNK, (c + 1) * RX_CHUNK))
 __global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const int32_t *__restrict__ keys, int64_t n, int shift,
-                                                            int64_t n_chunks, int64_t *__restrict__ table)
+                                                            int64_t n_chunks, int64_t *__restrict__ table,
+                                                            const int64_t *__restrict__ cstart, const int32_t *__restrict__ ccnt)
 {
     __shared__ int32_t h[256];
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
-    const int64_t base = (int64_t)blockIdx.x * RX_CHUNK;
-    const int cnt = (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
+    const int64_t base = cstart ? cstart[blockIdx.x] : (int64_t)blockIdx.x * RX_CHUNK;
+    const int cnt = cstart ? ccnt[blockIdx.x] : (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
+    if (cnt <= 0) {                               // an unused chunk of an aligned pass: a column of zeros
+        if (threadIdx.x < 256) table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = 0;
+        return;
+    }
     int32_t key[RX_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RX_ROUNDS; r++) {        // unconditional (clamped) loads: all in flight together
@@ -187,13 +202,16 @@ __device__ __forceinline__ int32_t row_of(const P *__restrict__ rp, int64_t i, i
 // addresses: a direct scatter issues one 4-8-byte write request per record and array and runs at the
 // chip's request rate (~24 ps per record measured), whereas runs of equal digits (16 records on
 // average) coalesce into full-line writes.
-template <class P, int VT, int MODE>
+// PK (packed two-pass route, see the file header): 1 = its first pass -- rows_out receives the word {high digit of the
+// key, payload} instead of the payload, no keys are written --, 2 = its second pass -- keys_in is that word (digit =
+// bits 31..24 with shift 24, payload = bits 23..0), chunks come from the descriptors cstart / ccnt.
+template <class P, int VT, int MODE, int PK = 0>
 __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     const int32_t *__restrict__ keys_in, const int32_t *__restrict__ rows_in, const void *__restrict__ vals_in,
     const P *__restrict__ rp, int32_t nrows, int64_t n, int shift, int64_t n_chunks,
     const int64_t *__restrict__ table, const int64_t *__restrict__ total, const int32_t *__restrict__ chunk_rlo,
     const int32_t *__restrict__ chunk_rhi, int32_t *__restrict__ keys_out, int32_t *__restrict__ rows_out,
-    double *__restrict__ vals_out)
+    double *__restrict__ vals_out, const int64_t *__restrict__ cstart = nullptr, const int32_t *__restrict__ ccnt = nullptr)
 {
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
     constexpr bool FIRST = MODE == 1;
@@ -209,8 +227,9 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
     const int64_t chunk = rx_chunk_of(blockIdx.x, n_chunks);
     if (chunk >= n_chunks) return;
-    const int64_t base = chunk * RX_CHUNK;
-    const int cnt = (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
+    const int64_t base = PK == 2 ? cstart[chunk] : chunk * RX_CHUNK;
+    const int cnt = PK == 2 ? ccnt[chunk] : (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
+    if (cnt <= 0) return;                         // (an unused chunk of an aligned pass)
     if (tid < 256) {
         // global offset of this chunk's run of digit `tid` = exclusive scan of the digit totals + the
         // in-row prefix left by rx_scan_kernel
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
             else if (VT == CSRK_VAL_F32) val[r] = (double)((const float *)vals_in)[i];
             else val[r] = 0.0;
         } else {
-            row[r] = rows_in[i];
+            row[r] = PK == 2 ? (key[r] & 0xffffff) : rows_in[i];
             if (MODE == 2 && VT == CSRK_VAL_F32) val[r] = (double)((const float *)vals_in)[i];
             else val[r] = HAS_V ? ((const double *)vals_in)[i] : 0.0;
         }
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
             const int d = (key[r] >> shift) & 255;
             const int o = s_loff[d] + s_wh[w][d] + rank[r];
             s_key[o] = key[r];
-            s_row[o] = row[r];
+            s_row[o] = PK == 1 ? (int32_t)(((uint32_t)(key[r] >> 8) << 24) | (uint32_t)row[r]) : row[r];
             if (HAS_V) s_val[o] = val[r];
         }
     }
@@ -361,13 +380,70 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
     }
 }
 
+// ---- packed two-pass route: chunks of pass 2 aligned to the runs of pass 1 ---------------------------------
+// run d (the records whose low digit is d, in pass-1 order) = [R[d], R[d + 1]) with R = exclusive scan of total1;
+// it is cut into ceil(len / RX_CHUNK) chunks.  One workgroup of 256 threads: thread d scans, then fills its chunks.
+__global__ __launch_bounds__(256) void rx_align_kernel(const int64_t *__restrict__ total1, int64_t n_chunks_cap,
+                                                      int64_t *__restrict__ cstart, int32_t *__restrict__ ccnt,
+                                                      int64_t *__restrict__ run_chunk0)
+{
+    __shared__ int64_t s_start[257], s_c0[257];
+    const int d = threadIdx.x;
+    const int64_t len = total1[d];
+    s_start[d + 1] = len;
+    s_c0[d + 1] = (len + RX_CHUNK - 1) / RX_CHUNK;
+    if (d == 0) s_start[0] = 0, s_c0[0] = 0;
+    __syncthreads();
+    if (d == 0)
+        for (int q = 1; q <= 256; q++) s_start[q] += s_start[q - 1], s_c0[q] += s_c0[q - 1];
+    __syncthreads();
+    const int64_t c0 = s_c0[d], c1 = s_c0[d + 1], st = s_start[d];
+    run_chunk0[d] = c0;
+    if (d == 255) run_chunk0[256] = c1;
+    for (int64_t c = c0; c < c1; c++) {
+        cstart[c] = st + (c - c0) * RX_CHUNK;
+        const int64_t left = len - (c - c0) * RX_CHUNK;
+        ccnt[c] = (int32_t)(left < RX_CHUNK ? left : RX_CHUNK);
+    }
+    for (int64_t c = s_c0[256] + d; c < n_chunks_cap; c += 256) {      // the unused tail of the descriptor arrays
+        cstart[c] = 0;
+        ccnt[c] = 0;
+    }
+}
+
+// rowptr[hi * 256 + lo] = records of smaller high digits + records of high digit hi in the chunks before run lo
+// (table2 holds the exclusive prefix over chunks of every digit's row, total2 the rows' totals)
+template <class P>
+__global__ __launch_bounds__(256) void rx_rowptr_from_table_kernel(const int64_t *__restrict__ table2, const int64_t *__restrict__ total2,
+                                                                  const int64_t *__restrict__ run_chunk0, int64_t n_chunks,
+                                                                  int32_t key_range, int64_t n, P *__restrict__ out_ptr)
+{
+    __shared__ int64_t s_before[257];
+    if (threadIdx.x == 0) {
+        s_before[0] = 0;
+        for (int q = 0; q < 256; q++) s_before[q + 1] = s_before[q] + total2[q];
+    }
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > key_range) return;
+    if (c == key_range) {
+        out_ptr[c] = (P)n;
+        return;
+    }
+    const int hi = (int)(c >> 8), lo = (int)(c & 255);
+    const int64_t ch = run_chunk0[lo];
+    const int64_t in_row = ch < n_chunks ? table2[(int64_t)hi * n_chunks + ch] : total2[hi];
+    out_ptr[c] = (P)(s_before[hi] + in_row);
+}
+
 // Stable sort of n records by a key in [0, key_range): payload (int32) -> out_payload, values (widened
 // to float64) -> out_vals, and the run starts of every key -> out_ptr[0..key_range].  FROM_CSR: the records
 // are the entries of a CSR matrix (keys = its colinds, payload = the entry's row, from `rp`); otherwise
 // keys / payload / values are the given device arrays (COO ingest).
 template <class P, int VT, bool FROM_CSR>
 static int sort_records(const int32_t *keys, const int32_t *payload, const void *vals, const P *rp, int32_t rp_rows,
-                        int64_t n, int32_t key_range, P *out_ptr, int32_t *out_payload, double *out_vals, hipStream_t s)
+                        int64_t n, int32_t key_range, int64_t payload_range, P *out_ptr, int32_t *out_payload,
+                        double *out_vals, hipStream_t s)
 {
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
     if (n == 0) {
@@ -381,7 +457,10 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
     const int64_t n_chunks = ceil_div(n, RX_CHUNK);
 
     DevBuf table, total, rlo, rhi, keyA, keyB, rowA, rowB, valA, valB, keyL;
-    CSRK_TRY(table.alloc((size_t)(256 * n_chunks + 1) * 8));
+    static const bool packed_ok = [] { const char *e = getenv("CSRK_TRANSPOSE_PACKED"); return !(e && e[0] == '0'); }();
+    const bool packed = passes == 2 && payload_range <= (1ll << 24) && packed_ok;
+    const int64_t n_chunks2 = packed ? n_chunks + 256 : n_chunks;      // aligned chunks: at most one partial chunk per run more
+    CSRK_TRY(table.alloc((size_t)(256 * n_chunks2 + 1) * 8));
     CSRK_TRY(total.alloc(256 * 8));
     if (FROM_CSR) {
         CSRK_TRY(rlo.alloc((size_t)n_chunks * 4));
@@ -389,6 +468,42 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         rx_rowbounds_kernel<P><<<(unsigned)ceil_div(n_chunks, 256), 256, 0, s>>>(rp, rp_rows, n, n_chunks, RX_CHUNK,
                                                                               rlo.as<int32_t>(), rhi.as<int32_t>());
         CSRK_LAUNCH_CHECK();
+    }
+    if (packed) {
+        // pass 1 (low digit): {high digit, payload} words + values; pass 2 (high digit) on chunks aligned to pass 1's runs
+        DevBuf cstart, ccnt, run0, total2;
+        CSRK_TRY(rowA.alloc((size_t)n * 4));
+        if (HAS_V) CSRK_TRY(valA.alloc((size_t)n * 8));
+        CSRK_TRY(cstart.alloc((size_t)n_chunks2 * 8));
+        CSRK_TRY(ccnt.alloc((size_t)n_chunks2 * 4));
+        CSRK_TRY(run0.alloc(257 * 8));
+        CSRK_TRY(total2.alloc(256 * 8));
+        double *v_mid = HAS_V ? valA.as<double>() : nullptr;
+        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(keys, n, 0, n_chunks, table.as<int64_t>(), nullptr, nullptr);
+        CSRK_LAUNCH_CHECK();
+        rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks, total.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        rx_scatter_kernel<P, VT, FROM_CSR ? 1 : 2, 1><<<(unsigned)(8 * ceil_div(n_chunks, 8)), RX_THREADS, 0, s>>>(
+            keys, payload, vals, rp, rp_rows, n, 0, n_chunks, table.as<int64_t>(), total.as<int64_t>(), rlo.as<int32_t>(),
+            rhi.as<int32_t>(), nullptr, rowA.as<int32_t>(), v_mid);
+        CSRK_LAUNCH_CHECK();
+        rx_align_kernel<<<1, 256, 0, s>>>(total.as<int64_t>(), n_chunks2, cstart.as<int64_t>(), ccnt.as<int32_t>(), run0.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        rx_hist_kernel<<<(unsigned)n_chunks2, RX_THREADS, 0, s>>>(rowA.as<int32_t>(), n, 24, n_chunks2, table.as<int64_t>(),
+                                                                 cstart.as<int64_t>(), ccnt.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks2, total2.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        constexpr int VMID2 = HAS_V ? CSRK_VAL_F64 : CSRK_VAL_NONE;
+        rx_scatter_kernel<P, VMID2, 0, 2><<<(unsigned)(8 * ceil_div(n_chunks2, 8)), RX_THREADS, 0, s>>>(
+            rowA.as<int32_t>(), nullptr, v_mid, rp, rp_rows, n, 24, n_chunks2, table.as<int64_t>(), total2.as<int64_t>(), nullptr,
+            nullptr, nullptr, out_payload, out_vals, cstart.as<int64_t>(), ccnt.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        rx_rowptr_from_table_kernel<P><<<(unsigned)ceil_div((int64_t)key_range + 1, 256), 256, 0, s>>>(
+            table.as<int64_t>(), total2.as<int64_t>(), run0.as<int64_t>(), n_chunks2, key_range, n, out_ptr);
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipStreamSynchronize(s));   // temporaries go back to the pool on return
+        return CSRK_OK;
     }
     CSRK_TRY(keyL.alloc((size_t)n * 4));          // sorted keys of the last pass -> run starts
     if (passes > 1) {
@@ -411,7 +526,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         int32_t *k_out = last ? keyL.as<int32_t>() : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
         int32_t *r_out = last ? out_payload : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
         double *v_out = !HAS_V ? nullptr : (last ? out_vals : ((p & 1) ? valB.as<double>() : valA.as<double>()));
-        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>());
+        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>(), nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
         rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks, total.as<int64_t>());
         CSRK_LAUNCH_CHECK();
@@ -440,7 +555,7 @@ template <class P, int VT>
 static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
 {
     return sort_records<P, VT, true>(a->d_colinds, nullptr, a->d_values, (const P *)a->d_rowptrs, a->nrows, a->nnz,
-                                     a->ncols, (P *)t->d_rowptrs, t->d_colinds, (double *)t->d_values, s);
+                                     a->ncols, a->nrows, (P *)t->d_rowptrs, t->d_colinds, (double *)t->d_values, s);
 }
 
 // Transpose `a` into a new matrix.  Exposed to the other translation units (spgemm_abt,
@@ -518,7 +633,7 @@ extern "C" int csrk_from_coo(int32_t nrows, int32_t ncols, int64_t nnz, const in
         }
 #define GO(P, VT)                                                                                                    \
     rc = sort_records<P, VT, false>(d_rows.as<int32_t>(), d_cols.as<int32_t>(), d_vals.p, (const P *)nullptr, 0, nnz,   \
-                                    nrows, (P *)m->d_rowptrs, m->d_colinds, v_out, nullptr)
+                                    nrows, ncols, (P *)m->d_rowptrs, m->d_colinds, v_out, nullptr)
         if (ptr64) {
             if (val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
             else if (val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
