@@ -86,30 +86,41 @@ __device__ __forceinline__ int64_t rx_chunk_of(int64_t b, int64_t n_chunks)
 // ---- radix pass: histogram ----------------------------------------------------------------
 // (cstart / ccnt: optional chunk descriptors -- first record and record count of every chunk -- for a pass whose chunks
 // are aligned to the previous pass's runs; without them chunk c is records [c * RX_CHUNK, (c + 1) * RX_CHUNK))
+// One workgroup counts RX_HC consecutive chunks: all their keys are requested before the first LDS atomic (a workgroup
+// per chunk was a load -> wait -> 4096 LDS atomics -> store chain per 16 KB of keys: 2.5 TB/s).
+constexpr int RX_HC = 4;
 __global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const int32_t *__restrict__ keys, int64_t n, int shift,
                                                             int64_t n_chunks, int64_t *__restrict__ table,
                                                             const int64_t *__restrict__ cstart, const int32_t *__restrict__ ccnt)
 {
-    __shared__ int32_t h[256];
-    if (threadIdx.x < 256) h[threadIdx.x] = 0;
-    const int64_t base = cstart ? cstart[blockIdx.x] : (int64_t)blockIdx.x * RX_CHUNK;
-    const int cnt = cstart ? ccnt[blockIdx.x] : (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK);
-    if (cnt <= 0) {                               // an unused chunk of an aligned pass: a column of zeros
-        if (threadIdx.x < 256) table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = 0;
-        return;
-    }
-    int32_t key[RX_ROUNDS];
+    __shared__ int32_t h[RX_HC][256];
+    for (int k = threadIdx.x; k < RX_HC * 256; k += RX_THREADS) (&h[0][0])[k] = 0;
+    int32_t key[RX_HC][RX_ROUNDS];
+    int cnt[RX_HC];
 #pragma unroll
-    for (int r = 0; r < RX_ROUNDS; r++) {        // unconditional (clamped) loads: all in flight together
-        const int k = r * RX_THREADS + threadIdx.x;
-        key[r] = keys[base + (k < cnt ? k : cnt - 1)];
+    for (int q = 0; q < RX_HC; q++) {
+        const int64_t chunk = (int64_t)blockIdx.x * RX_HC + q;
+        const bool in = chunk < n_chunks;
+        const int64_t base = !in ? 0 : (cstart ? cstart[chunk] : chunk * RX_CHUNK);
+        cnt[q] = !in ? 0 : (cstart ? ccnt[chunk] : (int)(n - base < RX_CHUNK ? n - base : RX_CHUNK));
+#pragma unroll
+        for (int r = 0; r < RX_ROUNDS; r++) {        // unconditional (clamped) loads: all in flight together
+            const int k = r * RX_THREADS + threadIdx.x;
+            key[q][r] = keys[base + (k < cnt[q] ? k : (cnt[q] > 0 ? cnt[q] - 1 : 0))];
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RX_ROUNDS; r++)
-        if (r * RX_THREADS + (int)threadIdx.x < cnt) atomicAdd(&h[(key[r] >> shift) & 255], 1);
+    for (int q = 0; q < RX_HC; q++)
+#pragma unroll
+        for (int r = 0; r < RX_ROUNDS; r++)
+            if (r * RX_THREADS + (int)threadIdx.x < cnt[q]) atomicAdd(&h[q][(key[q][r] >> shift) & 255], 1);
     __syncthreads();
-    if (threadIdx.x < 256) table[(int64_t)threadIdx.x * n_chunks + blockIdx.x] = h[threadIdx.x];
+    for (int k = threadIdx.x; k < RX_HC * 256; k += RX_THREADS) {
+        const int q = k >> 8, d = k & 255;
+        const int64_t chunk = (int64_t)blockIdx.x * RX_HC + q;
+        if (chunk < n_chunks) table[(int64_t)d * n_chunks + chunk] = h[q][d];      // (an unused chunk of an aligned pass: zeros)
+    }
 }
 
 // ---- radix pass: table scan ------------------------------------------------------------------
@@ -387,17 +398,23 @@ __global__ __launch_bounds__(256) void rx_align_kernel(const int64_t *__restrict
                                                       int64_t *__restrict__ cstart, int32_t *__restrict__ ccnt,
                                                       int64_t *__restrict__ run_chunk0)
 {
-    __shared__ int64_t s_start[257], s_c0[257];
-    const int d = threadIdx.x;
-    const int64_t len = total1[d];
-    s_start[d + 1] = len;
-    s_c0[d + 1] = (len + RX_CHUNK - 1) / RX_CHUNK;
-    if (d == 0) s_start[0] = 0, s_c0[0] = 0;
+    __shared__ int64_t s_ws[4], s_wc[4];
+    const int d = threadIdx.x, lane = d & (WAVE - 1), w = d / WAVE;
+    const int64_t len = total1[d], nch = (len + RX_CHUNK - 1) / RX_CHUNK;
+    int64_t is = len, ic = nch;                   // inclusive scans over the 256 digits: wavefront, then 4 wavefront totals
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int64_t a = __shfl_up(is, off, WAVE), b = __shfl_up(ic, off, WAVE);
+        if (lane >= off) is += a, ic += b;
+    }
+    if (lane == WAVE - 1) s_ws[w] = is, s_wc[w] = ic;
     __syncthreads();
-    if (d == 0)
-        for (int q = 1; q <= 256; q++) s_start[q] += s_start[q - 1], s_c0[q] += s_c0[q - 1];
-    __syncthreads();
-    const int64_t c0 = s_c0[d], c1 = s_c0[d + 1], st = s_start[d];
+    int64_t st = is - len, c0 = ic - nch, used = 0;
+    for (int k = 0; k < 4; k++) {
+        if (k < w) st += s_ws[k], c0 += s_wc[k];
+        used += s_wc[k];
+    }
+    const int64_t c1 = c0 + nch;
     run_chunk0[d] = c0;
     if (d == 255) run_chunk0[256] = c1;
     for (int64_t c = c0; c < c1; c++) {
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(256) void rx_align_kernel(const int64_t *__restrict
         const int64_t left = len - (c - c0) * RX_CHUNK;
         ccnt[c] = (int32_t)(left < RX_CHUNK ? left : RX_CHUNK);
     }
-    for (int64_t c = s_c0[256] + d; c < n_chunks_cap; c += 256) {      // the unused tail of the descriptor arrays
+    for (int64_t c = used + d; c < n_chunks_cap; c += 256) {      // the unused tail of the descriptor arrays
         cstart[c] = 0;
         ccnt[c] = 0;
     }
@@ -479,7 +496,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         CSRK_TRY(run0.alloc(257 * 8));
         CSRK_TRY(total2.alloc(256 * 8));
         double *v_mid = HAS_V ? valA.as<double>() : nullptr;
-        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(keys, n, 0, n_chunks, table.as<int64_t>(), nullptr, nullptr);
+        rx_hist_kernel<<<(unsigned)ceil_div(n_chunks, RX_HC), RX_THREADS, 0, s>>>(keys, n, 0, n_chunks, table.as<int64_t>(), nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
         rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks, total.as<int64_t>());
         CSRK_LAUNCH_CHECK();
@@ -489,7 +506,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         CSRK_LAUNCH_CHECK();
         rx_align_kernel<<<1, 256, 0, s>>>(total.as<int64_t>(), n_chunks2, cstart.as<int64_t>(), ccnt.as<int32_t>(), run0.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        rx_hist_kernel<<<(unsigned)n_chunks2, RX_THREADS, 0, s>>>(rowA.as<int32_t>(), n, 24, n_chunks2, table.as<int64_t>(),
+        rx_hist_kernel<<<(unsigned)ceil_div(n_chunks2, RX_HC), RX_THREADS, 0, s>>>(rowA.as<int32_t>(), n, 24, n_chunks2, table.as<int64_t>(),
                                                                  cstart.as<int64_t>(), ccnt.as<int32_t>());
         CSRK_LAUNCH_CHECK();
         rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks2, total2.as<int64_t>());
@@ -526,7 +543,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         int32_t *k_out = last ? keyL.as<int32_t>() : ((p & 1) ? keyB.as<int32_t>() : keyA.as<int32_t>());
         int32_t *r_out = last ? out_payload : ((p & 1) ? rowB.as<int32_t>() : rowA.as<int32_t>());
         double *v_out = !HAS_V ? nullptr : (last ? out_vals : ((p & 1) ? valB.as<double>() : valA.as<double>()));
-        rx_hist_kernel<<<(unsigned)n_chunks, RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>(), nullptr, nullptr);
+        rx_hist_kernel<<<(unsigned)ceil_div(n_chunks, RX_HC), RX_THREADS, 0, s>>>(k_in, n, shift, n_chunks, table.as<int64_t>(), nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
         rx_scan_kernel<<<256, RXS_THREADS, 0, s>>>(table.as<int64_t>(), n_chunks, total.as<int64_t>());
         CSRK_LAUNCH_CHECK();
