@@ -212,7 +212,21 @@ def main():
         torch.cuda.synchronize()
         once.append((time.perf_counter() - t_w) * 1e3)
     first_ms, plan_ms = once
-    del y_tmp
+    # Set-up check, untimed and before the warm-up: the planned product is bitwise reproducible (no float atomic
+    # decides an order anywhere in it) -- REPRO_CALLS products, every one compared bit for bit with the first.  It also
+    # means the card has been running the SpMV for a quarter of a second when the warm-up starts (the first ~50 steps
+    # of a cold card run ~2 % slower: clocks, caches), however few warm-up steps the caller asks for.
+    REPRO_CALLS = 300
+    y_ref = y_tmp[:n_loc].clone()
+    n_differ = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(REPRO_CALLS):
+        local(x, y_tmp[:n_loc])
+        n_differ += (y_tmp[:n_loc].view(torch.int64) != y_ref.view(torch.int64)).any().to(torch.int64)
+    torch.cuda.synchronize()
+    reproducible = int(n_differ.item()) == 0
+    if not reproducible:
+        sys.exit(f'[bench rank {rank}] the planned SpMV is not bitwise reproducible: {int(n_differ.item())} of {REPRO_CALLS} products differ')
+    del y_tmp, y_ref
 
     # N > 1: the ways of completing y on every rank (csr_amd/dist.py).  Chunked candidates hold one handle per chunk
     # (views of this rank's arrays, row pointers rebased).
@@ -386,8 +400,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 25)()
-    check(lib.csrk_spmv_plan_stats(hp, st, 25))
+    st = (C.c_int64 * 26)()
+    check(lib.csrk_spmv_plan_stats(hp, st, 26))
     if op_handles:
         # the roofline block describes the first chunk's handle (the kernels that were timed)
         i_r, i_c, i_n, i_p, i_v = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int(0), C.c_int(0)
@@ -494,6 +508,11 @@ def main():
         # (which builds the SpMV plan before launching)
         'first_call_ms': None if first_ms is None else round(first_ms, 2),
         'plan_build_call_ms': None if plan_ms is None else round(plan_ms, 2),
+        'setup_check': {'bitwise_reproducible_products': REPRO_CALLS, 'ok': reproducible},
+        # device memory: the CSR arrays this rank holds, and the SpMV plan built beside them (private streams of the
+        # three tiers, cold-staging lists, tables)
+        'matrix_bytes': nnz_loc * 12 + (n_loc + 1) * rp.element_size(), 'plan_bytes': int(st[25]),
+        'plan_over_matrix': round(int(st[25]) / max(1, nnz_loc * 12 + (n_loc + 1) * rp.element_size()), 3),
     }
     if compute_ms is not None:
         # per step: the slowest rank's local SpMV (device events) and what the exchange adds on top

@@ -35,6 +35,7 @@
 #include "wave.h"
 
 #include <algorithm>
+#include <ctime>
 #include <vector>
 
 namespace csrk {
@@ -2888,6 +2889,33 @@ static int build_tier1_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
+// CSRK_PLAN_TRACE=1: wall-clock time of the plan's build stages on stderr (each stage is synchronised first)
+struct PlanTrace {
+    bool on;
+    double t0;
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
+    {
+        if (on) {
+            (void)hipDeviceSynchronize();
+            t0 = now();
+        }
+    }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
+        t0 = t;
+    }
+};
+
 template <class P>
 static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
 {
@@ -2896,7 +2924,9 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
         p->tile_items = MERGE_ITEMS;
         p->nnz_light = m->nnz;
         p->split_considered = allow_split;
+        PlanTrace tr;
         if (allow_split) CSRK_TRY(build_heavy_split<P>(m, p, s));
+        tr.lap("heavy split + tiers");
         const P *rp_path = p->n_heavy ? p->rp_light.as<P>() : rp;
         int64_t total = (int64_t)m->nrows + p->nnz_light;
         p->n_tiles = ceil_div(total, MERGE_ITEMS);
@@ -2914,8 +2944,10 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
                 p->tile_cut.as<int32_t>());
             CSRK_LAUNCH_CHECK();
         }
+        tr.lap("merge-path tables");
         if (allow_split) {
             CSRK_TRY(build_hot_cache<P>(m, p, s));
+            tr.lap("hot-column census + pack");
             const char *ax = getenv("CSRK_SPMV_AUX");
             // (measured on the headline matrix: 0.753 ms with the auxiliary stream, 0.727 without -- the event
             // hand-overs cost more than the overlap of ~25 us of small kernels gains; off unless CSRK_SPMV_AUX=1)
@@ -2928,6 +2960,7 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
             else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
+            tr.lap("light stream + cold staging");
             if (p->n_hot && !p->ls.on) {        // the tile kernel stays in charge: it reads a renumbered colinds copy
                 CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
                 hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, p->hot_slot.as<int32_t>(),
@@ -3504,15 +3537,31 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
         a_nb = ap->nb;
     }
     const bool af = !p->acc.empty();
-    const int64_t v[25] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    // [25]: bytes of device memory the plan holds (private streams, tables, scratch)
+    int64_t plan_bytes = 0;
+    {
+        auto add = [&](const DevBuf &b) { plan_bytes += (int64_t)b.bytes; };
+        for (const DevBuf *b : {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut,
+                                &p->heavy_row, &p->ci_hot, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
+            add(*b);
+        for (const Panel &t : p->tier)
+            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y}) add(*b);
+        for (const AccPanel *ap : p->acc)
+            for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
+        for (const LightStream *l : {&p->ls, &p->t1s})
+            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
+                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold})
+                add(*b);
+    }
+    const int64_t v[26] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
                            af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
-                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold};
-    for (int i = 0; i < n && i < 25; i++) out[i] = v[i];
+                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes};
+    for (int i = 0; i < n && i < 26; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

@@ -136,7 +136,7 @@ CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *til
  * path's entries on packed columns (ppm), 18 tier-0 form (0 pairs, 1 accumulator), 19 pack slots,
  * 20 short rows on the light stream (1) or on the merge-path tile kernel (0), 21 light-stream tiles,
  * 22 non-empty rows of the light stream, 23 its workgroups, 24 light-stream entries whose x values are staged
- * per call (cold staging)}; n <= 25. */
+ * per call (cold staging), 25 bytes of device memory the plan holds}; n <= 26. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
