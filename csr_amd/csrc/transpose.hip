@@ -32,7 +32,10 @@
 
 namespace csrk {
 
-constexpr int RX_THREADS = 512;
+#ifndef CSRK_RX_THREADS
+#define CSRK_RX_THREADS 512
+#endif
+constexpr int RX_THREADS = CSRK_RX_THREADS;
 constexpr int RX_ROUNDS = 8;
 constexpr int RX_CHUNK = RX_THREADS * RX_ROUNDS;     // 4096 records per workgroup (8192: 0.67 vs 0.65 ms)
 constexpr int RX_WAVES = RX_THREADS / WAVE;
