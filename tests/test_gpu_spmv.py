@@ -476,3 +476,41 @@ def test_two_part_product_equals_the_whole(split_mode):
             check(lib.csrk_spmv_device_part(h.H, xd.data_ptr(), parts.data_ptr(), None, 0))
     finally:
         K.release_handle(h)
+
+
+def test_handle_cache_reaches_the_plan():
+    """
+    The reference's caller path (csr/csr.py:580-583: a handle per product) through csr_amd.CSR: the device copy made by
+    the first product is handed out again to the later ones (same csrk handle), so they run on the plan the second
+    product builds; results stay identical to the oracle's and to each other, a whole-array in-place edit of the host
+    values is picked up, a single poked element after `invalidate`.
+    """
+    from oracle import oracle as O
+    from csr_amd import CSR, synth
+    from csr_amd.kernels import hip as K
+    K.flush_handle_cache()
+    w = synth.powerlaw_csr(40000, 600000, 1500000, device='cpu')
+    A = CSR(40000, 600000, 1500000, w['rowptrs'].numpy(), w['colinds'].numpy(), w['values'].numpy().copy())
+    x = synth.dense_vector(600000).numpy()
+
+    def check(y):
+        ref = O.mult_vec(A.nrows, A.ncols, A.rowptrs, A.colinds, A.values, x)
+        bound = O.mult_vec(A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values), np.abs(x))
+        assert np.all(np.abs(y - ref) <= 1e-12 * bound + 1e-300)
+
+    h = K.to_handle(A)
+    H0 = h.H
+    K.release_handle(h)
+    ys = [A.mult_vec(x) for _ in range(4)]                  # product 1: plan-less kernel; 2: builds the plan; 3, 4: planned
+    h = K.to_handle(A)
+    assert h.H == H0                                        # still the same device copy
+    K.release_handle(h)
+    for y in ys:
+        check(y)
+    assert np.array_equal(ys[2], ys[3])
+    A.values *= 0.5                                         # whole-array edit in place: the fingerprint changes
+    check(A.mult_vec(x))
+    A.values[777] = 3.0                                     # one element: not sampled, the caller says so
+    K.invalidate(A)
+    check(A.mult_vec(x))
+    K.flush_handle_cache()
