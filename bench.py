@@ -353,7 +353,7 @@ def main():
         barrier()
         # kernel event pairs on every 10th step of a long run (recorded on every step they cost ~25 us per SpMV)
         if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-            every = 10 if args.steps >= 100 else (5 if args.steps >= 10 else 1)
+            every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)      # (event pairs cost ~3 us each on the stream)
             check(lib.csrk_spmv_profile_every(hp, every))
             check(lib.csrk_spmv_profile_begin(hp, args.steps // every + 2))
         op.timing = world > 1
