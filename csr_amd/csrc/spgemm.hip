@@ -24,8 +24,17 @@
 // Like the reference, entries that cancel to exactly 0.0 are KEPT (csr/csr.py:555 filters
 // them afterwards) and C's row pointers are int32 (multiply.py:28).
 // Column order inside a row is ascending here; the reference's order (reverse discovery) is
-// pinned by none of its tests (hard part 3).  Value sums use atomics, so
-// the last bits may vary run to run (tolerance: 1e-6 relative, north_star).
+// pinned by none of its tests (hard part 3).
+//
+// Determinism.  Every kernel walks an output row's products the way the reference does -- A's entries jj in storage
+// order, for each the whole row B_j -- with ALL lanes of the row's wavefront or workgroup on ONE jj at a time
+// (sg_walk_products): inside one B_j the columns are distinct, so no two lanes add to the same accumulator in a step,
+// and a barrier separates the steps, so every output entry receives its products in ascending jj: the reference's
+// own order (work[k] += a * b, multiply.py:117-121), products rounded before they are added.  The sums are therefore
+// bitwise reproducible run to run (test_spgemm_deterministic) and equal to the sequential loop's bit for bit
+// whenever B's rows hold no column twice (two copies of a column inside ONE B row are added by two lanes of the same
+// step: their relative order is the hardware's).  (Before, the wavefronts of a workgroup took different jj and raced on
+// the accumulators: last bits varied run to run, and a 10^4-entry B_j was one wavefront's 156 dependent round trips.)
 #include "common.h"
 
 namespace csrk {
@@ -53,6 +62,47 @@ __device__ __forceinline__ double val_at(const MatView &m, int64_t k)
 static MatView view_of(const Matrix *m)
 {
     return MatView{m->d_rowptrs, m->d_colinds, m->d_values, m->ptr64, m->val_type, m->nrows, m->ncols};
+}
+
+// Walk the products of one output row -- A entries [as, ae), for each the whole row B_j -- in the reference's order with
+// NT threads (a wavefront or a whole workgroup) in step: lane t takes B_j's entries t, t + NT, ...; `apply(k, a_ij, b_jk)`
+// is called once per product; `step_done()` after the last product of every jj (a barrier for NT > 64, nothing for a
+// single wavefront, whose LDS operations complete in order).  The (j, a_ij, row extent) of G consecutive jj and the first
+// NT entries of each B_j are requested before the first product is applied, so a group costs two memory round trips
+// instead of two per jj.  All trip counts are uniform over the NT threads.
+template <int NT, int G, class Apply, class StepDone>
+__device__ __forceinline__ void sg_walk_products(const MatView &a, const MatView &b, int64_t as, int64_t ae, int t,
+                                                 Apply &&apply, StepDone &&step_done)
+{
+    for (int64_t jj0 = as; jj0 < ae; jj0 += G) {
+        int64_t bs[G], be[G];
+        double av[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int64_t jj = jj0 + g < ae ? jj0 + g : ae - 1;          // clamped: the loads stay unconditional
+            const int32_t j = a.ci[jj];
+            av[g] = val_at(a, jj);
+            bs[g] = rp_at(b, j);
+            be[g] = jj0 + g < ae ? rp_at(b, j + 1) : bs[g];              // past the row's end: an empty extent
+        }
+        int32_t k0[G];
+        double v0[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int64_t kk = bs[g] + t;
+            const bool in = kk < be[g];
+            k0[g] = in ? b.ci[kk] : -1;
+            v0[g] = in ? val_at(b, kk) : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (jj0 + g < ae) {                                          // uniform
+                if (k0[g] >= 0) apply(k0[g], av[g], v0[g]);
+                for (int64_t kk = bs[g] + NT + t; kk < be[g]; kk += NT) apply(b.ci[kk], av[g], val_at(b, kk));
+                step_done();
+            }
+        }
+    }
 }
 
 constexpr int SG_THREADS = 256;
@@ -108,26 +158,25 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
 
     const int lane = tid & (WAVE - 1), w = tid / WAVE;
     const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-    for (int64_t jj = as + w; jj < ae; jj += SG_THREADS / WAVE) {
-        const int32_t j = a.ci[jj];
-        const double av = NUMERIC ? val_at(a, jj) : 0.0;
-        const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-        for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-            const int32_t k = b.ci[kk];
+    sg_walk_products<SG_THREADS, 4>(
+        a, b, as, ae, tid,
+        [&](int32_t k, double av, double bv) {
             uint32_t slot = sg_hash(k);
             for (;;) {
                 int32_t old = atomicCAS(&s_key[slot], -1, k);
                 if (old == -1 || old == k) {
                     if (NUMERIC)
-                        atomicAdd(&s_val[slot], av * val_at(b, kk));
+                        atomicAdd(&s_val[slot], __dmul_rn(av, bv));
                     else if (old == -1)
                         atomicAdd(&s_n, 1);
                     break;
                 }
                 slot = (slot + 1) & (SG_SLOTS - 1);
             }
-        }
-    }
+        },
+        [&]() {
+            if (NUMERIC) __syncthreads();      // (the distinct-column count of the symbolic pass does not depend on an order)
+        });
     __syncthreads();
     if (!NUMERIC) {
         if (tid == 0) cnt[i] = s_n;
@@ -216,24 +265,21 @@ __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, cons
     int found = 0;
     if (mine) {
         const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        for (int64_t jj = as; jj < ae; jj++) {
-            const int32_t j = a.ci[jj];
-            const double av = NUMERIC ? val_at(a, jj) : 0.0;
-            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-                const int32_t k = b.ci[kk];
+        sg_walk_products<WAVE, 4>(
+            a, b, as, ae, lane,
+            [&](int32_t k, double av, double bv) {
                 uint32_t slot = ((uint32_t)k * 2654435761u) & (SLOTS - 1);
                 for (;;) {
                     int32_t old = atomicCAS(&s_key[w][slot], -1, k);
                     if (old == -1 || old == k) {
-                        if (NUMERIC) atomicAdd(&s_val[w][slot], av * val_at(b, kk));
+                        if (NUMERIC) atomicAdd(&s_val[w][slot], __dmul_rn(av, bv));
                         else if (old == -1) found++;
                         break;
                     }
                     slot = (slot + 1) & (SLOTS - 1);
                 }
-            }
-        }
+            },
+            [&]() {});      // one wavefront: its LDS operations complete in order
     }
     __syncthreads();
     if (!NUMERIC) {
@@ -324,21 +370,22 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
         const bool sweep = NUMERIC && (int64_t)n_out * 8 >= nc;
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (int64_t jj = as + w; jj < ae; jj += SG_THREADS / WAVE) {
-            const int32_t j = a.ci[jj];
-            const double av = NUMERIC ? val_at(a, jj) : 0.0;
-            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-                const int32_t k = b.ci[kk];
-                if (NUMERIC) atomicAdd(&work[k], av * val_at(b, kk));
+        sg_walk_products<SG_THREADS, 4>(
+            a, b, as, ae, tid,
+            [&](int32_t k, double av, double bv) {
+                if (NUMERIC) atomicAdd(&work[k], __dmul_rn(av, bv));
                 if (NUMERIC && sweep) {
                     mark[k] = 1;                       // the sweep only needs the marker
                 } else if (atomicExch(&mark[k], 1) == 0) {
                     const int o = atomicAdd(&s_n, 1);
                     if (NUMERIC) lst[o] = k;
                 }
-            }
-        }
+            },
+            [&]() {
+                // the step's memory-side adds have been acknowledged (s_waitcnt vmcnt(0) in the barrier) before the
+                // next jj's are issued
+                if (NUMERIC) __syncthreads();
+            });
         __threadfence_block();
         __syncthreads();
         if (!NUMERIC) {
@@ -403,13 +450,13 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
 // product (plus one on the marker): ~16 ps per product.  When the output row is nearly full -- every A B^T
 // block of a MovieLens-shaped matrix -- it is cheaper to keep the accumulator ON CHIP:
 //   symbolic: one LDS bit per output column (up to 2^20 columns), set with ds_or, counted with popcount;
-//   numeric:  the output columns are taken in tiles of SGL_W = 16384 (128 KiB of float64 accumulators + a bit
+//   numeric:  the output columns are taken in tiles of SGL_W = 20096 (157 KiB of float64 accumulators + a bit
 //             per column); per tile the row's products are walked once (products outside the tile are
 //             skipped), accumulated with ds_add_f64, and the tile is compacted in ascending column order.
 // One persistent 1024-thread workgroup per CU.  Ascending columns, cancellation zeros kept, like the other
 // paths; sums by LDS atomics (last bits may vary run to run, as before).
 constexpr int SGL_THREADS = 1024;
-constexpr int SGL_W = 16384;
+constexpr int SGL_W = 20096;               // 157 KiB of accumulators + a bit per column: the LDS of a CU
 constexpr int SGL_MAXBITS = 1 << 20;       // symbolic: columns per LDS bitmask (128 KiB)
 constexpr int SGL_MAXTILES = 8;            // numeric: more column tiles than this -> the HBM path
 
@@ -432,14 +479,8 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a,
         if (tid == 0) s_tot = 0;
         __syncthreads();
         const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        for (int64_t jj = as + w; jj < ae; jj += SGL_THREADS / WAVE) {
-            const int32_t j = a.ci[jj];
-            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-                const int32_t k = b.ci[kk];
-                atomicOr(&sgl_bits[k >> 5], 1u << (k & 31));
-            }
-        }
+        sg_walk_products<SGL_THREADS, 8>(
+            a, b, as, ae, tid, [&](int32_t k, double, double) { atomicOr(&sgl_bits[k >> 5], 1u << (k & 31)); }, [&]() {});
         __syncthreads();
         int c = 0;
         for (int k = tid; k < nwords; k += SGL_THREADS) c += __popc(sgl_bits[k]);
@@ -476,18 +517,15 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, 
             for (int k = tid; k < SGL_W; k += SGL_THREADS) s_work[k] = 0.0;
             for (int k = tid; k < SGL_W / 32; k += SGL_THREADS) s_bits[k] = 0;
             __syncthreads();
-            for (int64_t jj = as + w; jj < ae; jj += SGL_THREADS / WAVE) {
-                const int32_t j = a.ci[jj];
-                const double av = val_at(a, jj);
-                const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-                for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-                    const int32_t k = b.ci[kk];
+            sg_walk_products<SGL_THREADS, 8>(
+                a, b, as, ae, tid,
+                [&](int32_t k, double av, double bv) {
                     if (k >= t0 && k < t1) {
-                        atomicAdd(&s_work[k - t0], av * val_at(b, kk));
+                        atomicAdd(&s_work[k - t0], __dmul_rn(av, bv));
                         atomicOr(&s_bits[(k - t0) >> 5], 1u << ((k - t0) & 31));
                     }
-                }
-            }
+                },
+                [&]() { __syncthreads(); });
             __syncthreads();
             // ascending compaction of the tile, 1024 columns at a time
             for (int32_t k0 = 0; k0 < t1 - t0; k0 += SGL_THREADS) {
@@ -546,23 +584,20 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
         }
         __syncthreads();
         const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        for (int64_t jj = as + w; jj < ae; jj += SGL_THREADS / WAVE) {
-            const int32_t j = a.ci[jj];
-            const double av = val_at(a, jj);
-            const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
-            for (int64_t kk = bs + lane; kk < be; kk += WAVE) {
-                const int32_t k = b.ci[kk];
+        sg_walk_products<SGL_THREADS, 8>(
+            a, b, as, ae, tid,
+            [&](int32_t k, double av, double bv) {
                 uint32_t slot = ((uint32_t)k * 2654435761u) >> 19;      // 13 bits
                 for (;;) {
                     const int32_t old = atomicCAS(&s_key[slot], -1, k);
                     if (old == -1 || old == k) {
-                        atomicAdd(&s_val[slot], av * val_at(b, kk));
+                        atomicAdd(&s_val[slot], __dmul_rn(av, bv));
                         break;
                     }
                     slot = (slot + 1) & (SGB_SLOTS - 1);
                 }
-            }
-        }
+            },
+            [&]() { __syncthreads(); });
         __syncthreads();
         // compact the occupied slots, then bitonic sort by column
         int base = 0;
@@ -670,7 +705,7 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         lds_symbolic = n_large > 0 && b->ncols <= SGL_MAXBITS;
         if (lds_symbolic) {
             CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_symbolic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_numeric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_numeric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             CSRK_HIP(hipFuncSetAttribute((const void *)sg_hash_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         }
         auto alloc_dense = [&]() -> int {       // HBM work / marker rows of the dense path, when some row needs it

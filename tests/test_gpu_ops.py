@@ -321,6 +321,61 @@ def test_mult_abt_movielens_shape_blocks():
         assert P.nnz == int(keep.sum()) and np.array_equal(P.colinds, rci[keep])
 
 
+def test_spgemm_deterministic():
+    """
+    Every SpGEMM kernel adds an output entry's products in ascending order of A's entries, the whole wavefront / workgroup
+    on one A entry at a time (csrc/spgemm.hip, sg_walk_products): the values are bitwise reproducible run to run, and --
+    B's rows holding no column twice -- bit-identical to the reference's sequential loop (multiply.py:117-121), which the
+    oracle restates.  Covers the wave-per-row, workgroup-hash, LDS-tile, big-hash and HBM-row paths.
+    """
+    from oracle import oracle as O
+    from csr_amd import CSR, synth
+    from csr_amd.kernels import hip as K
+
+    def uniq(rng, nrows, ncols, lens):
+        rp = np.zeros(nrows + 1, dtype=np.int32)
+        rp[1:] = np.cumsum(lens)
+        ci = np.concatenate([np.sort(rng.choice(ncols, size=int(n), replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        return CSR(nrows, ncols, int(rp[-1]), rp, ci, rng.uniform(-1, 1, size=int(rp[-1])), _cast=False)
+
+    rng = np.random.default_rng(99)
+    cases = []
+    # short rows (wave kernels), a few hundred products (workgroup hash), thousands of products onto few columns (big hash)
+    la = rng.integers(0, 10, 1200)
+    la[::40] = 300
+    lb = rng.integers(0, 12, 900)
+    lb[::30] = 200
+    cases.append((uniq(rng, 1200, 900, la), uniq(rng, 900, 6000, lb)))
+    # nearly full output rows (LDS tiles) and wide sparse ones (HBM work rows): 40000 output columns
+    la = rng.integers(0, 6, 300)
+    la[::10] = 700
+    lb = rng.integers(0, 40, 2500)
+    lb[::7] = 9000
+    cases.append((uniq(rng, 300, 2500, la), uniq(rng, 2500, 40000, lb)))
+    m = synth.movielens_like(device='cpu')
+    M = CSR(m['nrows'], m['ncols'], int(m['colinds'].numel()), m['rowptrs'].numpy(), m['colinds'].numpy(),
+            m['values'].numpy(), _cast=False)
+    for A, B, abt in [(a, b, False) for a, b in cases] + [(M.subset_rows(500, 700), M.subset_rows(30000, 33000), True)]:
+        outs = []
+        for _ in range(3):
+            ah, bh = K.to_handle(A), K.to_handle(B)
+            try:
+                ch = K.mult_abt(ah, bh) if abt else K.mult_ab(ah, bh)
+                outs.append(K.from_handle(ch))
+                K.release_handle(ch)
+            finally:
+                K.release_handle(ah)
+                K.release_handle(bh)
+        for c in outs[1:]:
+            assert np.array_equal(c.rowptrs, outs[0].rowptrs) and np.array_equal(c.colinds, outs[0].colinds)
+            assert np.array_equal(c.values.view(np.int64), outs[0].values.view(np.int64))      # bit for bit, run to run
+        bt = O.transpose(B.nrows, B.ncols, B.rowptrs, B.colinds, B.values) if abt else (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values)
+        nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
+        rci, rvs = sort_within_rows(crp, cci, cvs)
+        assert np.array_equal(outs[0].rowptrs, crp) and np.array_equal(outs[0].colinds, rci)
+        assert np.array_equal(outs[0].values.view(np.int64), rvs.view(np.int64))                  # = the sequential loop's bits
+
+
 def test_multiply_sharded(golden):
     "csr/csr.py:558-567: row sharding above max_nnz + _assemble_shards (tests/test_mkl.py:82-91)"
     from csr_amd.kernels import hip as K
