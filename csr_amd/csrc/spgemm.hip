@@ -48,20 +48,29 @@ struct MatView {
     int ptr64;
     int vt;
     int32_t nrows, ncols;
+    int64_t nnz;
 };
 
+// FAST: both operands have int32 row pointers and float64 values (every A B^T -- the transpose is float64 -- and the
+// usual A B): the accessors are plain typed loads.  With the run-time dtype tests of the general form every load sits
+// behind its own branch, the compiler cannot keep several in flight, and a row of B costs one memory round trip per
+// load (measured: the MovieLens-shaped A B^T block 8.7 ms in the general form).
+template <bool FAST>
 __device__ __forceinline__ int64_t rp_at(const MatView &m, int64_t i)
 {
+    if (FAST) return (int64_t)((const int32_t *)m.rp)[i];
     return m.ptr64 ? ((const int64_t *)m.rp)[i] : (int64_t)((const int32_t *)m.rp)[i];
 }
+template <bool FAST>
 __device__ __forceinline__ double val_at(const MatView &m, int64_t k)
 {
+    if (FAST) return ((const double *)m.vs)[k];
     return m.vt == CSRK_VAL_F64 ? ((const double *)m.vs)[k] : (double)((const float *)m.vs)[k];
 }
 
 static MatView view_of(const Matrix *m)
 {
-    return MatView{m->d_rowptrs, m->d_colinds, m->d_values, m->ptr64, m->val_type, m->nrows, m->ncols};
+    return MatView{m->d_rowptrs, m->d_colinds, m->d_values, m->ptr64, m->val_type, m->nrows, m->ncols, m->nnz};
 }
 
 // Walk the products of one output row -- A entries [as, ae), for each the whole row B_j -- in the reference's order with
@@ -70,7 +79,11 @@ static MatView view_of(const Matrix *m)
 // single wavefront, whose LDS operations complete in order).  The (j, a_ij, row extent) of G consecutive jj and the first
 // NT entries of each B_j are requested before the first product is applied, so a group costs two memory round trips
 // instead of two per jj.  All trip counts are uniform over the NT threads.
-template <int NT, int G, class Apply, class StepDone>
+#ifndef CSRK_SG_U
+#define CSRK_SG_U 8
+#endif
+constexpr int SG_U = CSRK_SG_U;
+template <bool FAST, int NT, int G, bool NEEDV, class Apply, class StepDone>
 __device__ __forceinline__ void sg_walk_products(const MatView &a, const MatView &b, int64_t as, int64_t ae, int t,
                                                  Apply &&apply, StepDone &&step_done)
 {
@@ -81,24 +94,47 @@ __device__ __forceinline__ void sg_walk_products(const MatView &a, const MatView
         for (int g = 0; g < G; g++) {
             const int64_t jj = jj0 + g < ae ? jj0 + g : ae - 1;          // clamped: the loads stay unconditional
             const int32_t j = a.ci[jj];
-            av[g] = val_at(a, jj);
-            bs[g] = rp_at(b, j);
-            be[g] = jj0 + g < ae ? rp_at(b, j + 1) : bs[g];              // past the row's end: an empty extent
+            av[g] = NEEDV ? val_at<FAST>(a, jj) : 0.0;
+            bs[g] = rp_at<FAST>(b, j);
+            be[g] = jj0 + g < ae ? rp_at<FAST>(b, j + 1) : bs[g];              // past the row's end: an empty extent
         }
+        // (loads past a row's end are clamped to B's last entry and selected away: a load behind a branch is waited for
+        // before the next one is issued)
+        const int64_t last = b.nnz - 1;
         int32_t k0[G];
         double v0[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int64_t kk = bs[g] + t;
             const bool in = kk < be[g];
-            k0[g] = in ? b.ci[kk] : -1;
-            v0[g] = in ? val_at(b, kk) : 0.0;
+            const int64_t kc = in ? kk : last;
+            const int32_t kl = b.ci[kc];
+            const double vl = NEEDV ? val_at<FAST>(b, kc) : 0.0;      // (the symbolic passes read the columns only)
+            k0[g] = in ? kl : -1;
+            v0[g] = vl;
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (jj0 + g < ae) {                                          // uniform
                 if (k0[g] >= 0) apply(k0[g], av[g], v0[g]);
-                for (int64_t kk = bs[g] + NT + t; kk < be[g]; kk += NT) apply(b.ci[kk], av[g], val_at(b, kk));
+                // a long B_j: SG_U passes of NT entries requested at a time (one pass per round trip made a
+                // 10^4-entry row of B a chain of ten memory latencies)
+                for (int64_t kb = bs[g] + NT; kb < be[g]; kb += SG_U * (int64_t)NT) {      // uniform
+                    int32_t kx[SG_U];
+                    double vx[SG_U];
+#pragma unroll
+                    for (int u = 0; u < SG_U; u++) {
+                        const int64_t kk = kb + (int64_t)u * NT + t;
+                        const bool in = kk < be[g];
+                        const int64_t kc = in ? kk : last;
+                        const int32_t kl = b.ci[kc];
+                        vx[u] = NEEDV ? val_at<FAST>(b, kc) : 0.0;
+                        kx[u] = in ? kl : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < SG_U; u++)
+                        if (kx[u] >= 0) apply(kx[u], av[g], vx[u]);
+                }
                 step_done();
             }
         }
@@ -112,16 +148,17 @@ constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take t
 
 // products per output row: ub[i] = sum_{j in A_i} |B_j| (one wavefront per row: a thread per row spent 1.9 ms
 // on 2000 rows of a MovieLens-shaped A, whose rows have up to 7000 entries)
+template <bool FAST>
 __global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     if (i >= a.nrows) return;
-    const int64_t s = rp_at(a, i), e = rp_at(a, i + 1);
+    const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
     int64_t tot = 0;
     for (int64_t jj = s + lane; jj < e; jj += WAVE) {
         const int32_t j = a.ci[jj];
-        tot += rp_at(b, j + 1) - rp_at(b, j);
+        tot += rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j);
     }
     for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
     if (lane == 0) ub[i] = tot;
@@ -138,7 +175,7 @@ __global__ void sg_list_large(const int64_t *__restrict__ ub, int32_t nrows, int
 __device__ __forceinline__ uint32_t sg_hash(int32_t k) { return ((uint32_t)k * 2654435761u) >> 21; }   // 11 bits
 
 // One workgroup per output row with 0 < ub <= SG_CAP.
-template <bool NUMERIC>
+template <bool NUMERIC, bool FAST>
 __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView b, const int64_t *__restrict__ ub,
                                                             int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
                                                             int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
@@ -157,8 +194,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
     __syncthreads();
 
     const int lane = tid & (WAVE - 1), w = tid / WAVE;
-    const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-    sg_walk_products<SG_THREADS, 4>(
+    const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
+    sg_walk_products<FAST, SG_THREADS, 4, NUMERIC>(
         a, b, as, ae, tid,
         [&](int32_t k, double av, double bv) {
             uint32_t slot = sg_hash(k);
@@ -243,7 +280,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
 // workgroup serves four rows, each with a private SLOTS-entry hash table in LDS.  A workgroup-per-row
 // launch with a 2048-slot table costs ~20 us of fixed work (clear, compact, sort) however few products
 // the row has; most rows of a sparse product have a handful.
-template <int SLOTS, bool NUMERIC>
+template <int SLOTS, bool NUMERIC, bool FAST>
 __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub, int lo, int hi,
                                                      int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
                                                      int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
@@ -264,8 +301,8 @@ __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, cons
     __syncthreads();
     int found = 0;
     if (mine) {
-        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        sg_walk_products<WAVE, 4>(
+        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
+        sg_walk_products<FAST, WAVE, 4, NUMERIC>(
             a, b, as, ae, lane,
             [&](int32_t k, double av, double bv) {
                 uint32_t slot = ((uint32_t)k * 2654435761u) & (SLOTS - 1);
@@ -342,7 +379,7 @@ __device__ inline void wg_bitonic(int32_t *p, int np2, int tid)
     }
 }
 
-template <bool NUMERIC>
+template <bool NUMERIC, bool FAST>
 __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                              int32_t n_large, double *__restrict__ work_all,
                                                              int32_t *__restrict__ mark_all, int32_t *__restrict__ scratch_all,
@@ -360,7 +397,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
     int32_t *scratch = NUMERIC ? scratch_all + (int64_t)blockIdx.x * scratch_len : nullptr;
     for (int q = blockIdx.x; q < n_large; q += gridDim.x) {
         const int i = list[q];
-        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
         const int32_t base = NUMERIC ? c_rp[i] : 0;
         const int32_t n_out = NUMERIC ? c_rp[i + 1] - base : 0;
         // where the touched-column list is collected and sorted
@@ -370,7 +407,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
         const bool sweep = NUMERIC && (int64_t)n_out * 8 >= nc;
         if (tid == 0) s_n = 0;
         __syncthreads();
-        sg_walk_products<SG_THREADS, 4>(
+        sg_walk_products<FAST, SG_THREADS, 4, NUMERIC>(
             a, b, as, ae, tid,
             [&](int32_t k, double av, double bv) {
                 if (NUMERIC) atomicAdd(&work[k], __dmul_rn(av, bv));
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
             // clear the markers by walking the products again
             for (int64_t jj = as + w; jj < ae; jj += SG_THREADS / WAVE) {
                 const int32_t j = a.ci[jj];
-                const int64_t bs = rp_at(b, j), be = rp_at(b, j + 1);
+                const int64_t bs = rp_at<FAST>(b, j), be = rp_at<FAST>(b, j + 1);
                 for (int64_t kk = bs + lane; kk < be; kk += WAVE) mark[b.ci[kk]] = 0;
             }
             __syncthreads();
@@ -460,13 +497,14 @@ constexpr int SGL_W = 20096;               // 157 KiB of accumulators + a bit pe
 constexpr int SGL_MAXBITS = 1 << 20;       // symbolic: columns per LDS bitmask (128 KiB)
 constexpr int SGL_MAXTILES = 8;            // numeric: more column tiles than this -> the HBM path
 
+template <bool FAST>
 __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                                      int32_t n_large, int32_t *__restrict__ cnt,
                                                                      int32_t *__restrict__ next)
 {
     extern __shared__ uint32_t sgl_bits[];
     __shared__ int32_t s_tot, s_q;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int nwords = (b.ncols + 31) / 32;
     for (;;) {
         // rows are claimed one at a time (product counts differ by orders of magnitude between rows)
@@ -478,8 +516,8 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a,
         for (int k = tid; k < nwords; k += SGL_THREADS) sgl_bits[k] = 0;
         if (tid == 0) s_tot = 0;
         __syncthreads();
-        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        sg_walk_products<SGL_THREADS, 8>(
+        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
+        sg_walk_products<FAST, SGL_THREADS, 8, false>(
             a, b, as, ae, tid, [&](int32_t k, double, double) { atomicOr(&sgl_bits[k >> 5], 1u << (k & 31)); }, [&]() {});
         __syncthreads();
         int c = 0;
@@ -492,6 +530,7 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a,
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                                     int32_t n_rows, const int32_t *__restrict__ c_rp,
                                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs,
@@ -510,22 +549,28 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, 
         const int q = s_q;
         if (q >= n_rows) break;
         const int i = list[q];
-        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
+        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
         int pos = c_rp[i];
         for (int32_t t0 = 0; t0 < nc; t0 += SGL_W) {
             const int32_t t1 = t0 + SGL_W < nc ? t0 + SGL_W : nc;
             for (int k = tid; k < SGL_W; k += SGL_THREADS) s_work[k] = 0.0;
             for (int k = tid; k < SGL_W / 32; k += SGL_THREADS) s_bits[k] = 0;
             __syncthreads();
-            sg_walk_products<SGL_THREADS, 8>(
+            sg_walk_products<FAST, SGL_THREADS, 8, true>(
                 a, b, as, ae, tid,
                 [&](int32_t k, double av, double bv) {
                     if (k >= t0 && k < t1) {
                         atomicAdd(&s_work[k - t0], __dmul_rn(av, bv));
+#ifndef CSRK_SG_NOBITS
                         atomicOr(&s_bits[(k - t0) >> 5], 1u << ((k - t0) & 31));
+#endif
                     }
                 },
-                [&]() { __syncthreads(); });
+                [&]() {
+#ifndef CSRK_SG_NOBAR
+                    __syncthreads();
+#endif
+                });
             __syncthreads();
             // ascending compaction of the tile, 1024 columns at a time
             for (int32_t k0 = 0; k0 < t1 - t0; k0 += SGL_THREADS) {
@@ -559,6 +604,7 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, 
 // through the HBM work rows: 9.8 of the 12 ms of a 200k x 200k power-law product.)
 constexpr int SGB_SLOTS = 8192;
 constexpr int SGB_CAP = 4096;
+template <bool FAST>
 __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, MatView b, const int32_t *__restrict__ list,
                                                                  int32_t n_rows, const int32_t *__restrict__ c_rp,
                                                                  int32_t *__restrict__ c_ci, double *__restrict__ c_vs,
@@ -583,8 +629,8 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
             s_val[sl] = 0.0;
         }
         __syncthreads();
-        const int64_t as = rp_at(a, i), ae = rp_at(a, i + 1);
-        sg_walk_products<SGL_THREADS, 8>(
+        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
+        sg_walk_products<FAST, SGL_THREADS, 8, true>(
             a, b, as, ae, tid,
             [&](int32_t k, double av, double bv) {
                 uint32_t slot = ((uint32_t)k * 2654435761u) >> 19;      // 13 bits
@@ -671,12 +717,24 @@ __global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large
         list_b[atomicAdd(&n_ahb[2], 1)] = i;
 }
 
-static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
+template <bool FAST>
+static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
 {
     CSRK_REQUIRE(a->ncols == b->nrows, "mult_ab: A is %d x %d but B is %d x %d", a->nrows, a->ncols, b->nrows, b->ncols);
     CSRK_REQUIRE(a->val_type != CSRK_VAL_NONE && b->val_type != CSRK_VAL_NONE,
                  "mult_ab needs values on both operands (csr/kernels/numba/multiply.py:115,120)");
     const int32_t nr = a->nrows;
+    if (a->nnz == 0 || b->nnz == 0) {         // no products at all (also: the walker's clamped loads need an entry of B)
+        Matrix *c = nullptr;
+        CSRK_TRY(new_matrix(nr, b->ncols, 0, 0, CSRK_VAL_F64, &c));
+        if (hipMemset(c->d_rowptrs, 0, (size_t)(nr + 1) * 4) != hipSuccess) {
+            set_error("hipMemset failed");
+            delete c;
+            return CSRK_ERR_HIP;
+        }
+        *out = c;
+        return CSRK_OK;
+    }
     MatView av = view_of(a), bv = view_of(b);
     DevBuf ub, cnt, list, nl, work, mark, scratch, list_a, list_h, list_b, n_ab, next;
     int grid_lds = 256;
@@ -694,7 +752,7 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
     int grid_dense = 0;
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
-        sg_count_products<<<(unsigned)ceil_div((int64_t)nr * WAVE, 256), 256>>>(av, bv, ub.as<int64_t>());
+        sg_count_products<FAST><<<(unsigned)ceil_div((int64_t)nr * WAVE, 256), 256>>>(av, bv, ub.as<int64_t>());
         CSRK_LAUNCH_CHECK();
         sg_list_large<<<g, 256>>>(ub.as<int64_t>(), nr, list.as<int32_t>(), nl.as<int32_t>());
         CSRK_LAUNCH_CHECK();
@@ -704,9 +762,10 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         grid_lds = cus > 0 ? cus : 256;
         lds_symbolic = n_large > 0 && b->ncols <= SGL_MAXBITS;
         if (lds_symbolic) {
-            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_symbolic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_numeric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            CSRK_HIP(hipFuncSetAttribute((const void *)sg_hash_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_symbolic_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_lds_numeric_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((size_t)SGL_W * 8 + SGL_W / 8)));
+            CSRK_HIP(hipFuncSetAttribute((const void *)sg_hash_big_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         }
         auto alloc_dense = [&]() -> int {       // HBM work / marker rows of the dense path, when some row needs it
             if (work.p) return CSRK_OK;
@@ -725,17 +784,17 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
         if (n_large > 0 && !lds_symbolic) CSRK_TRY(alloc_dense());
         // symbolic (rows with no products keep the zero count of the memset)
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, false><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
-        sg_wave_kernel<256, false><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
-        sg_hash_kernel<false><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        sg_hash_kernel<false, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
         if (n_large > 0 && lds_symbolic) {
             const size_t lds = (size_t)((b->ncols + 31) / 32) * 4;
             CSRK_TRY(next.alloc(12));
             CSRK_HIP(hipMemset(next.p, 0, 12));
-            sg_lds_symbolic_kernel<<<(unsigned)(n_large < grid_lds ? n_large : grid_lds), SGL_THREADS, lds>>>(
+            sg_lds_symbolic_kernel<FAST><<<(unsigned)(n_large < grid_lds ? n_large : grid_lds), SGL_THREADS, lds>>>(
                 av, bv, list.as<int32_t>(), n_large, cnt.as<int32_t>(), next.as<int32_t>());
             CSRK_LAUNCH_CHECK();
             // numeric: nearly full rows -> LDS tiles, the others -> HBM work rows
@@ -755,7 +814,7 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
             n_hbm = nab[2];
             if (n_hbm > 0) CSRK_TRY(alloc_dense());
         } else if (n_large > 0) {
-            sg_dense_kernel<false><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
+            sg_dense_kernel<false, FAST><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
                                                               mark.as<int32_t>(), nullptr, 0, cnt.as<int32_t>(), nullptr,
                                                               nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
@@ -778,24 +837,24 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
     int rc = exclusive_scan_i32(cnt.as<int32_t>(), (int32_t *)c->d_rowptrs, nr, nullptr);
     if (rc == CSRK_OK && nr > 0 && c_nnz > 0) {
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, true><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
+        sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
                                               c->d_colinds, (double *)c->d_values);
-        sg_wave_kernel<256, true><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, nullptr,
+        sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, nullptr,
                                                (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
-        sg_hash_kernel<true><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
+        sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
                                                          c->d_colinds, (double *)c->d_values);
         if (n_lds > 0)
-            sg_lds_numeric_kernel<<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,
+            sg_lds_numeric_kernel<FAST><<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,
                                     (size_t)SGL_W * 8 + SGL_W / 8>>>(av, bv, list_a.as<int32_t>(), n_lds,
                                                                      (const int32_t *)c->d_rowptrs, c->d_colinds,
                                                                      (double *)c->d_values, next.as<int32_t>() + 1);
         if (n_hash > 0)
-            sg_hash_big_kernel<<<(unsigned)(n_hash < grid_lds ? n_hash : grid_lds), SGL_THREADS,
+            sg_hash_big_kernel<FAST><<<(unsigned)(n_hash < grid_lds ? n_hash : grid_lds), SGL_THREADS,
                                  (size_t)SGB_SLOTS * 12 + (size_t)SGB_CAP * 12>>>(av, bv, list_h.as<int32_t>(), n_hash,
                                                                                   (const int32_t *)c->d_rowptrs, c->d_colinds,
                                                                                   (double *)c->d_values, next.as<int32_t>() + 2);
         if (n_hbm > 0)
-            sg_dense_kernel<true><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
+            sg_dense_kernel<true, FAST><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
                                                              n_hbm, work.as<double>(), mark.as<int32_t>(),
                                                              scratch.as<int32_t>(), scratch_len, nullptr,
                                                              (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
@@ -812,6 +871,12 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
     }
     *out = c;
     return CSRK_OK;
+}
+
+static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
+{
+    const bool fast = !a->ptr64 && !b->ptr64 && a->val_type == CSRK_VAL_F64 && b->val_type == CSRK_VAL_F64;
+    return fast ? spgemm_run<true>(a, b, out) : spgemm_run<false>(a, b, out);
 }
 
 }  // namespace csrk
