@@ -699,6 +699,227 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
     }
 }
 
+// ---- rows with many products per output column: column strips, one wavefront each ---------------------------------
+// The heavy rows of an A B^T block of a ratings matrix have 10^5..10^6 products over 10^4 columns, and up to 7000 entries
+// of A.  With a whole workgroup on one row, ordered accumulation is a chain of |A_i| steps with a barrier each, every step
+// waiting for its own memory round trips: the longest row alone took 5 ms of the 8 ms call.  Here the row's output columns
+// are cut into STRIPS of SGS_W columns and every (row, strip) is a unit of work for ONE wavefront, which keeps the
+// strip's float64 accumulators in 9.5 KiB of LDS: sixteen units per CU, no barriers (one wavefront's LDS operations
+// complete in program order, so each column receives its products in ascending jj -- the reference's order), and a heavy
+// row spreads over as many wavefronts as it has strips.  A unit must find, for every A entry (i, j), the entries of B_j
+// inside its strip: B's rows are strictly ascending (checked; A B^T's right operand comes out of the transpose that
+// way), so these are a sub-range of B_j, and the sub-range bounds of every (A entry, strip boundary) are found once by
+// binary search (sg_strip_table) -- the table is 4 (S+1) bytes per A entry, which is why only rows with at least
+// SGS_MIN_PER_CELL products per (A entry, strip) on average take this path.
+constexpr int SGS_W = 1216;                 // columns per strip (19 x 64)
+constexpr int SGS_CHUNKS = SGS_W / WAVE;
+constexpr int SGS_MAX_S = 256;              // strips per row (wider products fall back to the workgroup paths)
+constexpr int SGS_G = 4;                    // sub-ranges requested per round trip
+constexpr int SGS_U = 4;                    // passes of a long sub-range requested per round trip
+constexpr int SGS_MIN_PER_CELL = 4;
+constexpr int SGS_HEAVY_J = 1024;           // rows with this many A entries are scheduled first (longest chains)
+constexpr int64_t SGS_TABLE_BUDGET = 2ll << 30;
+
+// bad[0] = 1 unless every row of the matrix is strictly ascending in its columns
+__global__ void sg_sorted_check(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, int32_t nrows, int64_t nnz,
+                                int32_t *__restrict__ bad)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (k >= nnz) return;
+    if (ci[k] > ci[k - 1]) return;
+    // a descent is fine only across a row boundary: k must be the first entry of its row
+    int32_t lo = 0, hi = nrows;            // largest r with rp[r] <= k
+    while (hi - lo > 1) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if ((int64_t)rp[mid] <= k) lo = mid; else hi = mid;
+    }
+    if ((int64_t)rp[lo] != k) bad[0] = 1;
+}
+
+// Rows with more than SG_CAP products: strip rows (S > 0 and enough products per table cell; counters[1], their A
+// entries numbered from counters[2]) or the workgroup paths' list (counters[0]).  Two launches: rows with long A rows
+// first (pass 0), so the longest chains start first.
+__global__ void sg_list_rows(const int32_t *__restrict__ a_rp, const int64_t *__restrict__ ub, int32_t nrows, int32_t S, int pass,
+                             int32_t *__restrict__ list_large, int32_t *__restrict__ list_strip, int32_t *__restrict__ ebase,
+                             int32_t *__restrict__ counters)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows || ub[i] <= SG_CAP) return;
+    const int32_t J = a_rp[i + 1] - a_rp[i];
+    const bool strip = S > 0 && ub[i] >= (int64_t)SGS_MIN_PER_CELL * J * S;
+    if (strip) {
+        if ((J >= SGS_HEAVY_J) == (pass == 0)) {
+            const int32_t q = atomicAdd(&counters[1], 1);
+            list_strip[q] = (int32_t)i;
+            ebase[q] = atomicAdd(&counters[2], J);
+        }
+    } else if (pass == 0) {
+        list_large[atomicAdd(&counters[0], 1)] = (int32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_strip_expand(const int32_t *__restrict__ a_rp, const int32_t *__restrict__ list_strip,
+                                                       const int32_t *__restrict__ ebase, int32_t *__restrict__ emap)
+{
+    const int32_t i = list_strip[blockIdx.x], as = a_rp[i], J = a_rp[i + 1] - as, eb = ebase[blockIdx.x];
+    for (int32_t t = threadIdx.x; t < J; t += 256) emap[eb + t] = as + t;
+}
+
+// T[s * E + e] = first entry of B_j (j = the column of A entry emap[e]) whose column is >= s * SGS_W, s = 0..S
+__global__ __launch_bounds__(256) void sg_strip_table(const int32_t *__restrict__ a_ci, const int32_t *__restrict__ b_rp,
+                                                      const int32_t *__restrict__ b_ci, const int32_t *__restrict__ emap,
+                                                      int32_t E, int32_t S, int32_t *__restrict__ T)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)E * (S + 1)) return;
+    const int32_t s = (int32_t)(idx / E), e = (int32_t)(idx - (int64_t)s * E);
+    const int32_t j = a_ci[emap[e]];
+    int32_t lo = b_rp[j], hi = b_rp[j + 1];
+    if (s == S) lo = hi;
+    else if (s > 0) {
+        const int32_t target = s * SGS_W;
+        while (lo < hi) {
+            const int32_t mid = lo + (hi - lo) / 2;
+            if (b_ci[mid] < target) lo = mid + 1; else hi = mid;
+        }
+    }
+    T[idx] = lo;
+}
+
+__device__ __forceinline__ double sg_readlane_f64(double x, int r)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), r), __builtin_amdgcn_readlane(__double2loint(x), r));
+}
+
+// One wavefront per (strip row, strip).  Symbolic: a flag byte per column -> the strip's occupancy words (occ, 64 columns
+// each) and count; numeric: float64 accumulators, compacted through the symbolic pass's occupancy words (entries that
+// cancel to 0.0 stay, like the reference's).
+template <bool NUMERIC>
+__global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restrict__ a_rp, const double *__restrict__ a_vs,
+                                                       const int32_t *__restrict__ b_ci, const double *__restrict__ b_vs,
+                                                       int64_t b_last, const int32_t *__restrict__ list_strip,
+                                                       const int32_t *__restrict__ ebase, int32_t n_strip, int32_t S, int32_t E,
+                                                       const int32_t *__restrict__ T, int32_t *__restrict__ cnt_s,
+                                                       unsigned long long *__restrict__ occ, int32_t *__restrict__ cnt,
+                                                       const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
+                                                       double *__restrict__ c_vs, int32_t *__restrict__ next)
+{
+    __shared__ double s_work[NUMERIC ? SGS_W : 1];
+    __shared__ unsigned char s_flag[NUMERIC ? 4 : SGS_W];
+    const int lane = threadIdx.x;
+    for (int c = 0; c < SGS_CHUNKS; c++) {
+        if (NUMERIC) s_work[c * WAVE + lane] = 0.0;
+        else s_flag[c * WAVE + lane] = 0;
+    }
+    __syncthreads();
+    const int64_t n_units = (int64_t)n_strip * S;
+    int32_t u = 0;
+    if (lane == 0) u = atomicAdd(next, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    while (u < n_units) {
+        int32_t u_next = 0;
+        if (lane == 0) u_next = atomicAdd(next, 1);          // (needed only after this unit)
+        const int32_t q = u / S, s = u - q * S;
+        const int32_t i = list_strip[q], as = a_rp[i], J = a_rp[i + 1] - as;
+        const int32_t *__restrict__ t_lo = T + (int64_t)s * E + ebase[q];
+        const int32_t *__restrict__ t_hi = t_lo + E;
+        const int32_t c0 = s * SGS_W;
+        auto apply = [&](int32_t k, double av, double bv) {
+            if (NUMERIC) atomicAdd(&s_work[k - c0], __dmul_rn(av, bv));
+            else s_flag[k - c0] = 1;
+        };
+        // the (sub-range, a_ij) of 64 A entries at a time, one per lane, the next 64 requested before these are used
+        int32_t lo_n, hi_n;
+        double av_n;
+        auto fetch = [&](int32_t e0) {
+            const int32_t e = e0 + lane;
+            const bool in = e < J;
+            const int32_t ec = in ? e : J - 1;
+            const int32_t l = t_lo[ec], h = t_hi[ec];
+            lo_n = l;
+            hi_n = in ? h : l;
+            av_n = NUMERIC ? a_vs[as + ec] : 0.0;
+        };
+        fetch(0);
+        for (int32_t e0 = 0; e0 < J; e0 += WAVE) {
+            const int32_t lo = lo_n, len = hi_n - lo_n;
+            const double av = av_n;
+            fetch(e0 + WAVE < J ? e0 + WAVE : e0);
+            unsigned long long mask = __ballot(len > 0);
+            while (mask) {                                    // uniform
+                int32_t lo_g[SGS_G], len_g[SGS_G], k_g[SGS_G];
+                double av_g[SGS_G], v_g[SGS_G];
+#pragma unroll
+                for (int g = 0; g < SGS_G; g++) {
+                    const bool have = mask != 0;
+                    const int r = have ? __builtin_ctzll(mask) : 0;
+                    mask &= mask - 1;                         // (0 stays 0)
+                    lo_g[g] = __builtin_amdgcn_readlane(lo, r);
+                    len_g[g] = have ? __builtin_amdgcn_readlane(len, r) : 0;
+                    av_g[g] = NUMERIC ? sg_readlane_f64(av, r) : 0.0;
+                    const bool in = lane < len_g[g];
+                    const int64_t kc = in ? (int64_t)lo_g[g] + lane : b_last;      // clamped: the loads stay unconditional
+                    const int32_t kl = b_ci[kc];
+                    v_g[g] = NUMERIC ? b_vs[kc] : 0.0;
+                    k_g[g] = in ? kl : -1;
+                }
+#pragma unroll
+                for (int g = 0; g < SGS_G; g++) {
+                    if (k_g[g] >= 0) apply(k_g[g], av_g[g], v_g[g]);
+                    for (int32_t off = WAVE; off < len_g[g]; off += SGS_U * WAVE) {      // uniform; a long sub-range
+                        int32_t kx[SGS_U];
+                        double vx[SGS_U];
+#pragma unroll
+                        for (int x = 0; x < SGS_U; x++) {
+                            const int32_t o = off + x * WAVE + lane;
+                            const bool in = o < len_g[g];
+                            const int64_t kc = in ? (int64_t)lo_g[g] + o : b_last;
+                            const int32_t kl = b_ci[kc];
+                            vx[x] = NUMERIC ? b_vs[kc] : 0.0;
+                            kx[x] = in ? kl : -1;
+                        }
+#pragma unroll
+                        for (int x = 0; x < SGS_U; x++)
+                            if (kx[x] >= 0) apply(kx[x], av_g[g], vx[x]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                       // (one wavefront: no s_barrier, the LDS queue drains)
+        if (NUMERIC) {
+            int32_t pre = 0;
+            for (int32_t s0 = 0; s0 < s; s0 += WAVE) pre += s0 + lane < s ? cnt_s[(int64_t)q * S + s0 + lane] : 0;
+            for (int off = WAVE / 2; off; off >>= 1) pre += __shfl_xor(pre, off, WAVE);
+            int32_t pos = c_rp[i] + pre;
+            for (int c = 0; c < SGS_CHUNKS; c++) {
+                const unsigned long long word = occ[(int64_t)u * SGS_CHUNKS + c];
+                const double x = s_work[c * WAVE + lane];
+                s_work[c * WAVE + lane] = 0.0;
+                if ((word >> lane) & 1ull) {
+                    const int32_t o = pos + __popcll(word & ((1ull << lane) - 1ull));
+                    c_ci[o] = c0 + c * WAVE + lane;
+                    c_vs[o] = x;
+                }
+                pos += __popcll(word);
+            }
+        } else {
+            int32_t tot = 0;
+            for (int c = 0; c < SGS_CHUNKS; c++) {
+                const unsigned long long word = __ballot(s_flag[c * WAVE + lane] != 0);
+                s_flag[c * WAVE + lane] = 0;
+                if (lane == 0) occ[(int64_t)u * SGS_CHUNKS + c] = word;
+                tot += __popcll(word);
+            }
+            if (lane == 0) {
+                cnt_s[u] = tot;
+                if (tot) atomicAdd(&cnt[i], tot);
+            }
+        }
+        __syncthreads();
+        u = __builtin_amdgcn_readfirstlane(u_next);
+    }
+}
+
 // large rows (list[0..n_large)) -> (a) output nearly full and narrow enough for the LDS tiles, (h) few enough
 // distinct output columns for the big LDS hash table, (b) the others (HBM work rows)
 __global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large, const int32_t *__restrict__ cnt, int32_t nc,
@@ -736,8 +957,9 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
         return CSRK_OK;
     }
     MatView av = view_of(a), bv = view_of(b);
-    DevBuf ub, cnt, list, nl, work, mark, scratch, list_a, list_h, list_b, n_ab, next;
+    DevBuf ub, cnt, list, work, mark, scratch, list_a, list_h, list_b, n_ab, next;
     int grid_lds = 256;
+    unsigned grid_strip = 0;
     int32_t n_lds = 0, n_hash = 0, n_hbm = 0;
     bool lds_symbolic = false;
     int64_t scratch_len = 1;
@@ -745,18 +967,57 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
     CSRK_TRY(ub.alloc((size_t)(nr + 1) * 8));
     CSRK_TRY(cnt.alloc((size_t)(nr + 1) * 4));
     CSRK_TRY(list.alloc((size_t)(nr + 1) * 4));
-    CSRK_TRY(nl.alloc(4));
-    CSRK_HIP(hipMemset(nl.p, 0, 4));
     CSRK_HIP(hipMemset(cnt.p, 0, (size_t)(nr + 1) * 4));
     int32_t n_large = 0;
     int grid_dense = 0;
+    // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
+    DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad;
+    int32_t n_strip = 0, n_strip_e = 0, strips = 0;
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
         sg_count_products<FAST><<<(unsigned)ceil_div((int64_t)nr * WAVE, 256), 256>>>(av, bv, ub.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        sg_list_large<<<g, 256>>>(ub.as<int64_t>(), nr, list.as<int32_t>(), nl.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpy(&n_large, nl.p, 4, hipMemcpyDeviceToHost));
+        CSRK_TRY(counters.alloc(16));
+        CSRK_TRY(list_s.alloc((size_t)(nr + 1) * 4));
+        CSRK_TRY(ebase.alloc((size_t)(nr + 1) * 4));
+        const char *strips_env = getenv("CSRK_SPGEMM_STRIPS");      // 0: workgroup paths only (A/B measurements)
+        if (FAST && !(strips_env && atoi(strips_env) == 0)) {
+            strips = (int32_t)ceil_div(b->ncols, SGS_W);
+            if (strips > SGS_MAX_S || (int64_t)nr * strips > (1ll << 30)) strips = 0;
+        }
+        if (strips > 0 && b->nnz > 1) {          // the strips need B's rows strictly ascending
+            CSRK_TRY(sorted_bad.alloc(4));
+            CSRK_HIP(hipMemset(sorted_bad.p, 0, 4));
+            sg_sorted_check<<<(unsigned)ceil_div(b->nnz - 1, 256), 256>>>((const int32_t *)b->d_rowptrs, b->d_colinds, b->nrows,
+                                                                         b->nnz, sorted_bad.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            int32_t bad = 0;
+            CSRK_HIP(hipMemcpy(&bad, sorted_bad.p, 4, hipMemcpyDeviceToHost));
+            if (bad) strips = 0;
+        }
+        int32_t cnts[4] = {0, 0, 0, 0};
+        for (;;) {
+            CSRK_HIP(hipMemset(counters.p, 0, 16));
+            if (strips > 0) {
+                for (int pass = 0; pass < 2; pass++) {
+                    sg_list_rows<<<g, 256>>>((const int32_t *)a->d_rowptrs, ub.as<int64_t>(), nr, strips, pass, list.as<int32_t>(),
+                                             list_s.as<int32_t>(), ebase.as<int32_t>(), counters.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                }
+            } else {
+                sg_list_large<<<g, 256>>>(ub.as<int64_t>(), nr, list.as<int32_t>(), counters.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+            }
+            CSRK_HIP(hipMemcpy(cnts, counters.p, 16, hipMemcpyDeviceToHost));
+            if (strips > 0 && (int64_t)cnts[2] * (strips + 1) * 4 > SGS_TABLE_BUDGET) {
+                strips = 0;                      // the sub-range table would not pay for itself: workgroup paths
+                continue;
+            }
+            break;
+        }
+        n_large = cnts[0];
+        n_strip = cnts[1];
+        n_strip_e = cnts[2];
         int cus = 0;
         CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
         grid_lds = cus > 0 ? cus : 256;
@@ -790,10 +1051,33 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
         CSRK_LAUNCH_CHECK();
         sg_hash_kernel<false, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
+        CSRK_TRY(next.alloc(20));
+        CSRK_HIP(hipMemset(next.p, 0, 20));
+        if constexpr (FAST) {
+            if (n_strip > 0) {
+                const int64_t n_units = (int64_t)n_strip * strips;
+                CSRK_TRY(emap.alloc((size_t)n_strip_e * 4));
+                CSRK_TRY(table.alloc((size_t)n_strip_e * (strips + 1) * 4));
+                CSRK_TRY(cnt_s.alloc((size_t)n_units * 4));
+                CSRK_TRY(occ_s.alloc((size_t)n_units * SGS_CHUNKS * 8));
+                sg_strip_expand<<<(unsigned)n_strip, 256>>>((const int32_t *)a->d_rowptrs, list_s.as<int32_t>(), ebase.as<int32_t>(),
+                                                            emap.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+                sg_strip_table<<<(unsigned)ceil_div((int64_t)n_strip_e * (strips + 1), 256), 256>>>(
+                    a->d_colinds, (const int32_t *)b->d_rowptrs, b->d_colinds, emap.as<int32_t>(), n_strip_e, strips,
+                    table.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+                grid_strip = (unsigned)(n_units < (int64_t)grid_lds * 16 ? n_units : (int64_t)grid_lds * 16);
+                const unsigned grid_sym = (unsigned)(n_units < (int64_t)grid_lds * 32 ? n_units : (int64_t)grid_lds * 32);
+                sg_strip_kernel<false><<<grid_sym, WAVE>>>(
+                    (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
+                    list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
+                    occ_s.as<unsigned long long>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr, next.as<int32_t>() + 3);
+                CSRK_LAUNCH_CHECK();
+            }
+        }
         if (n_large > 0 && lds_symbolic) {
             const size_t lds = (size_t)((b->ncols + 31) / 32) * 4;
-            CSRK_TRY(next.alloc(12));
-            CSRK_HIP(hipMemset(next.p, 0, 12));
             sg_lds_symbolic_kernel<FAST><<<(unsigned)(n_large < grid_lds ? n_large : grid_lds), SGL_THREADS, lds>>>(
                 av, bv, list.as<int32_t>(), n_large, cnt.as<int32_t>(), next.as<int32_t>());
             CSRK_LAUNCH_CHECK();
@@ -843,6 +1127,14 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                                                (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
         sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
                                                          c->d_colinds, (double *)c->d_values);
+        if constexpr (FAST) {
+            if (n_strip > 0)
+                sg_strip_kernel<true><<<grid_strip, WAVE>>>(
+                    (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
+                    list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
+                    occ_s.as<unsigned long long>(), nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values,
+                    next.as<int32_t>() + 4);
+        }
         if (n_lds > 0)
             sg_lds_numeric_kernel<FAST><<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,
                                     (size_t)SGL_W * 8 + SGL_W / 8>>>(av, bv, list_a.as<int32_t>(), n_lds,
