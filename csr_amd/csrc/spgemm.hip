@@ -36,6 +36,7 @@
 // step: their relative order is the hardware's).  (Before, the wavefronts of a workgroup took different jj and raced on
 // the accumulators: last bits varied run to run, and a 10^4-entry B_j was one wavefront's 156 dependent round trips.)
 #include "common.h"
+#include "wave.h"
 
 namespace csrk {
 
@@ -517,8 +518,12 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_symbolic_kernel(MatView a,
         if (tid == 0) s_tot = 0;
         __syncthreads();
         const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
-        sg_walk_products<FAST, SGL_THREADS, 8, false>(
-            a, b, as, ae, tid, [&](int32_t k, double, double) { atomicOr(&sgl_bits[k >> 5], 1u << (k & 31)); }, [&]() {});
+        // (the set of columns does not depend on the order: every wavefront walks its own slice of A_i)
+        const int64_t per = (ae - as + SGL_THREADS / WAVE - 1) / (SGL_THREADS / WAVE);
+        const int64_t ws = as + (tid / WAVE) * per < ae ? as + (tid / WAVE) * per : ae;
+        const int64_t we = ws + per < ae ? ws + per : ae;
+        sg_walk_products<FAST, WAVE, 8, false>(
+            a, b, ws, we, lane, [&](int32_t k, double, double) { atomicOr(&sgl_bits[k >> 5], 1u << (k & 31)); }, [&]() {});
         __syncthreads();
         int c = 0;
         for (int k = tid; k < nwords; k += SGL_THREADS) c += __popc(sgl_bits[k]);
@@ -711,11 +716,17 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
 // way), so these are a sub-range of B_j, and the sub-range bounds of every (A entry, strip boundary) are found once by
 // binary search (sg_strip_table) -- the table is 4 (S+1) bytes per A entry, which is why only rows with at least
 // SGS_MIN_PER_CELL products per (A entry, strip) on average take this path.
-constexpr int SGS_W = 1216;                 // columns per strip (19 x 64)
+#ifndef CSRK_SGS_W
+#define CSRK_SGS_W 1088
+#endif
+constexpr int SGS_W = CSRK_SGS_W;           // columns per strip (17 x 64): 8.5 KiB of sums + a tag byte per column
+constexpr int SGS_WAVES_PER_CU = 16 * 1088 / SGS_W;
 constexpr int SGS_CHUNKS = SGS_W / WAVE;
 constexpr int SGS_MAX_S = 256;              // strips per row (wider products fall back to the workgroup paths)
-constexpr int SGS_G = 4;                    // sub-ranges requested per round trip
-constexpr int SGS_U = 4;                    // passes of a long sub-range requested per round trip
+#ifndef CSRK_SGS_G
+#define CSRK_SGS_G 8
+#endif
+constexpr int SGS_G = CSRK_SGS_G;         // sub-ranges requested per round trip
 constexpr int SGS_MIN_PER_CELL = 4;
 constexpr int SGS_HEAVY_J = 1024;           // rows with this many A entries are scheduled first (longest chains)
 constexpr int64_t SGS_TABLE_BUDGET = 2ll << 30;
@@ -786,10 +797,26 @@ __global__ __launch_bounds__(256) void sg_strip_table(const int32_t *__restrict_
     T[idx] = lo;
 }
 
+// Diagnostic build only (-DCSRK_SG_STAMPS): per-unit (cycles, |A_i|, positions, chunks, start time) of the numeric strip kernel
+#ifdef CSRK_SG_STAMPS
+__device__ unsigned long long g_sg_stamps[65536 * 8];
+#define SG_STAMP(I) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[I] += now_ - st_last; st_last = now_; }
+#else
+#define SG_STAMP(I)
+#endif
+
 __device__ __forceinline__ double sg_readlane_f64(double x, int r)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), r), __builtin_amdgcn_readlane(__double2loint(x), r));
 }
+
+// SGS_G chunks (64 positions each) of a unit's products, requested from memory and not yet applied
+template <bool NUMERIC>
+struct SgsGroup {
+    int32_t r[SGS_G], k[SGS_G];                    // per lane: A entry (of the 64 in the batch), column (-1: no product)
+    double av[NUMERIC ? SGS_G : 1], v[NUMERIC ? SGS_G : 1];
+    bool one[SGS_G];                               // uniform: the chunk lies inside ONE sub-range
+};
 
 // One wavefront per (strip row, strip).  Symbolic: a flag byte per column -> the strip's occupancy words (occ, 64 columns
 // each) and count; numeric: float64 accumulators, compacted through the symbolic pass's occupancy words (entries that
@@ -806,6 +833,8 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
 {
     __shared__ double s_work[NUMERIC ? SGS_W : 1];
     __shared__ unsigned char s_flag[NUMERIC ? 4 : SGS_W];
+    // the chunk search's markers (64 words) and, in the numeric pass, the column tags (SGS_W bytes): never live together
+    __shared__ int32_t s_mark[NUMERIC ? SGS_W / 4 : WAVE];
     const int lane = threadIdx.x;
     for (int c = 0; c < SGS_CHUNKS; c++) {
         if (NUMERIC) s_work[c * WAVE + lane] = 0.0;
@@ -824,10 +853,10 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
         const int32_t *__restrict__ t_lo = T + (int64_t)s * E + ebase[q];
         const int32_t *__restrict__ t_hi = t_lo + E;
         const int32_t c0 = s * SGS_W;
-        auto apply = [&](int32_t k, double av, double bv) {
-            if (NUMERIC) atomicAdd(&s_work[k - c0], __dmul_rn(av, bv));
-            else s_flag[k - c0] = 1;
-        };
+#ifdef CSRK_SG_STAMPS
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+        unsigned long long st_pos = 0, st_chunks = 0, st_last = st0, st_acc[3] = {0, 0, 0};
+#endif
         // the (sub-range, a_ij) of 64 A entries at a time, one per lane, the next 64 requested before these are used
         int32_t lo_n, hi_n;
         double av_n;
@@ -840,52 +869,134 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
             hi_n = in ? h : l;
             av_n = NUMERIC ? a_vs[as + ec] : 0.0;
         };
+        auto apply_group = [&](const SgsGroup<NUMERIC> &gr) {
+#pragma unroll
+            for (int g = 0; g < SGS_G; g++) {
+                const bool in = gr.k[g] >= 0;
+                if constexpr (!NUMERIC) {
+                    if (in) s_flag[gr.k[g] - c0] = 1;
+                    continue;
+                }
+                const double prod = __dmul_rn(gr.av[NUMERIC ? g : 0], gr.v[NUMERIC ? g : 0]);
+                if (gr.one[g]) {
+                    if (in) atomicAdd(&s_work[gr.k[g] - c0], prod);
+                    continue;
+                }
+                // Lanes of one A entry hold distinct columns; two entries of the chunk may hold the same column, and the
+                // order of same-address lanes inside one LDS instruction is the hardware's.  Only those lanes need an
+                // order: every lane tags its column with its lane number and reads the tag back -- a lane that finds
+                // another's number shares its column, and overwrites the tag with 0xff so that the lane that won
+                // learns it too.  Columns seen once take ONE LDS add together; the others go entry by entry, ascending.
+                // (One add per entry for all lanes cost the heaviest unit of a ratings block -- 7000 short sub-ranges,
+                // ~30 entries per chunk, of which ~4 lanes clash -- 1.4 of its 2.5 M clocks.)
+                unsigned char *tag = (unsigned char *)s_mark;
+                const int32_t col = in ? gr.k[g] - c0 : 0;
+                if (in) tag[col] = (unsigned char)lane;
+                asm volatile("" ::: "memory");
+                const bool lost = in && tag[col] != (unsigned char)lane;
+                asm volatile("" ::: "memory");
+                if (lost) tag[col] = 0xff;
+                asm volatile("" ::: "memory");
+                const bool dup = in && (lost || tag[col] == 0xff);
+                asm volatile("" ::: "memory");
+                if (in && !dup) atomicAdd(&s_work[col], prod);
+                // (scalar unit only: an entry's lanes are a run of the chunk, `starts` marks where the runs begin)
+                const unsigned long long starts = __builtin_amdgcn_ballot_w64(gr.r[g] != wave_up1_i32(gr.r[g], -1));
+                unsigned long long rem = __builtin_amdgcn_ballot_w64(dup);
+                while (rem) {                                           // uniform: the entries that hold clashing lanes, ascending
+                    const int l = __builtin_ctzll(rem);
+                    const unsigned long long above = starts & ~((2ull << l) - 1ull);      // run starts after lane l
+                    const unsigned long long upto = above ? (1ull << __builtin_ctzll(above)) - 1ull : ~0ull;
+                    if (__builtin_amdgcn_inverse_ballot_w64(rem & upto)) atomicAdd(&s_work[col], prod);
+                    rem &= ~upto;
+                }
+            }
+        };
+        SgsGroup<NUMERIC> pend;
+        bool have_pend = false;
         fetch(0);
         for (int32_t e0 = 0; e0 < J; e0 += WAVE) {
             const int32_t lo = lo_n, len = hi_n - lo_n;
             const double av = av_n;
             fetch(e0 + WAVE < J ? e0 + WAVE : e0);
-            unsigned long long mask = __ballot(len > 0);
-            while (mask) {                                    // uniform
-                int32_t lo_g[SGS_G], len_g[SGS_G], k_g[SGS_G];
-                double av_g[SGS_G], v_g[SGS_G];
+            // The sub-ranges of these 64 A entries laid end to end: position p belongs to the last entry r whose start
+            // is <= p and is B entry base_r + p.  64 positions (a chunk) are requested per load, SGS_G chunks per round
+            // trip, whatever the sub-ranges' lengths (requesting sub-range by sub-range, the heaviest row's 7000 short
+            // sub-ranges and its long ones' passes were 1100 dependent round trips: 1.5 ms for one unit).
+            const int32_t start = wave_exscan_i32(len, lane);
+            const int32_t total = __builtin_amdgcn_readlane(start + len, WAVE - 1);
+            const int32_t base = lo - start;
+            const int32_t n_chunks = (total + WAVE - 1) / WAVE;
+#ifdef CSRK_SG_STAMPS
+            st_pos += total;
+            st_chunks += n_chunks;
+#endif
+            const int32_t end = start + len;
+            SG_STAMP(0)
+            for (int32_t cb = 0; cb < n_chunks; cb += SGS_G) {      // uniform
+                // request this group's entries, THEN apply the group requested one step earlier: two groups are in
+                // flight, across the 64-entry batches too (a group per round trip left the heaviest unit of a ratings
+                // block -- 7000 A entries, 1400 chunks -- waiting 2 us per group: 1.1 ms for one wavefront)
+                SgsGroup<NUMERIC> cur;
 #pragma unroll
                 for (int g = 0; g < SGS_G; g++) {
-                    const bool have = mask != 0;
-                    const int r = have ? __builtin_ctzll(mask) : 0;
-                    mask &= mask - 1;                         // (0 stays 0)
-                    lo_g[g] = __builtin_amdgcn_readlane(lo, r);
-                    len_g[g] = have ? __builtin_amdgcn_readlane(len, r) : 0;
-                    av_g[g] = NUMERIC ? sg_readlane_f64(av, r) : 0.0;
-                    const bool in = lane < len_g[g];
-                    const int64_t kc = in ? (int64_t)lo_g[g] + lane : b_last;      // clamped: the loads stay unconditional
-                    const int32_t kl = b_ci[kc];
-                    v_g[g] = NUMERIC ? b_vs[kc] : 0.0;
-                    k_g[g] = in ? kl : -1;
-                }
-#pragma unroll
-                for (int g = 0; g < SGS_G; g++) {
-                    if (k_g[g] >= 0) apply(k_g[g], av_g[g], v_g[g]);
-                    for (int32_t off = WAVE; off < len_g[g]; off += SGS_U * WAVE) {      // uniform; a long sub-range
-                        int32_t kx[SGS_U];
-                        double vx[SGS_U];
-#pragma unroll
-                        for (int x = 0; x < SGS_U; x++) {
-                            const int32_t o = off + x * WAVE + lane;
-                            const bool in = o < len_g[g];
-                            const int64_t kc = in ? (int64_t)lo_g[g] + o : b_last;
-                            const int32_t kl = b_ci[kc];
-                            vx[x] = NUMERIC ? b_vs[kc] : 0.0;
-                            kx[x] = in ? kl : -1;
-                        }
-#pragma unroll
-                        for (int x = 0; x < SGS_U; x++)
-                            if (kx[x] >= 0) apply(kx[x], av_g[g], vx[x]);
+                    const int32_t p0 = (cb + g) * WAVE;        // (chunks past the end: no position is valid)
+                    const bool in = p0 + lane < total;
+                    // the entry that holds position p0: the last non-empty one that starts at or before it
+                    const unsigned long long before = __ballot(len > 0 && start <= p0);
+                    const int cur_e = before ? 63 - __builtin_clzll(before) : 0;
+                    const int32_t cur_end = __builtin_amdgcn_readlane(end, cur_e);
+                    const int32_t p1 = p0 + WAVE < total ? p0 + WAVE : total;
+                    cur.one[g] = p1 <= cur_end;
+                    int32_t bs;
+                    if (cur.one[g]) {
+                        // 92 % of a ratings block's products: scalars, no search
+                        bs = __builtin_amdgcn_readlane(base, cur_e);
+                        if constexpr (NUMERIC) cur.av[g] = sg_readlane_f64(av, cur_e);
+                        cur.r[g] = cur_e;
+                    } else {
+                        // (the lanes talk through s_mark: without the compiler fence a lane's own stores are forwarded
+                        // to its load; a volatile access would do, but costs an s_waitcnt vmcnt(0) -- every chunk a
+                        // memory round trip of its own)
+                        s_mark[lane] = 0;
+                        const int32_t rel = start - p0;
+                        if (len > 0 && rel >= 0 && rel < WAVE) s_mark[rel] = lane + 1;
+                        asm volatile("" ::: "memory");
+                        const int32_t mk = s_mark[lane];
+                        asm volatile("" ::: "memory");
+                        const int32_t m = max(wave_incl_max_i32(mk), cur_e + 1);
+                        const int32_t r = in ? m - 1 : 0;
+                        cur.r[g] = r;
+                        bs = __shfl(base, r, WAVE);
+                        if constexpr (NUMERIC) cur.av[g] = __shfl(av, r, WAVE);
                     }
+                    const int64_t kc = in ? (int64_t)bs + p0 + lane : b_last;      // clamped: the loads stay unconditional
+                    const int32_t kl = b_ci[kc];
+                    if constexpr (NUMERIC) cur.v[g] = b_vs[kc];
+                    cur.k[g] = in ? kl : -1;
                 }
+                SG_STAMP(1)
+                if (have_pend) apply_group(pend);
+                pend = cur;
+                have_pend = true;
+                SG_STAMP(2)
             }
         }
+        if (have_pend) apply_group(pend);
         __syncthreads();                                       // (one wavefront: no s_barrier, the LDS queue drains)
+#ifdef CSRK_SG_STAMPS
+        if (NUMERIC && lane == 0 && u < 65536) {
+            const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+            g_sg_stamps[u * 8 + 0] = st1 - st0;
+            g_sg_stamps[u * 8 + 1] = J;
+            g_sg_stamps[u * 8 + 2] = st_pos;
+            g_sg_stamps[u * 8 + 3] = st_chunks;
+            g_sg_stamps[u * 8 + 4] = st0;
+            g_sg_stamps[u * 8 + 5] = st_acc[0];
+            g_sg_stamps[u * 8 + 6] = st_acc[1];
+            g_sg_stamps[u * 8 + 7] = st_acc[2];
+        }
+#endif
         if (NUMERIC) {
             int32_t pre = 0;
             for (int32_t s0 = 0; s0 < s; s0 += WAVE) pre += s0 + lane < s ? cnt_s[(int64_t)q * S + s0 + lane] : 0;
@@ -1067,7 +1178,7 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                     a->d_colinds, (const int32_t *)b->d_rowptrs, b->d_colinds, emap.as<int32_t>(), n_strip_e, strips,
                     table.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
-                grid_strip = (unsigned)(n_units < (int64_t)grid_lds * 16 ? n_units : (int64_t)grid_lds * 16);
+                grid_strip = (unsigned)(n_units < (int64_t)grid_lds * SGS_WAVES_PER_CU ? n_units : (int64_t)grid_lds * SGS_WAVES_PER_CU);
                 const unsigned grid_sym = (unsigned)(n_units < (int64_t)grid_lds * 32 ? n_units : (int64_t)grid_lds * 32);
                 sg_strip_kernel<false><<<grid_sym, WAVE>>>(
                     (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
@@ -1176,6 +1287,15 @@ static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
 using namespace csrk;
 
 extern "C" {
+
+#ifdef CSRK_SG_STAMPS
+CSRK_API int csrk_debug_sg_stamps(unsigned long long *out, int n)
+{
+    CSRK_HIP(hipDeviceSynchronize());
+    CSRK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sg_stamps), (size_t)n * 8));
+    return CSRK_OK;
+}
+#endif
 
 int csrk_spgemm_ab(csrk_handle_t ah, csrk_handle_t bh, csrk_handle_t *out)
 {

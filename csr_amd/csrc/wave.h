@@ -50,6 +50,19 @@ __device__ __forceinline__ int wave_exscan_i32(int v, int /*lane*/)
     return s - v;
 }
 
+// inclusive prefix maximum over the 64 lanes (values >= 0)
+__device__ __forceinline__ int wave_incl_max_i32(int v)
+{
+    int s = v;
+    s = max(s, dpp_i32<DPP_ROW_SHR1>(0, s));
+    s = max(s, dpp_i32<DPP_ROW_SHR2>(0, s));
+    s = max(s, dpp_i32<DPP_ROW_SHR4>(0, s));
+    s = max(s, dpp_i32<DPP_ROW_SHR8>(0, s));
+    s = max(s, dpp_i32<DPP_ROW_BCAST15, 0xa>(0, s));
+    s = max(s, dpp_i32<DPP_ROW_BCAST31, 0xc>(0, s));
+    return s;
+}
+
 // Inclusive segmented sum over the lanes: a lane with `reset` set does not take the running sum of the lanes below it.
 // Fixed combination tree (inside rows of 16 by distances 1, 2, 4, 8, then whole rows): bitwise reproducible.
 __device__ __forceinline__ double wave_segscan(double v, bool reset, int /*lane*/)

@@ -15,7 +15,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob('$OUT/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'csrk::sg_lds' not in n: continue
+        if 'csrk::sg_strip' not in n and 'csrk::sg_lds' not in n: continue
         k = n.split('csrk::')[1].split('(')[0][:40]
         agg[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
 for (k, c), v in sorted(agg.items()): print(f'{k:42s} {c:26s} {sum(v)/len(v):.4g}')

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_sg
 rm -rf $OUT; mkdir -p $OUT
 for v in default "$@"; do
   if [ $v = default ]; then unset CSRK_LIBRARY; else export CSRK_LIBRARY=$GRAFT_REPO_ROOT/csr_amd/libcsrk_$v.so; fi
-  for w in probe_spgemm_noorc probe_abt2; do
+  for w in ${SG_WORKLOADS:-probe_spgemm_noorc probe_abt2}; do
     PYTHONPATH=$GRAFT_REPO_ROOT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$v-$w -- python $GRAFT_REPO_ROOT/tools/$w.py > $OUT/$v-$w.log 2>&1 || tail -3 $OUT/$v-$w.log
     echo "== $v $w"; grep " ms" $OUT/$v-$w.log
     python - <<PY
