@@ -1031,9 +1031,167 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
     }
 }
 
+// ---- heavy rows with a wide, sparse output: expand, sort, compress ---------------------------------------------------
+// Rows with more than SGB_CAP distinct output columns that are not nearly full (power-law A times power-law B) have too
+// many outputs for an LDS table and too few products per column for the strips.  Their products are written out in the
+// reference's order (A entries ascending, each with its row of B), as the rows of a CSR matrix P with repeated columns;
+// two stable transposes (transpose.hip: an LSD radix sort that keeps the input order inside a key) bring every row of P
+// into ascending column order with the products of one column still in their original order, and one thread per run of
+// equal columns adds the run front to back: the reference's sums, bit for bit, without atomics.  (Before: a dense float64
+// work row in HBM per workgroup, a barrier per A entry: 7.5 ms of a 200k x 200k product's 13.8.)
+constexpr int64_t SGE_BUDGET_PRODUCTS = 200ll << 20;     // above this the HBM work rows are used instead
+
+__global__ void sg_esc_gather(const int32_t *__restrict__ list, int32_t n, const int64_t *__restrict__ ub, int64_t *__restrict__ pu)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) pu[q] = ub[list[q]];
+}
+
+__global__ void sg_esc_rowptr(const int64_t *__restrict__ poff, int32_t n, int32_t *__restrict__ rp)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q <= n) rp[q] = (int32_t)poff[q];
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup; *total = the sum.  s_w: 4 words of LDS.
+__device__ __forceinline__ int64_t sg_block_exscan(int64_t v, int tid, int64_t *s_w, int64_t *total)
+{
+    const int lane = tid & (WAVE - 1), w = tid / WAVE;
+    int64_t inc = v;
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int64_t o = __shfl_up(inc, off, WAVE);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    int64_t before = 0, tot = 0;
+#pragma unroll
+    for (int u = 0; u < 256 / WAVE; u++) {
+        if (u < w) before += s_w[u];
+        tot += s_w[u];
+    }
+    *total = tot;
+    return before + inc - v;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void sg_esc_expand(MatView a, MatView b, const int32_t *__restrict__ list,
+                                                     const int64_t *__restrict__ poff, int32_t *__restrict__ p_ci,
+                                                     double *__restrict__ p_vs)
+{
+    __shared__ int64_t s_off[256], s_bs[256], s_w[256 / WAVE];
+    __shared__ double s_av[256];
+    const int tid = threadIdx.x;
+    const int32_t i = list[blockIdx.x];
+    const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
+    int64_t out = poff[blockIdx.x];
+    for (int64_t base = as; base < ae; base += 256) {
+        const int64_t jj = base + tid;
+        int64_t len = 0, bs = 0;
+        double av = 0.0;
+        if (jj < ae) {
+            const int32_t j = a.ci[jj];
+            bs = rp_at<FAST>(b, j);
+            len = rp_at<FAST>(b, j + 1) - bs;
+            av = val_at<FAST>(a, jj);
+        }
+        int64_t total;
+        const int64_t off = sg_block_exscan(len, tid, s_w, &total);
+        s_off[tid] = off;
+        s_bs[tid] = bs;
+        s_av[tid] = av;
+        __syncthreads();
+        for (int64_t p = tid; p < total; p += 256) {
+            int lo = 0, hi = 256;                      // the last A entry of the batch whose products start at or before p
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) / 2;
+                if (s_off[mid] <= p) lo = mid; else hi = mid;
+            }
+            const int64_t kk = s_bs[lo] + (p - s_off[lo]);
+            p_ci[out + p] = b.ci[kk];
+            p_vs[out + p] = __dmul_rn(s_av[lo], val_at<FAST>(b, kk));
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
+// Sorted product matrix -> rows of C: one output entry per run of equal columns inside a row, the run added front to back.
+// Position-parallel (a workgroup per row left the longest row's 10^5 products to 256 threads: 1 ms): tiles of 1024
+// positions count their run starts (WRITE = false), the counts are scanned, and the second launch numbers the runs --
+// run g of the product matrix is entry g - first_run[q] of row q's output (first_run = scan of the symbolic counts).
+constexpr int SGE_TILE = 1024;
+template <bool WRITE>
+__global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ list, int32_t n_q, const int32_t *__restrict__ p_rp,
+                                                   const int32_t *__restrict__ p_ci, const double *__restrict__ p_vs,
+                                                   int32_t n_pos, int32_t *__restrict__ tile_cnt,
+                                                   const int32_t *__restrict__ tile_off, const int32_t *__restrict__ first_run,
+                                                   const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
+                                                   double *__restrict__ c_vs)
+{
+    __shared__ int64_t s_w[256 / WAVE];
+    const int tid = threadIdx.x;
+    const int32_t t0 = blockIdx.x * SGE_TILE + tid * 4;
+    // the row of position t0: the last q with p_rp[q] <= t0
+    int32_t lo = 0, hi = n_q;
+    while (hi - lo > 1) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if (p_rp[mid] <= t0) lo = mid; else hi = mid;
+    }
+    int32_t q = lo, q_end = t0 < n_pos ? p_rp[q + 1] : 0;
+    int32_t prev = t0 > 0 && t0 <= n_pos ? p_ci[t0 - 1] : -1;
+    bool start[4];
+    int32_t qx[4], kx[4];
+    int n = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int32_t t = t0 + x;
+        start[x] = false;
+        qx[x] = q;
+        kx[x] = -1;
+        if (t < n_pos) {
+            while (t >= q_end) {                       // (rows without products are skipped)
+                q++;
+                q_end = p_rp[q + 1];
+            }
+            const int32_t k = p_ci[t];
+            start[x] = t == p_rp[q] || k != prev;
+            qx[x] = q;
+            kx[x] = k;
+            prev = k;
+            n += start[x] ? 1 : 0;
+        }
+    }
+    int64_t total;
+    const int64_t before = sg_block_exscan(n, tid, s_w, &total);
+    if (!WRITE) {
+        if (tid == 0) tile_cnt[blockIdx.x] = (int32_t)total;
+        return;
+    }
+    int32_t g = tile_off[blockIdx.x] + (int32_t)before;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (!start[x]) continue;
+        const int32_t t = t0 + x, e = p_rp[qx[x] + 1];
+        double sum = 0.0 + p_vs[t];                   // (the reference's work[k] starts from +0.0: -0.0 products)
+        for (int32_t u = t + 1; u < e && p_ci[u] == kx[x]; u++) sum += p_vs[u];
+        const int64_t o = (int64_t)c_rp[list[qx[x]]] + (g - first_run[qx[x]]);
+        c_ci[o] = kx[x];
+        c_vs[o] = sum;
+        g++;
+    }
+}
+
+__global__ void sg_esc_gather_cnt(const int32_t *__restrict__ list, int32_t n, const int32_t *__restrict__ cnt, int32_t *__restrict__ out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = cnt[list[q]];
+}
+
 // large rows (list[0..n_large)) -> (a) output nearly full and narrow enough for the LDS tiles, (h) few enough
 // distinct output columns for the big LDS hash table, (b) the others (HBM work rows)
-__global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large, const int32_t *__restrict__ cnt, int32_t nc,
+__global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large, const int32_t *__restrict__ cnt, int32_t nc, int32_t hash_cap,
                                int32_t *__restrict__ list_a, int32_t *__restrict__ list_h, int32_t *__restrict__ list_b,
                                int32_t *__restrict__ n_ahb)
 {
@@ -1043,7 +1201,7 @@ __global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large
     const bool lds = (int64_t)cnt[i] * 8 >= nc && (int64_t)nc <= (int64_t)SGL_W * SGL_MAXTILES;
     if (lds)
         list_a[atomicAdd(&n_ahb[0], 1)] = i;
-    else if (cnt[i] <= SGB_CAP)
+    else if (cnt[i] <= hash_cap)
         list_h[atomicAdd(&n_ahb[1], 1)] = i;
     else
         list_b[atomicAdd(&n_ahb[2], 1)] = i;
@@ -1082,7 +1240,9 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
     int32_t n_large = 0;
     int grid_dense = 0;
     // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
-    DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad;
+    DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, esc_pu, esc_off;
+    bool use_esc = false;
+    int64_t esc_products = 0;
     int32_t n_strip = 0, n_strip_e = 0, strips = 0;
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
@@ -1196,18 +1356,43 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
             CSRK_TRY(list_a.alloc((size_t)n_large * 4));
             CSRK_TRY(list_h.alloc((size_t)n_large * 4));
             CSRK_TRY(list_b.alloc((size_t)n_large * 4));
+            // Rows that are not nearly full go through expand-sort-compress (the rows the big LDS hash table could hold
+            // too: 2.8 -> 0.3 ms on the power-law products) while their products fit the budget; beyond it the table
+            // takes the rows it can hold and the HBM work rows the others.  CSRK_SPGEMM_ESC=0 / CSRK_SPGEMM_HASHCAP=n:
+            // measurements.
+            const char *hc_env = getenv("CSRK_SPGEMM_HASHCAP"), *esc_env = getenv("CSRK_SPGEMM_ESC");
+            const bool esc_on = !(esc_env && atoi(esc_env) == 0);
+            int32_t hash_cap = hc_env ? (atoi(hc_env) < SGB_CAP ? atoi(hc_env) : SGB_CAP) : (esc_on ? 0 : SGB_CAP);
             CSRK_TRY(n_ab.alloc(12));
-            CSRK_HIP(hipMemset(n_ab.p, 0, 12));
-            sg_split_large<<<(unsigned)ceil_div(n_large, 256), 256>>>(list.as<int32_t>(), n_large, cnt.as<int32_t>(), b->ncols,
-                                                                     list_a.as<int32_t>(), list_h.as<int32_t>(),
-                                                                     list_b.as<int32_t>(), n_ab.as<int32_t>());
-            CSRK_LAUNCH_CHECK();
-            int32_t nab[3] = {0, 0, 0};
-            CSRK_HIP(hipMemcpy(nab, n_ab.p, 12, hipMemcpyDeviceToHost));
-            n_lds = nab[0];
-            n_hash = nab[1];
-            n_hbm = nab[2];
-            if (n_hbm > 0) CSRK_TRY(alloc_dense());
+            for (;;) {
+                CSRK_HIP(hipMemset(n_ab.p, 0, 12));
+                sg_split_large<<<(unsigned)ceil_div(n_large, 256), 256>>>(list.as<int32_t>(), n_large, cnt.as<int32_t>(), b->ncols,
+                                                                         hash_cap, list_a.as<int32_t>(), list_h.as<int32_t>(),
+                                                                         list_b.as<int32_t>(), n_ab.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+                int32_t nab[3] = {0, 0, 0};
+                CSRK_HIP(hipMemcpy(nab, n_ab.p, 12, hipMemcpyDeviceToHost));
+                n_lds = nab[0];
+                n_hash = nab[1];
+                n_hbm = nab[2];
+                use_esc = false;
+                if (n_hbm > 0 && esc_on) {
+                    CSRK_TRY(esc_pu.alloc((size_t)(n_hbm + 1) * 8));
+                    CSRK_TRY(esc_off.alloc((size_t)(n_hbm + 1) * 8));
+                    sg_esc_gather<<<(unsigned)ceil_div(n_hbm, 256), 256>>>(list_b.as<int32_t>(), n_hbm, ub.as<int64_t>(),
+                                                                           esc_pu.as<int64_t>());
+                    CSRK_LAUNCH_CHECK();
+                    CSRK_TRY(exclusive_scan_i64(esc_pu.as<int64_t>(), esc_off.as<int64_t>(), n_hbm, nullptr));
+                    CSRK_HIP(hipMemcpy(&esc_products, esc_off.as<int64_t>() + n_hbm, 8, hipMemcpyDeviceToHost));
+                    use_esc = esc_products > 0 && esc_products <= SGE_BUDGET_PRODUCTS;
+                }
+                if (n_hbm > 0 && !use_esc && hash_cap < SGB_CAP && !hc_env) {
+                    hash_cap = SGB_CAP;          // over the budget: give the LDS table its rows back and look again
+                    continue;
+                }
+                break;
+            }
+            if (n_hbm > 0 && !use_esc) CSRK_TRY(alloc_dense());
         } else if (n_large > 0) {
             sg_dense_kernel<false, FAST><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
                                                               mark.as<int32_t>(), nullptr, 0, cnt.as<int32_t>(), nullptr,
@@ -1256,7 +1441,46 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                                  (size_t)SGB_SLOTS * 12 + (size_t)SGB_CAP * 12>>>(av, bv, list_h.as<int32_t>(), n_hash,
                                                                                   (const int32_t *)c->d_rowptrs, c->d_colinds,
                                                                                   (double *)c->d_values, next.as<int32_t>() + 2);
-        if (n_hbm > 0)
+        if (n_hbm > 0 && use_esc) {
+            Matrix *pm = nullptr, *pt = nullptr, *ps = nullptr;
+            rc = new_matrix(n_hbm, b->ncols, esc_products, 0, CSRK_VAL_F64, &pm);
+            if (rc == CSRK_OK) {
+                sg_esc_rowptr<<<(unsigned)ceil_div(n_hbm + 1, 256), 256>>>(esc_off.as<int64_t>(), n_hbm, (int32_t *)pm->d_rowptrs);
+                sg_esc_expand<FAST><<<(unsigned)n_hbm, 256>>>(av, bv, list_b.as<int32_t>(), esc_off.as<int64_t>(), pm->d_colinds,
+                                                              (double *)pm->d_values);
+                rc = transpose_matrix(pm, 1, &pt, nullptr);
+            }
+            delete pm;
+            if (rc == CSRK_OK) rc = transpose_matrix(pt, 1, &ps, nullptr);
+            delete pt;
+            if (rc == CSRK_OK) {
+                const int32_t n_pos = (int32_t)esc_products, n_tiles = (int32_t)ceil_div(n_pos, SGE_TILE);
+                DevBuf tile_cnt, tile_off, row_cnt, first_run;
+                rc = tile_cnt.alloc((size_t)(n_tiles + 1) * 4);
+                if (rc == CSRK_OK) rc = tile_off.alloc((size_t)(n_tiles + 1) * 4);
+                if (rc == CSRK_OK) rc = row_cnt.alloc((size_t)(n_hbm + 1) * 4);
+                if (rc == CSRK_OK) rc = first_run.alloc((size_t)(n_hbm + 1) * 4);
+                if (rc == CSRK_OK) {
+                    sg_esc_gather_cnt<<<(unsigned)ceil_div(n_hbm, 256), 256>>>(list_b.as<int32_t>(), n_hbm, cnt.as<int32_t>(),
+                                                                               row_cnt.as<int32_t>());
+                    rc = exclusive_scan_i32(row_cnt.as<int32_t>(), first_run.as<int32_t>(), n_hbm, nullptr);
+                }
+                if (rc == CSRK_OK) {
+                    sg_esc_runs<false><<<(unsigned)n_tiles, 256>>>(list_b.as<int32_t>(), n_hbm, (const int32_t *)ps->d_rowptrs,
+                                                                   ps->d_colinds, (const double *)ps->d_values, n_pos,
+                                                                   tile_cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr);
+                    rc = exclusive_scan_i32(tile_cnt.as<int32_t>(), tile_off.as<int32_t>(), n_tiles, nullptr);
+                }
+                if (rc == CSRK_OK)
+                    sg_esc_runs<true><<<(unsigned)n_tiles, 256>>>(list_b.as<int32_t>(), n_hbm, (const int32_t *)ps->d_rowptrs,
+                                                                  ps->d_colinds, (const double *)ps->d_values, n_pos, nullptr,
+                                                                  tile_off.as<int32_t>(), first_run.as<int32_t>(),
+                                                                  (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
+                if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;   // the buffers are read by the kernels
+            }
+            if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;      // `ps` is read by the kernel
+            delete ps;
+        } else if (n_hbm > 0)
             sg_dense_kernel<true, FAST><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
                                                              n_hbm, work.as<double>(), mark.as<int32_t>(),
                                                              scratch.as<int32_t>(), scratch_len, nullptr,
