@@ -5,36 +5,34 @@
 //
 // The reference is a two-pass row-by-row algorithm with a dense marker/work row.  The GPU
 // version keeps the two passes (symbolic count -> exclusive scan -> numeric fill) but gives
-// every output row its own accumulator so rows run in parallel:
-//   * rows with <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or
-//     256-slot hash table in LDS, rank sort;
-//   * rows whose product count (sum over A_i of |B_j|) is <= 1024: one 256-thread workgroup
-//     per row, open-addressing hash table of 2048 slots in LDS (keys by atomicCAS, values by
-//     LDS float64 atomic add); the occupied slots are compacted and bitonic-sorted by column
-//     in LDS, so the output structure is deterministic and ascending;
-//   * heavier rows whose output is nearly full (>= 1/8 of the columns; every A B^T block of a
-//     MovieLens-shaped matrix): accumulated ON CHIP by persistent 1024-thread workgroups -- an LDS bit
-//     per output column for the symbolic pass, 16384-column float64 tiles for the numeric pass
-//     (ds_add_f64), ascending compaction -- see "rows with many products, accumulated in LDS";
-//   * heavy rows with at most 4096 distinct output columns: an 8192-slot LDS hash table sized by the
-//     output count (known from the symbolic pass), persistent workgroups, compaction + bitonic sort;
-//   * other heavy rows: a persistent grid of workgroups, each owning a dense float64 work row and
-//     marker row in HBM (the reference's `work` / `index` arrays, multiply.py:62,106); touched
-//     columns are listed as they are first marked, the list is bitonic-sorted, the sums gathered.
+// every output row its own accumulator so rows run in parallel, by product count (sum over A_i of |B_j|):
+//   * <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or 256-slot hash
+//     table in LDS, rank sort;
+//   * <= 1024 products: one 256-thread workgroup per row, open-addressing hash table of 2048 slots in
+//     LDS (keys by atomicCAS, values by LDS float64 add), compaction + bitonic sort by column;
+//   * more, with at least 4 products per (A entry, 1088-column strip) on average and B's rows ascending
+//     (every A B^T block of a ratings matrix): COLUMN STRIPS -- one wavefront per (row, strip), the
+//     strip's sums in 8.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once by binary
+//     search -- see "column strips";
+//   * the other heavy rows (wide, sparse outputs: power-law times power-law): EXPAND-SORT-COMPRESS --
+//     the products written out in the reference's order, two stable transposes, runs of equal columns
+//     added front to back -- see "expand, sort, compress";
+//   * fallbacks when those do not apply (B unsorted, products beyond the sort's budget): 16384-column
+//     float64 tiles in LDS for nearly full rows, an 8192-slot LDS hash table for rows with at most 4096
+//     distinct outputs, dense float64 work rows in HBM (the reference's `work` / `index` arrays,
+//     multiply.py:62,106) for the rest.
 // Like the reference, entries that cancel to exactly 0.0 are KEPT (csr/csr.py:555 filters
 // them afterwards) and C's row pointers are int32 (multiply.py:28).
 // Column order inside a row is ascending here; the reference's order (reverse discovery) is
 // pinned by none of its tests (hard part 3).
 //
-// Determinism.  Every kernel walks an output row's products the way the reference does -- A's entries jj in storage
-// order, for each the whole row B_j -- with ALL lanes of the row's wavefront or workgroup on ONE jj at a time
-// (sg_walk_products): inside one B_j the columns are distinct, so no two lanes add to the same accumulator in a step,
-// and a barrier separates the steps, so every output entry receives its products in ascending jj: the reference's
-// own order (work[k] += a * b, multiply.py:117-121), products rounded before they are added.  The sums are therefore
-// bitwise reproducible run to run (test_spgemm_deterministic) and equal to the sequential loop's bit for bit
-// whenever B's rows hold no column twice (two copies of a column inside ONE B row are added by two lanes of the same
-// step: their relative order is the hardware's).  (Before, the wavefronts of a workgroup took different jj and raced on
-// the accumulators: last bits varied run to run, and a 10^4-entry B_j was one wavefront's 156 dependent round trips.)
+// Determinism.  Every path gives each output entry its products in the reference's order -- A's entries jj in storage
+// order, for each the row B_j (work[k] += a * b, multiply.py:117-121) -- with the products rounded before they are
+// added, so the sums are bitwise reproducible run to run (test_spgemm_deterministic) and equal to the sequential
+// loop's bit for bit whenever B's rows hold no column twice.  The workgroup paths do it by walking with ALL lanes on ONE
+// jj at a time (sg_walk_products: inside one B_j the columns are distinct, a barrier separates the steps); the strips by
+// giving every column to one wavefront, whose LDS operations complete in program order; expand-sort-compress by a stable
+// sort.  (Round 1 let the wavefronts of a workgroup take different jj and race on the accumulators: last bits varied.)
 #include "common.h"
 #include "wave.h"
 
@@ -80,10 +78,7 @@ static MatView view_of(const Matrix *m)
 // single wavefront, whose LDS operations complete in order).  The (j, a_ij, row extent) of G consecutive jj and the first
 // NT entries of each B_j are requested before the first product is applied, so a group costs two memory round trips
 // instead of two per jj.  All trip counts are uniform over the NT threads.
-#ifndef CSRK_SG_U
-#define CSRK_SG_U 8
-#endif
-constexpr int SG_U = CSRK_SG_U;
+constexpr int SG_U = 8;
 template <bool FAST, int NT, int G, bool NEEDV, class Apply, class StepDone>
 __device__ __forceinline__ void sg_walk_products(const MatView &a, const MatView &b, int64_t as, int64_t ae, int t,
                                                  Apply &&apply, StepDone &&step_done)
@@ -566,16 +561,10 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, 
                 [&](int32_t k, double av, double bv) {
                     if (k >= t0 && k < t1) {
                         atomicAdd(&s_work[k - t0], __dmul_rn(av, bv));
-#ifndef CSRK_SG_NOBITS
                         atomicOr(&s_bits[(k - t0) >> 5], 1u << ((k - t0) & 31));
-#endif
                     }
                 },
-                [&]() {
-#ifndef CSRK_SG_NOBAR
-                    __syncthreads();
-#endif
-                });
+                [&]() { __syncthreads(); });
             __syncthreads();
             // ascending compaction of the tile, 1024 columns at a time
             for (int32_t k0 = 0; k0 < t1 - t0; k0 += SGL_THREADS) {

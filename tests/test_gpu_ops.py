@@ -321,13 +321,18 @@ def test_mult_abt_movielens_shape_blocks():
         assert P.nnz == int(keep.sum()) and np.array_equal(P.colinds, rci[keep])
 
 
-def test_spgemm_deterministic():
+@pytest.mark.parametrize('paths', ['default', 'fallbacks'])
+def test_spgemm_deterministic(paths, monkeypatch):
     """
-    Every SpGEMM kernel adds an output entry's products in ascending order of A's entries, the whole wavefront / workgroup
-    on one A entry at a time (csrc/spgemm.hip, sg_walk_products): the values are bitwise reproducible run to run, and --
-    B's rows holding no column twice -- bit-identical to the reference's sequential loop (multiply.py:117-121), which the
-    oracle restates.  Covers the wave-per-row, workgroup-hash, LDS-tile, big-hash and HBM-row paths.
+    Every SpGEMM path adds an output entry's products in ascending order of A's entries (csrc/spgemm.hip, "Determinism"):
+    the values are bitwise reproducible run to run, and -- B's rows holding no column twice -- bit-identical to the
+    reference's sequential loop (multiply.py:117-121), which the oracle restates.  'default': wave-per-row, workgroup
+    hash, column strips, expand-sort-compress; 'fallbacks' (CSRK_SPGEMM_STRIPS=0, CSRK_SPGEMM_ESC=0, what runs when B's
+    rows are unsorted or the products exceed the sort's budget): LDS tiles, the big LDS hash table, HBM work rows.
     """
+    if paths == 'fallbacks':
+        monkeypatch.setenv('CSRK_SPGEMM_STRIPS', '0')
+        monkeypatch.setenv('CSRK_SPGEMM_ESC', '0')
     from oracle import oracle as O
     from csr_amd import CSR, synth
     from csr_amd.kernels import hip as K
@@ -720,3 +725,44 @@ def test_spmm_survives_spmv_algo_change(monkeypatch):
     for c in (c1, c2, c3):
         assert np.allclose(c, ref, rtol=1e-10, atol=1e-12)
     assert np.allclose(y, ref[:, 0], rtol=1e-10, atol=1e-12)
+
+
+def test_spgemm_unsorted_b_rows():
+    """
+    The column strips need B's rows strictly ascending (sub-range bounds by binary search); sg_sorted_check sends a B
+    with unordered rows -- legal for the reference, whose SMMP never looks at the order (multiply.py:60-129) -- to the
+    other paths.  Same A, B as the nearly-full case of test_spgemm_deterministic, B's rows shuffled: the product must
+    equal the oracle's on the shuffled B bit for bit (the sums' order is A's, untouched by the shuffle).
+    """
+    from oracle import oracle as O
+    from csr_amd import CSR
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(7)
+    la = rng.integers(0, 6, 200)
+    la[::10] = 500
+    lb = rng.integers(0, 40, 1500)
+    lb[::7] = 5000
+    def mk(nrows, ncols, lens, shuffle):
+        rp = np.zeros(nrows + 1, dtype=np.int32)
+        rp[1:] = np.cumsum(lens)
+        rows = []
+        for n in lens:
+            c = np.sort(rng.choice(ncols, size=int(n), replace=False))
+            if shuffle:
+                rng.shuffle(c)
+            rows.append(c)
+        ci = np.concatenate(rows + [np.zeros(0, np.int64)]).astype(np.int32)
+        return CSR(nrows, ncols, int(rp[-1]), rp, ci, rng.uniform(-1, 1, size=int(rp[-1])), _cast=False)
+    A, B = mk(200, 1500, la, False), mk(1500, 20000, lb, True)
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        ch = K.mult_ab(ah, bh)
+        C = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values))
+    rci, rvs = sort_within_rows(crp, cci, cvs)
+    assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, rci)
+    assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64))
