@@ -22,6 +22,12 @@ def _csr(m):
     return CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False)
 
 
+def _rows_hold_no_column_twice(B):
+    rows = np.repeat(np.arange(B.nrows, dtype=np.int64), np.diff(B.rowptrs))
+    key = rows * B.ncols + B.colinds
+    return np.unique(key).size == key.size
+
+
 def _rand(rng, nrows, ncols, lens, dtype=np.float64, ptr64=False, values=True, sort=False):
     from csr_amd import CSR
     rp = np.zeros(nrows + 1, dtype=np.int64 if ptr64 else np.int32)
@@ -277,6 +283,9 @@ def test_spgemm_vs_oracle(case):
     _, bsorted = sort_within_rows(crp, cci, babs)
     assert np.all(np.abs(C.values - rvs) <= 1e-6 * bsorted + 1e-300)
     assert np.all(np.abs(C.values - rvs) <= 1e-12 * bsorted + 1e-300)
+    if _rows_hold_no_column_twice(B):
+        # the sums are taken in the reference's order (csrc/spgemm.hip, "Determinism"): the same bits
+        assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64))
 
 
 def test_mult_abt_movielens_shape_blocks():
@@ -315,6 +324,7 @@ def test_mult_abt_movielens_shape_blocks():
                                      (bt[0], bt[1], bt[2], bt[3], np.abs(bt[4])))
         _, bsorted = sort_within_rows(crp, cci, babs)
         assert np.all(np.abs(Cm.values - rvs) <= 1e-12 * bsorted + 1e-300)
+        assert np.array_equal(Cm.values.view(np.int64), rvs.view(np.int64))      # same order of addition: same bits
         # the caller's path (csr/csr.py:524-567): same product after _filter_zeros
         P = A.multiply(B, transpose=True)
         keep = rvs != 0.0
