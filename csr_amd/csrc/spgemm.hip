@@ -719,6 +719,7 @@ constexpr int SGS_G = CSRK_SGS_G;         // sub-ranges requested per round trip
 constexpr int SGS_MIN_PER_CELL = 4;
 constexpr int SGS_HEAVY_J = 1024;           // rows with this many A entries are scheduled first (longest chains)
 constexpr int64_t SGS_TABLE_BUDGET = 2ll << 30;
+constexpr int64_t SGS_TEMP_BUDGET = 24ll << 30;      // bytes of compacted strips held between the one pass and the copy
 
 // bad[0] = 1 unless every row of the matrix is strictly ascending in its columns
 __global__ void sg_sorted_check(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, int32_t nrows, int64_t nnz,
@@ -807,10 +808,13 @@ struct SgsGroup {
     bool one[SGS_G];                               // uniform: the chunk lies inside ONE sub-range
 };
 
-// One wavefront per (strip row, strip).  Symbolic: a flag byte per column -> the strip's occupancy words (occ, 64 columns
-// each) and count; numeric: float64 accumulators, compacted through the symbolic pass's occupancy words (entries that
-// cancel to 0.0 stay, like the reference's).
-template <bool NUMERIC>
+// One wavefront per (strip row, strip).  MODE 2 (the default): ONE pass -- float64 accumulators and a tag byte per column
+// (non-zero = the column received a product; entries that cancel to 0.0 stay, like the reference's), compacted into a
+// temporary region sized by the unit's product count (t_off, from sg_strip_cap); the counts give the row pointers and
+// sg_strip_copy moves the regions into C.  (A symbolic walk first cost 0.69 ms of a ratings block's 2.3; the copy 0.1.)
+// MODE 0 / 1: the two-pass form for products whose temporary would not fit the budget -- symbolic: a flag byte per
+// column -> the strip's occupancy words (occ, 64 columns each) and count; numeric: compacted through those words.
+template <int MODE>
 __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restrict__ a_rp, const double *__restrict__ a_vs,
                                                        const int32_t *__restrict__ b_ci, const double *__restrict__ b_vs,
                                                        int64_t b_last, const int32_t *__restrict__ list_strip,
@@ -818,16 +822,22 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
                                                        const int32_t *__restrict__ T, int32_t *__restrict__ cnt_s,
                                                        unsigned long long *__restrict__ occ, int32_t *__restrict__ cnt,
                                                        const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
-                                                       double *__restrict__ c_vs, int32_t *__restrict__ next)
+                                                       double *__restrict__ c_vs, const int64_t *__restrict__ t_off,
+                                                       int32_t *__restrict__ next)
 {
+    constexpr bool NUMERIC = MODE != 0, FUSED = MODE == 2;
     __shared__ double s_work[NUMERIC ? SGS_W : 1];
     __shared__ unsigned char s_flag[NUMERIC ? 4 : SGS_W];
-    // the chunk search's markers (64 words) and, in the numeric pass, the column tags (SGS_W bytes): never live together
-    __shared__ int32_t s_mark[NUMERIC ? SGS_W / 4 : WAVE];
+    __shared__ unsigned char s_tag[NUMERIC ? SGS_W : 4];      // numeric: lane number + 1 of the last lane that added to the column
+    __shared__ int32_t s_mark[WAVE];                          // the chunk search's markers
     const int lane = threadIdx.x;
     for (int c = 0; c < SGS_CHUNKS; c++) {
-        if (NUMERIC) s_work[c * WAVE + lane] = 0.0;
-        else s_flag[c * WAVE + lane] = 0;
+        if (NUMERIC) {
+            s_work[c * WAVE + lane] = 0.0;
+            s_tag[c * WAVE + lane] = 0;
+        } else {
+            s_flag[c * WAVE + lane] = 0;
+        }
     }
     __syncthreads();
     const int64_t n_units = (int64_t)n_strip * S;
@@ -868,21 +878,24 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
                 }
                 const double prod = __dmul_rn(gr.av[NUMERIC ? g : 0], gr.v[NUMERIC ? g : 0]);
                 if (gr.one[g]) {
-                    if (in) atomicAdd(&s_work[gr.k[g] - c0], prod);
+                    if (in) {
+                        atomicAdd(&s_work[gr.k[g] - c0], prod);
+                        if (FUSED) s_tag[gr.k[g] - c0] = 1;
+                    }
                     continue;
                 }
                 // Lanes of one A entry hold distinct columns; two entries of the chunk may hold the same column, and the
                 // order of same-address lanes inside one LDS instruction is the hardware's.  Only those lanes need an
-                // order: every lane tags its column with its lane number and reads the tag back -- a lane that finds
+                // order: every lane tags its column with its lane number + 1 and reads the tag back -- a lane that finds
                 // another's number shares its column, and overwrites the tag with 0xff so that the lane that won
                 // learns it too.  Columns seen once take ONE LDS add together; the others go entry by entry, ascending.
                 // (One add per entry for all lanes cost the heaviest unit of a ratings block -- 7000 short sub-ranges,
                 // ~30 entries per chunk, of which ~4 lanes clash -- 1.4 of its 2.5 M clocks.)
-                unsigned char *tag = (unsigned char *)s_mark;
+                unsigned char *tag = s_tag;
                 const int32_t col = in ? gr.k[g] - c0 : 0;
-                if (in) tag[col] = (unsigned char)lane;
+                if (in) tag[col] = (unsigned char)(lane + 1);
                 asm volatile("" ::: "memory");
-                const bool lost = in && tag[col] != (unsigned char)lane;
+                const bool lost = in && tag[col] != (unsigned char)(lane + 1);
                 asm volatile("" ::: "memory");
                 if (lost) tag[col] = 0xff;
                 asm volatile("" ::: "memory");
@@ -986,7 +999,27 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
             g_sg_stamps[u * 8 + 7] = st_acc[2];
         }
 #endif
-        if (NUMERIC) {
+        if (FUSED) {
+            const int64_t base = t_off[u];
+            int32_t tot = 0;
+            for (int c = 0; c < SGS_CHUNKS; c++) {
+                const bool there = s_tag[c * WAVE + lane] != 0;
+                const unsigned long long word = __builtin_amdgcn_ballot_w64(there);
+                const double x = s_work[c * WAVE + lane];
+                s_work[c * WAVE + lane] = 0.0;
+                s_tag[c * WAVE + lane] = 0;
+                if (there) {
+                    const int64_t o = base + tot + __popcll(word & ((1ull << lane) - 1ull));
+                    c_ci[o] = c0 + c * WAVE + lane;
+                    c_vs[o] = x;
+                }
+                tot += __popcll(word);
+            }
+            if (lane == 0) {
+                cnt_s[u] = tot;
+                if (tot) atomicAdd(&cnt[i], tot);
+            }
+        } else if (NUMERIC) {
             int32_t pre = 0;
             for (int32_t s0 = 0; s0 < s; s0 += WAVE) pre += s0 + lane < s ? cnt_s[(int64_t)q * S + s0 + lane] : 0;
             for (int off = WAVE / 2; off; off >>= 1) pre += __shfl_xor(pre, off, WAVE);
@@ -1017,6 +1050,45 @@ __global__ __launch_bounds__(WAVE) void sg_strip_kernel(const int32_t *__restric
         }
         __syncthreads();
         u = __builtin_amdgcn_readfirstlane(u_next);
+    }
+}
+
+// cap[u] = min(SGS_W, products of unit u): what its compacted strip can hold at most (one wavefront per unit)
+__global__ __launch_bounds__(256) void sg_strip_cap(const int32_t *__restrict__ a_rp, const int32_t *__restrict__ list_strip,
+                                                    const int32_t *__restrict__ ebase, int32_t n_strip, int32_t S, int32_t E,
+                                                    const int32_t *__restrict__ T, int32_t *__restrict__ cap)
+{
+    const int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (u >= (int64_t)n_strip * S) return;
+    const int32_t q = (int32_t)(u / S), s = (int32_t)(u - (int64_t)q * S);
+    const int32_t i = list_strip[q], J = a_rp[i + 1] - a_rp[i];
+    const int32_t *t_lo = T + (int64_t)s * E + ebase[q], *t_hi = t_lo + E;
+    int64_t tot = 0;
+    for (int32_t e = lane; e < J; e += WAVE) tot += t_hi[e] - t_lo[e];
+    for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_xor(tot, off, WAVE);
+    if (lane == 0) cap[u] = (int32_t)(tot < SGS_W ? tot : SGS_W);
+}
+
+// the units' compacted strips -> their places in C (one wavefront per unit)
+__global__ __launch_bounds__(256) void sg_strip_copy(const int32_t *__restrict__ list_strip, int32_t n_strip, int32_t S,
+                                                     const int32_t *__restrict__ cnt_s, const int64_t *__restrict__ t_off,
+                                                     const int32_t *__restrict__ t_ci, const double *__restrict__ t_vs,
+                                                     const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
+                                                     double *__restrict__ c_vs)
+{
+    const int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (u >= (int64_t)n_strip * S) return;
+    const int32_t q = (int32_t)(u / S), s = (int32_t)(u - (int64_t)q * S);
+    int32_t pre = 0;
+    for (int32_t s0 = 0; s0 < s; s0 += WAVE) pre += s0 + lane < s ? cnt_s[(int64_t)q * S + s0 + lane] : 0;
+    for (int off = WAVE / 2; off; off >>= 1) pre += __shfl_xor(pre, off, WAVE);
+    const int64_t src = t_off[u], dst = (int64_t)c_rp[list_strip[q]] + pre;
+    const int32_t n = cnt_s[u];
+    for (int32_t t = lane; t < n; t += WAVE) {
+        c_ci[dst + t] = t_ci[src + t];
+        c_vs[dst + t] = t_vs[src + t];
     }
 }
 
@@ -1230,7 +1302,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
     int grid_dense = 0;
     // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
     DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, esc_pu, esc_off;
-    bool use_esc = false;
+    bool use_esc = false, strip_fused = false;
+    DevBuf strip_off, strip_tci, strip_tvs;
     int64_t esc_products = 0;
     int32_t n_strip = 0, n_strip_e = 0, strips = 0;
     if (nr > 0) {
@@ -1319,7 +1392,6 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                 CSRK_TRY(emap.alloc((size_t)n_strip_e * 4));
                 CSRK_TRY(table.alloc((size_t)n_strip_e * (strips + 1) * 4));
                 CSRK_TRY(cnt_s.alloc((size_t)n_units * 4));
-                CSRK_TRY(occ_s.alloc((size_t)n_units * SGS_CHUNKS * 8));
                 sg_strip_expand<<<(unsigned)n_strip, 256>>>((const int32_t *)a->d_rowptrs, list_s.as<int32_t>(), ebase.as<int32_t>(),
                                                             emap.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
@@ -1328,11 +1400,39 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                     table.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
                 grid_strip = (unsigned)(n_units < (int64_t)grid_lds * SGS_WAVES_PER_CU ? n_units : (int64_t)grid_lds * SGS_WAVES_PER_CU);
-                const unsigned grid_sym = (unsigned)(n_units < (int64_t)grid_lds * 32 ? n_units : (int64_t)grid_lds * 32);
-                sg_strip_kernel<false><<<grid_sym, WAVE>>>(
-                    (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
-                    list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
-                    occ_s.as<unsigned long long>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr, next.as<int32_t>() + 3);
+                // one pass into a temporary when it fits (CSRK_SPGEMM_STRIP_FUSED=0: the two-pass form, for measurements)
+                const char *fu_env = getenv("CSRK_SPGEMM_STRIP_FUSED");
+                if (!(fu_env && atoi(fu_env) == 0)) {
+                    DevBuf cap;
+                    CSRK_TRY(cap.alloc((size_t)(n_units + 1) * 4));
+                    CSRK_TRY(strip_off.alloc((size_t)(n_units + 1) * 8));
+                    sg_strip_cap<<<(unsigned)ceil_div(n_units * WAVE, 256), 256>>>((const int32_t *)a->d_rowptrs, list_s.as<int32_t>(),
+                                                                                ebase.as<int32_t>(), n_strip, strips, n_strip_e,
+                                                                                table.as<int32_t>(), cap.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                    CSRK_TRY(exclusive_scan_i32_to_i64(cap.as<int32_t>(), strip_off.as<int64_t>(), n_units, nullptr));
+                    int64_t total_cap = 0;
+                    CSRK_HIP(hipMemcpy(&total_cap, strip_off.as<int64_t>() + n_units, 8, hipMemcpyDeviceToHost));
+                    strip_fused = total_cap * 12 <= SGS_TEMP_BUDGET;
+                    if (strip_fused) {
+                        CSRK_TRY(strip_tci.alloc((size_t)(total_cap + 1) * 4));
+                        CSRK_TRY(strip_tvs.alloc((size_t)(total_cap + 1) * 8));
+                    }
+                }
+                if (strip_fused) {
+                    sg_strip_kernel<2><<<grid_strip, WAVE>>>(
+                        (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
+                        list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
+                        nullptr, cnt.as<int32_t>(), nullptr, strip_tci.as<int32_t>(), strip_tvs.as<double>(),
+                        strip_off.as<int64_t>(), next.as<int32_t>() + 3);
+                } else {
+                    CSRK_TRY(occ_s.alloc((size_t)n_units * SGS_CHUNKS * 8));
+                    const unsigned grid_sym = (unsigned)(n_units < (int64_t)grid_lds * 32 ? n_units : (int64_t)grid_lds * 32);
+                    sg_strip_kernel<0><<<grid_sym, WAVE>>>(
+                        (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
+                        list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
+                        occ_s.as<unsigned long long>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, next.as<int32_t>() + 3);
+                }
                 CSRK_LAUNCH_CHECK();
             }
         }
@@ -1413,12 +1513,16 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
         sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
                                                          c->d_colinds, (double *)c->d_values);
         if constexpr (FAST) {
-            if (n_strip > 0)
-                sg_strip_kernel<true><<<grid_strip, WAVE>>>(
+            if (n_strip > 0 && strip_fused)
+                sg_strip_copy<<<(unsigned)ceil_div((int64_t)n_strip * strips * WAVE, 256), 256>>>(
+                    list_s.as<int32_t>(), n_strip, strips, cnt_s.as<int32_t>(), strip_off.as<int64_t>(), strip_tci.as<int32_t>(),
+                    strip_tvs.as<double>(), (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
+            else if (n_strip > 0)
+                sg_strip_kernel<1><<<grid_strip, WAVE>>>(
                     (const int32_t *)a->d_rowptrs, (const double *)a->d_values, b->d_colinds, (const double *)b->d_values, b->nnz - 1,
                     list_s.as<int32_t>(), ebase.as<int32_t>(), n_strip, strips, n_strip_e, table.as<int32_t>(), cnt_s.as<int32_t>(),
                     occ_s.as<unsigned long long>(), nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values,
-                    next.as<int32_t>() + 4);
+                    nullptr, next.as<int32_t>() + 4);
         }
         if (n_lds > 0)
             sg_lds_numeric_kernel<FAST><<<(unsigned)(n_lds < grid_lds ? n_lds : grid_lds), SGL_THREADS,

@@ -331,7 +331,7 @@ def test_mult_abt_movielens_shape_blocks():
         assert P.nnz == int(keep.sum()) and np.array_equal(P.colinds, rci[keep])
 
 
-@pytest.mark.parametrize('paths', ['default', 'fallbacks'])
+@pytest.mark.parametrize('paths', ['default', 'two-pass strips', 'fallbacks'])
 def test_spgemm_deterministic(paths, monkeypatch):
     """
     Every SpGEMM path adds an output entry's products in ascending order of A's entries (csrc/spgemm.hip, "Determinism"):
@@ -340,6 +340,8 @@ def test_spgemm_deterministic(paths, monkeypatch):
     hash, column strips, expand-sort-compress; 'fallbacks' (CSRK_SPGEMM_STRIPS=0, CSRK_SPGEMM_ESC=0, what runs when B's
     rows are unsorted or the products exceed the sort's budget): LDS tiles, the big LDS hash table, HBM work rows.
     """
+    if paths == 'two-pass strips':          # (the strips' form for products whose temporary exceeds the budget)
+        monkeypatch.setenv('CSRK_SPGEMM_STRIP_FUSED', '0')
     if paths == 'fallbacks':
         monkeypatch.setenv('CSRK_SPGEMM_STRIPS', '0')
         monkeypatch.setenv('CSRK_SPGEMM_ESC', '0')
