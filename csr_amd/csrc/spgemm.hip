@@ -795,6 +795,54 @@ __device__ unsigned long long g_sg_stamps[65536 * 8];
 #define SG_STAMP(I)
 #endif
 
+// Strip pointers of every row of B: SP[j * (S + 1) + s] = first entry of B_j whose column is >= s * SGS_W (one wavefront
+// per row, one pass over B), and the table gathered from them -- 0.03 ms where the binary searches of sg_strip_table take
+// 0.20 on a ratings block; used when B has few enough rows for the array (else the searches).
+__global__ __launch_bounds__(256) void sg_strip_rowstarts(const int32_t *__restrict__ b_rp, int32_t nrows, int32_t S,
+                                                          uint32_t *__restrict__ start_bits, int32_t *__restrict__ SP)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nrows) return;
+    const int32_t rs = b_rp[j], re = b_rp[j + 1];
+    if (rs == re) {
+        for (int32_t t = 0; t <= S; t++) SP[j * (S + 1) + t] = rs;       // an empty row: every boundary at its (empty) extent
+    } else {
+        atomicOr(&start_bits[rs >> 5], 1u << (rs & 31));
+    }
+}
+
+// one thread per entry of B; only the entries that open a strip (and each row's last) look their row up
+__global__ __launch_bounds__(256) void sg_strip_rowptrs(const int32_t *__restrict__ b_rp, const int32_t *__restrict__ b_ci,
+                                                        int32_t nrows, int64_t nnz, int32_t S,
+                                                        const uint32_t *__restrict__ start_bits, int32_t *__restrict__ SP)
+{
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nnz) return;
+    const bool first = (start_bits[pos >> 5] >> (pos & 31)) & 1u;
+    const bool last = pos + 1 == nnz || ((start_bits[(pos + 1) >> 5] >> ((pos + 1) & 31)) & 1u);
+    const int32_t sc = b_ci[pos] / SGS_W, sb = first ? -1 : b_ci[pos - 1] / SGS_W;
+    if (sc == sb && !last) return;
+    int32_t lo = 0, hi = nrows;            // the row of pos: the largest j with b_rp[j] <= pos (empty rows in between skipped)
+    while (hi - lo > 1) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if ((int64_t)b_rp[mid] <= pos) lo = mid; else hi = mid;
+    }
+    int32_t *sp = SP + (int64_t)lo * (S + 1);
+    for (int32_t t = sb + 1; t <= sc; t++) sp[t] = (int32_t)pos;          // the first entry at or beyond these boundaries
+    if (last)
+        for (int32_t t = sc + 1; t <= S; t++) sp[t] = (int32_t)pos + 1;
+}
+
+__global__ __launch_bounds__(256) void sg_strip_table_gather(const int32_t *__restrict__ a_ci, const int32_t *__restrict__ emap,
+                                                             const int32_t *__restrict__ SP, int32_t E, int32_t S,
+                                                             int32_t *__restrict__ T)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)E * (S + 1)) return;
+    const int32_t s = (int32_t)(idx / E), e = (int32_t)(idx - (int64_t)s * E);
+    T[idx] = SP[(int64_t)a_ci[emap[e]] * (S + 1) + s];
+}
+
 __device__ __forceinline__ double sg_readlane_f64(double x, int r)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), r), __builtin_amdgcn_readlane(__double2loint(x), r));
@@ -1269,7 +1317,7 @@ __global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large
 }
 
 template <bool FAST>
-static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
+static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 {
     CSRK_REQUIRE(a->ncols == b->nrows, "mult_ab: A is %d x %d but B is %d x %d", a->nrows, a->ncols, b->nrows, b->ncols);
     CSRK_REQUIRE(a->val_type != CSRK_VAL_NONE && b->val_type != CSRK_VAL_NONE,
@@ -1318,7 +1366,7 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
             strips = (int32_t)ceil_div(b->ncols, SGS_W);
             if (strips > SGS_MAX_S || (int64_t)nr * strips > (1ll << 30)) strips = 0;
         }
-        if (strips > 0 && b->nnz > 1) {          // the strips need B's rows strictly ascending
+        if (strips > 0 && b->nnz > 1 && !b_rows_ascend) {          // the strips need B's rows strictly ascending (our transpose's are)
             CSRK_TRY(sorted_bad.alloc(4));
             CSRK_HIP(hipMemset(sorted_bad.p, 0, 4));
             sg_sorted_check<<<(unsigned)ceil_div(b->nnz - 1, 256), 256>>>((const int32_t *)b->d_rowptrs, b->d_colinds, b->nrows,
@@ -1395,10 +1443,28 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
                 sg_strip_expand<<<(unsigned)n_strip, 256>>>((const int32_t *)a->d_rowptrs, list_s.as<int32_t>(), ebase.as<int32_t>(),
                                                             emap.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
-                sg_strip_table<<<(unsigned)ceil_div((int64_t)n_strip_e * (strips + 1), 256), 256>>>(
-                    a->d_colinds, (const int32_t *)b->d_rowptrs, b->d_colinds, emap.as<int32_t>(), n_strip_e, strips,
-                    table.as<int32_t>());
-                CSRK_LAUNCH_CHECK();
+                if ((int64_t)b->nrows <= 2 * (int64_t)n_strip_e) {
+                    DevBuf sp, start_bits;
+                    CSRK_TRY(sp.alloc((size_t)b->nrows * (strips + 1) * 4));
+                    CSRK_TRY(start_bits.alloc((size_t)(b->nnz / 32 + 2) * 4));
+                    CSRK_HIP(hipMemsetAsync(start_bits.p, 0, (size_t)(b->nnz / 32 + 2) * 4, nullptr));
+                    sg_strip_rowstarts<<<(unsigned)ceil_div(b->nrows, 256), 256>>>((const int32_t *)b->d_rowptrs, b->nrows, strips,
+                                                                                  start_bits.as<uint32_t>(), sp.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                    sg_strip_rowptrs<<<(unsigned)ceil_div(b->nnz, 256), 256>>>((const int32_t *)b->d_rowptrs, b->d_colinds, b->nrows,
+                                                                              b->nnz, strips, start_bits.as<uint32_t>(),
+                                                                              sp.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                    sg_strip_table_gather<<<(unsigned)ceil_div((int64_t)n_strip_e * (strips + 1), 256), 256>>>(
+                        a->d_colinds, emap.as<int32_t>(), sp.as<int32_t>(), n_strip_e, strips, table.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                    // (`sp` goes back to the pool here: every launch of this call is on the default stream, in order)
+                } else {
+                    sg_strip_table<<<(unsigned)ceil_div((int64_t)n_strip_e * (strips + 1), 256), 256>>>(
+                        a->d_colinds, (const int32_t *)b->d_rowptrs, b->d_colinds, emap.as<int32_t>(), n_strip_e, strips,
+                        table.as<int32_t>());
+                    CSRK_LAUNCH_CHECK();
+                }
                 grid_strip = (unsigned)(n_units < (int64_t)grid_lds * SGS_WAVES_PER_CU ? n_units : (int64_t)grid_lds * SGS_WAVES_PER_CU);
                 // one pass into a temporary when it fits (CSRK_SPGEMM_STRIP_FUSED=0: the two-pass form, for measurements)
                 const char *fu_env = getenv("CSRK_SPGEMM_STRIP_FUSED");
@@ -1593,10 +1659,12 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out)
     return CSRK_OK;
 }
 
-static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out)
+// b_rows_ascend: the caller knows that B's rows hold strictly ascending columns (the transpose of a matrix without
+// repeated entries); otherwise a kernel checks before the strips rely on it
+static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 {
     const bool fast = !a->ptr64 && !b->ptr64 && a->val_type == CSRK_VAL_F64 && b->val_type == CSRK_VAL_F64;
-    return fast ? spgemm_run<true>(a, b, out) : spgemm_run<false>(a, b, out);
+    return fast ? spgemm_run<true>(a, b, out, b_rows_ascend) : spgemm_run<false>(a, b, out, b_rows_ascend);
 }
 
 }  // namespace csrk
@@ -1621,7 +1689,7 @@ int csrk_spgemm_ab(csrk_handle_t ah, csrk_handle_t bh, csrk_handle_t *out)
     Matrix *a = from_handle(ah), *b = from_handle(bh);
     if (!a || !b) return CSRK_ERR_INVALID;
     Matrix *c = nullptr;
-    CSRK_TRY(spgemm_impl(a, b, &c));
+    CSRK_TRY(spgemm_impl(a, b, &c, false));
     *out = to_handle(c);
     return CSRK_OK;
 }
@@ -1638,7 +1706,9 @@ int csrk_spgemm_abt(csrk_handle_t ah, csrk_handle_t bh, csrk_handle_t *out)
     Matrix *bt = nullptr;
     CSRK_TRY(transpose_matrix(b, 1, &bt, nullptr));
     Matrix *c = nullptr;
-    int rc = spgemm_impl(a, bt, &c);
+    // (the transpose's rows ascend -- strictly, unless a row of B holds a column twice; the strips' sub-range bounds need
+    // only the order)
+    int rc = spgemm_impl(a, bt, &c, true);
     delete bt;
     if (rc != CSRK_OK) return rc;
     *out = to_handle(c);
