@@ -502,6 +502,9 @@ def main():
                    'parallelism': f'row-partition x{world}',
                    'collective': collective},
         'hbm_gbs_end_to_end': round((nnz * 12 + (nrows + 1) * 4 + nrows * 8 + ncols * 8) / (elapsed / args.steps) / 1e9, 1),
+        # the whole SpMV against the roofline: algorithmic bytes of one product / step time / 8 TB/s (north_star's 0.60 target;
+        # roofline.frac below is the dominant kernel's own)
+        'whole_spmv_frac_of_hbm_roofline': (roofline or {}).get('frac_whole_spmv_over_step'),
         'roofline': roofline,
         'gen_seconds': round(t_gen, 2),
         # one-off costs on this handle, outside the timed region: the first call (plan-less kernel) and the second
