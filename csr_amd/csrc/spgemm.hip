@@ -160,28 +160,21 @@ __global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, i
     if (lane == 0) ub[i] = tot;
 }
 
-__global__ void sg_list_large(const int64_t *__restrict__ ub, int32_t nrows, int32_t *__restrict__ list,
-                              int32_t *__restrict__ n_large)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrows) return;
-    if (ub[i] > SG_CAP) list[atomicAdd(n_large, 1)] = (int32_t)i;
-}
-
 __device__ __forceinline__ uint32_t sg_hash(int32_t k) { return ((uint32_t)k * 2654435761u) >> 21; }   // 11 bits
 
 // One workgroup per output row with 0 < ub <= SG_CAP.
 template <bool NUMERIC, bool FAST>
 __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView b, const int64_t *__restrict__ ub,
-                                                            int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
-                                                            int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+                                                            const unsigned char *__restrict__ route, int32_t *__restrict__ cnt,
+                                                            const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
+                                                            double *__restrict__ c_vs)
 {
     __shared__ int32_t s_key[SG_SLOTS];
     __shared__ double s_val[NUMERIC ? SG_SLOTS : 1];
     __shared__ int32_t s_n;
     const int i = blockIdx.x, tid = threadIdx.x;
     const int64_t u = ub[i];
-    if (u > SG_CAP || u <= SG_WAVE_CAP) return;   // dense path / wave-per-row path
+    if (u > SG_CAP || u <= SG_WAVE_CAP || route[i] != 0) return;   // heavy-row paths / wave-per-row path / expand-sort-compress
     for (int s = tid; s < SG_SLOTS; s += SG_THREADS) {
         s_key[s] = -1;
         if (NUMERIC) s_val[s] = 0.0;
@@ -277,7 +270,8 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
 // launch with a 2048-slot table costs ~20 us of fixed work (clear, compact, sort) however few products
 // the row has; most rows of a sparse product have a handful.
 template <int SLOTS, bool NUMERIC, bool FAST>
-__global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub, int lo, int hi,
+__global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub,
+                                                     const unsigned char *__restrict__ route, int lo, int hi,
                                                      int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
                                                      int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
 {
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, cons
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int64_t i = (int64_t)blockIdx.x * WPB + w;
     const int64_t u = i < a.nrows ? ub[i] : 0;
-    const bool mine = u > lo && u <= hi;          // wave-uniform; every wave still reaches the barriers
+    const bool mine = u > lo && u <= hi && route[i] == 0;          // wave-uniform; every wave still reaches the barriers
     for (int sl = lane; sl < SLOTS; sl += WAVE) {
         s_key[w][sl] = -1;
         if (NUMERIC) s_val[w][sl] = 0.0;
@@ -737,25 +731,41 @@ __global__ void sg_sorted_check(const int32_t *__restrict__ rp, const int32_t *_
     if ((int64_t)rp[lo] != k) bad[0] = 1;
 }
 
-// Rows with more than SG_CAP products: strip rows (S > 0 and enough products per table cell; counters[1], their A
-// entries numbered from counters[2]) or the workgroup paths' list (counters[0]).  Two launches: rows with long A rows
-// first (pass 0), so the longest chains start first.
-__global__ void sg_list_rows(const int32_t *__restrict__ a_rp, const int64_t *__restrict__ ub, int32_t nrows, int32_t S, int pass,
-                             int32_t *__restrict__ list_large, int32_t *__restrict__ list_strip, int32_t *__restrict__ ebase,
+// Where every row with products goes (route[i]; 0 = the wave-per-row kernels, <= SG_WAVE_CAP products, or the workgroup hash
+// kernel, <= SG_CAP):
+//   1 strips          more than SG_CAP products, at least SGS_MIN_PER_CELL per (A entry, strip) on average, strips usable
+//                     (counters[1]; their A entries numbered from counters[2]);
+//   2 expand-sort-compress   more than esc_min products and not (more than SG_CAP and that dense) (counters[3]), when it
+//                     is on (esc_min >= 0);
+//   3 the round-1 heavy-row paths (counters[0]): the other rows with more than SG_CAP products.
+// Two launches: strip rows with long A rows first (pass 0), so the longest chains start first.
+template <bool FAST>
+__global__ void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t nrows, int32_t s_dense, int strips_ok,
+                             int64_t esc_min, int pass, unsigned char *__restrict__ route, int32_t *__restrict__ list_large,
+                             int32_t *__restrict__ list_strip, int32_t *__restrict__ ebase, int32_t *__restrict__ list_esc,
                              int32_t *__restrict__ counters)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrows || ub[i] <= SG_CAP) return;
-    const int32_t J = a_rp[i + 1] - a_rp[i];
-    const bool strip = S > 0 && ub[i] >= (int64_t)SGS_MIN_PER_CELL * J * S;
-    if (strip) {
+    if (i >= nrows) return;
+    const int64_t u = ub[i];
+    if (u <= 0) return;
+    const int64_t J = rp_at<FAST>(a, i + 1) - rp_at<FAST>(a, i);
+    const bool dense = s_dense > 0 && u >= (int64_t)SGS_MIN_PER_CELL * J * s_dense;
+    if (u > SG_CAP && dense && strips_ok) {
         if ((J >= SGS_HEAVY_J) == (pass == 0)) {
             const int32_t q = atomicAdd(&counters[1], 1);
             list_strip[q] = (int32_t)i;
-            ebase[q] = atomicAdd(&counters[2], J);
+            ebase[q] = atomicAdd(&counters[2], (int32_t)J);
+            route[i] = 1;
         }
-    } else if (pass == 0) {
+    } else if (pass != 0) {
+        return;
+    } else if (esc_min >= 0 && u > esc_min && !(dense && u > SG_CAP)) {
+        list_esc[atomicAdd(&counters[3], 1)] = (int32_t)i;
+        route[i] = 2;
+    } else if (u > SG_CAP) {
         list_large[atomicAdd(&counters[0], 1)] = (int32_t)i;
+        route[i] = 3;
     }
 }
 
@@ -1148,7 +1158,11 @@ __global__ __launch_bounds__(256) void sg_strip_copy(const int32_t *__restrict__
 // into ascending column order with the products of one column still in their original order, and one thread per run of
 // equal columns adds the run front to back: the reference's sums, bit for bit, without atomics.  (Before: a dense float64
 // work row in HBM per workgroup, a barrier per A entry: 7.5 ms of a 200k x 200k product's 13.8.)
-constexpr int64_t SGE_BUDGET_PRODUCTS = 200ll << 20;     // above this the HBM work rows are used instead
+constexpr int64_t SGE_BUDGET_PRODUCTS = 200ll << 20;     // above this the round-1 heavy-row paths are used instead
+#ifndef CSRK_SGE_MIN
+#define CSRK_SGE_MIN 128
+#endif
+constexpr int64_t SGE_MIN = CSRK_SGE_MIN;                // rows with more products than this (and not dense enough for strips)
 
 __global__ void sg_esc_gather(const int32_t *__restrict__ list, int32_t n, const int64_t *__restrict__ ub, int64_t *__restrict__ pu)
 {
@@ -1231,11 +1245,11 @@ __global__ __launch_bounds__(256) void sg_esc_expand(MatView a, MatView b, const
 // positions count their run starts (WRITE = false), the counts are scanned, and the second launch numbers the runs --
 // run g of the product matrix is entry g - first_run[q] of row q's output (first_run = scan of the symbolic counts).
 constexpr int SGE_TILE = 1024;
-template <bool WRITE>
+template <int MODE>      // 0: count the run starts of every tile, 1: number the runs (first run of every row), 2: write C
 __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ list, int32_t n_q, const int32_t *__restrict__ p_rp,
                                                    const int32_t *__restrict__ p_ci, const double *__restrict__ p_vs,
                                                    int32_t n_pos, int32_t *__restrict__ tile_cnt,
-                                                   const int32_t *__restrict__ tile_off, const int32_t *__restrict__ first_run,
+                                                   const int32_t *__restrict__ tile_off, int32_t *__restrict__ first_run,
                                                    const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
                                                    double *__restrict__ c_vs)
 {
@@ -1274,7 +1288,7 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
     }
     int64_t total;
     const int64_t before = sg_block_exscan(n, tid, s_w, &total);
-    if (!WRITE) {
+    if (MODE == 0) {
         if (tid == 0) tile_cnt[blockIdx.x] = (int32_t)total;
         return;
     }
@@ -1283,6 +1297,11 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
     for (int x = 0; x < 4; x++) {
         if (!start[x]) continue;
         const int32_t t = t0 + x, e = p_rp[qx[x] + 1];
+        if (MODE == 1) {
+            if (t == p_rp[qx[x]]) first_run[qx[x]] = g;      // (every row here has products: its first position is a run start)
+            g++;
+            continue;
+        }
         double sum = 0.0 + p_vs[t];                   // (the reference's work[k] starts from +0.0: -0.0 products)
         for (int32_t u = t + 1; u < e && p_ci[u] == kx[x]; u++) sum += p_vs[u];
         const int64_t o = (int64_t)c_rp[list[qx[x]]] + (g - first_run[qx[x]]);
@@ -1292,10 +1311,12 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
     }
 }
 
-__global__ void sg_esc_gather_cnt(const int32_t *__restrict__ list, int32_t n, const int32_t *__restrict__ cnt, int32_t *__restrict__ out)
+// cnt[row] = runs of the row = first_run of the next row (the total after the last) - its own
+__global__ void sg_esc_rowcnt(const int32_t *__restrict__ list, int32_t n, const int32_t *__restrict__ first_run,
+                              const int32_t *__restrict__ total_runs, int32_t *__restrict__ cnt)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n) out[q] = cnt[list[q]];
+    if (q < n) cnt[list[q]] = (q + 1 < n ? first_run[q + 1] : total_runs[0]) - first_run[q];
 }
 
 // large rows (list[0..n_large)) -> (a) output nearly full and narrow enough for the LDS tiles, (h) few enough
@@ -1349,9 +1370,17 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int32_t n_large = 0;
     int grid_dense = 0;
     // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
-    DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, esc_pu, esc_off;
-    bool use_esc = false, strip_fused = false;
+    DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, route;
+    bool strip_fused = false, hash_rows = true;
     DevBuf strip_off, strip_tci, strip_tvs;
+    // expand-sort-compress rows: their list, the sorted product matrix (kept from the counting step to the write), run numbering
+    DevBuf list_e, esc_pu, esc_off, esc_tile_cnt, esc_tile_off, esc_first_run;
+    Matrix *esc_ps = nullptr;
+    struct EscGuard {
+        Matrix **m;
+        ~EscGuard() { delete *m; }
+    } esc_guard{&esc_ps};
+    int32_t n_esc = 0, esc_tiles = 0;
     int64_t esc_products = 0;
     int32_t n_strip = 0, n_strip_e = 0, strips = 0;
     if (nr > 0) {
@@ -1376,17 +1405,22 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             CSRK_HIP(hipMemcpy(&bad, sorted_bad.p, 4, hipMemcpyDeviceToHost));
             if (bad) strips = 0;
         }
+        // expand-sort-compress takes the rows above esc_min products that are not dense enough for the strips
+        // (CSRK_SPGEMM_ESC=0: off; CSRK_SPGEMM_ESC_MIN=n: its lower bound, default SGE_MIN)
+        const char *esc_env = getenv("CSRK_SPGEMM_ESC"), *escmin_env = getenv("CSRK_SPGEMM_ESC_MIN");
+        int64_t esc_min = (esc_env && atoi(esc_env) == 0) ? -1 : (escmin_env && atoll(escmin_env) >= 0 ? atoll(escmin_env) : SGE_MIN);
+        int32_t s_dense = (int32_t)ceil_div(b->ncols, SGS_W);       // the strips' density test, whether they can be used or not
+        if (s_dense > SGS_MAX_S) s_dense = 0;
+        CSRK_TRY(route.alloc((size_t)nr + 1));
+        CSRK_TRY(list_e.alloc((size_t)(nr + 1) * 4));
         int32_t cnts[4] = {0, 0, 0, 0};
         for (;;) {
             CSRK_HIP(hipMemset(counters.p, 0, 16));
-            if (strips > 0) {
-                for (int pass = 0; pass < 2; pass++) {
-                    sg_list_rows<<<g, 256>>>((const int32_t *)a->d_rowptrs, ub.as<int64_t>(), nr, strips, pass, list.as<int32_t>(),
-                                             list_s.as<int32_t>(), ebase.as<int32_t>(), counters.as<int32_t>());
-                    CSRK_LAUNCH_CHECK();
-                }
-            } else {
-                sg_list_large<<<g, 256>>>(ub.as<int64_t>(), nr, list.as<int32_t>(), counters.as<int32_t>());
+            CSRK_HIP(hipMemset(route.p, 0, (size_t)nr + 1));
+            for (int pass = 0; pass < (strips > 0 ? 2 : 1); pass++) {
+                sg_list_rows<FAST><<<g, 256>>>(av, ub.as<int64_t>(), nr, s_dense, strips > 0 ? 1 : 0, esc_min, pass,
+                                               route.as<unsigned char>(), list.as<int32_t>(), list_s.as<int32_t>(),
+                                               ebase.as<int32_t>(), list_e.as<int32_t>(), counters.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
             }
             CSRK_HIP(hipMemcpy(cnts, counters.p, 16, hipMemcpyDeviceToHost));
@@ -1394,8 +1428,22 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                 strips = 0;                      // the sub-range table would not pay for itself: workgroup paths
                 continue;
             }
+            if (cnts[3] > 0) {                   // do the products of the expand-sort-compress rows fit its budget?
+                CSRK_TRY(esc_pu.alloc((size_t)(cnts[3] + 1) * 8));
+                CSRK_TRY(esc_off.alloc((size_t)(cnts[3] + 1) * 8));
+                sg_esc_gather<<<(unsigned)ceil_div(cnts[3], 256), 256>>>(list_e.as<int32_t>(), cnts[3], ub.as<int64_t>(),
+                                                                         esc_pu.as<int64_t>());
+                CSRK_LAUNCH_CHECK();
+                CSRK_TRY(exclusive_scan_i64(esc_pu.as<int64_t>(), esc_off.as<int64_t>(), cnts[3], nullptr));
+                CSRK_HIP(hipMemcpy(&esc_products, esc_off.as<int64_t>() + cnts[3], 8, hipMemcpyDeviceToHost));
+                if (esc_products > SGE_BUDGET_PRODUCTS) {
+                    esc_min = -1;                // beyond the sort's budget: the round-1 heavy-row paths take these rows
+                    continue;
+                }
+            }
             break;
         }
+        n_esc = cnts[3];
         n_large = cnts[0];
         n_strip = cnts[1];
         n_strip_e = cnts[2];
@@ -1424,14 +1472,50 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             return CSRK_OK;
         };
         if (n_large > 0 && !lds_symbolic) CSRK_TRY(alloc_dense());
+        if (n_esc > 0) {
+            // expand-sort-compress, first half: products out in the reference's order, two stable transposes, runs counted
+            Matrix *pm = nullptr, *pt = nullptr;
+            CSRK_TRY(new_matrix(n_esc, b->ncols, esc_products, 0, CSRK_VAL_F64, &pm));
+            sg_esc_rowptr<<<(unsigned)ceil_div(n_esc + 1, 256), 256>>>(esc_off.as<int64_t>(), n_esc, (int32_t *)pm->d_rowptrs);
+            sg_esc_expand<FAST><<<(unsigned)n_esc, 256>>>(av, bv, list_e.as<int32_t>(), esc_off.as<int64_t>(), pm->d_colinds,
+                                                          (double *)pm->d_values);
+            int erc = transpose_matrix(pm, 1, &pt, nullptr);
+            delete pm;
+            if (erc == CSRK_OK) erc = transpose_matrix(pt, 1, &esc_ps, nullptr);
+            delete pt;
+            CSRK_TRY(erc);
+            const int32_t n_pos = (int32_t)esc_products;
+            esc_tiles = (int32_t)ceil_div(n_pos, SGE_TILE);
+            CSRK_TRY(esc_tile_cnt.alloc((size_t)(esc_tiles + 1) * 4));
+            CSRK_TRY(esc_tile_off.alloc((size_t)(esc_tiles + 1) * 4));
+            CSRK_TRY(esc_first_run.alloc((size_t)(n_esc + 1) * 4));
+#define ESC_RUNS(MODE, C_RP, C_CI, C_VS)                                                                                     \
+    sg_esc_runs<MODE><<<(unsigned)esc_tiles, 256>>>(list_e.as<int32_t>(), n_esc, (const int32_t *)esc_ps->d_rowptrs,           \
+                                                    esc_ps->d_colinds, (const double *)esc_ps->d_values, n_pos,                 \
+                                                    esc_tile_cnt.as<int32_t>(), esc_tile_off.as<int32_t>(),                     \
+                                                    esc_first_run.as<int32_t>(), C_RP, C_CI, C_VS)
+            ESC_RUNS(0, nullptr, nullptr, nullptr);
+            CSRK_LAUNCH_CHECK();
+            CSRK_TRY(exclusive_scan_i32(esc_tile_cnt.as<int32_t>(), esc_tile_off.as<int32_t>(), esc_tiles, nullptr));
+            ESC_RUNS(1, nullptr, nullptr, nullptr);
+            CSRK_LAUNCH_CHECK();
+            sg_esc_rowcnt<<<(unsigned)ceil_div(n_esc, 256), 256>>>(list_e.as<int32_t>(), n_esc, esc_first_run.as<int32_t>(),
+                                                                   esc_tile_off.as<int32_t>() + esc_tiles, cnt.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+        }
         // symbolic (rows with no products keep the zero count of the memset)
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
-        sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
+        sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
         CSRK_LAUNCH_CHECK();
-        sg_hash_kernel<false, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), cnt.as<int32_t>(), nullptr, nullptr, nullptr);
-        CSRK_LAUNCH_CHECK();
+        // (with expand-sort-compress taking every row above SG_WAVE_CAP products the workgroup hash kernel has no rows)
+        hash_rows = esc_min < 0 || esc_min > SG_WAVE_CAP;
+        if (hash_rows) {
+            sg_hash_kernel<false, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), cnt.as<int32_t>(),
+                                                                     nullptr, nullptr, nullptr);
+            CSRK_LAUNCH_CHECK();
+        }
         CSRK_TRY(next.alloc(20));
         CSRK_HIP(hipMemset(next.p, 0, 20));
         if constexpr (FAST) {
@@ -1511,43 +1595,18 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             CSRK_TRY(list_a.alloc((size_t)n_large * 4));
             CSRK_TRY(list_h.alloc((size_t)n_large * 4));
             CSRK_TRY(list_b.alloc((size_t)n_large * 4));
-            // Rows that are not nearly full go through expand-sort-compress (the rows the big LDS hash table could hold
-            // too: 2.8 -> 0.3 ms on the power-law products) while their products fit the budget; beyond it the table
-            // takes the rows it can hold and the HBM work rows the others.  CSRK_SPGEMM_ESC=0 / CSRK_SPGEMM_HASHCAP=n:
-            // measurements.
-            const char *hc_env = getenv("CSRK_SPGEMM_HASHCAP"), *esc_env = getenv("CSRK_SPGEMM_ESC");
-            const bool esc_on = !(esc_env && atoi(esc_env) == 0);
-            int32_t hash_cap = hc_env ? (atoi(hc_env) < SGB_CAP ? atoi(hc_env) : SGB_CAP) : (esc_on ? 0 : SGB_CAP);
             CSRK_TRY(n_ab.alloc(12));
-            for (;;) {
-                CSRK_HIP(hipMemset(n_ab.p, 0, 12));
-                sg_split_large<<<(unsigned)ceil_div(n_large, 256), 256>>>(list.as<int32_t>(), n_large, cnt.as<int32_t>(), b->ncols,
-                                                                         hash_cap, list_a.as<int32_t>(), list_h.as<int32_t>(),
-                                                                         list_b.as<int32_t>(), n_ab.as<int32_t>());
-                CSRK_LAUNCH_CHECK();
-                int32_t nab[3] = {0, 0, 0};
-                CSRK_HIP(hipMemcpy(nab, n_ab.p, 12, hipMemcpyDeviceToHost));
-                n_lds = nab[0];
-                n_hash = nab[1];
-                n_hbm = nab[2];
-                use_esc = false;
-                if (n_hbm > 0 && esc_on) {
-                    CSRK_TRY(esc_pu.alloc((size_t)(n_hbm + 1) * 8));
-                    CSRK_TRY(esc_off.alloc((size_t)(n_hbm + 1) * 8));
-                    sg_esc_gather<<<(unsigned)ceil_div(n_hbm, 256), 256>>>(list_b.as<int32_t>(), n_hbm, ub.as<int64_t>(),
-                                                                           esc_pu.as<int64_t>());
-                    CSRK_LAUNCH_CHECK();
-                    CSRK_TRY(exclusive_scan_i64(esc_pu.as<int64_t>(), esc_off.as<int64_t>(), n_hbm, nullptr));
-                    CSRK_HIP(hipMemcpy(&esc_products, esc_off.as<int64_t>() + n_hbm, 8, hipMemcpyDeviceToHost));
-                    use_esc = esc_products > 0 && esc_products <= SGE_BUDGET_PRODUCTS;
-                }
-                if (n_hbm > 0 && !use_esc && hash_cap < SGB_CAP && !hc_env) {
-                    hash_cap = SGB_CAP;          // over the budget: give the LDS table its rows back and look again
-                    continue;
-                }
-                break;
-            }
-            if (n_hbm > 0 && !use_esc) CSRK_TRY(alloc_dense());
+            CSRK_HIP(hipMemset(n_ab.p, 0, 12));
+            sg_split_large<<<(unsigned)ceil_div(n_large, 256), 256>>>(list.as<int32_t>(), n_large, cnt.as<int32_t>(), b->ncols,
+                                                                     SGB_CAP, list_a.as<int32_t>(), list_h.as<int32_t>(),
+                                                                     list_b.as<int32_t>(), n_ab.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            int32_t nab[3] = {0, 0, 0};
+            CSRK_HIP(hipMemcpy(nab, n_ab.p, 12, hipMemcpyDeviceToHost));
+            n_lds = nab[0];
+            n_hash = nab[1];
+            n_hbm = nab[2];
+            if (n_hbm > 0) CSRK_TRY(alloc_dense());
         } else if (n_large > 0) {
             sg_dense_kernel<false, FAST><<<grid_dense, SG_THREADS>>>(av, bv, list.as<int32_t>(), n_large, work.as<double>(),
                                                               mark.as<int32_t>(), nullptr, 0, cnt.as<int32_t>(), nullptr,
@@ -1572,12 +1631,14 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int rc = exclusive_scan_i32(cnt.as<int32_t>(), (int32_t *)c->d_rowptrs, nr, nullptr);
     if (rc == CSRK_OK && nr > 0 && c_nnz > 0) {
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
+        sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
                                               c->d_colinds, (double *)c->d_values);
-        sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), 32, SG_WAVE_CAP, nullptr,
+        sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, nullptr,
                                                (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
-        sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), nullptr, (const int32_t *)c->d_rowptrs,
-                                                         c->d_colinds, (double *)c->d_values);
+        if (hash_rows)
+            sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), nullptr,
+                                                             (const int32_t *)c->d_rowptrs,
+                                                             c->d_colinds, (double *)c->d_values);
         if constexpr (FAST) {
             if (n_strip > 0 && strip_fused)
                 sg_strip_copy<<<(unsigned)ceil_div((int64_t)n_strip * strips * WAVE, 256), 256>>>(
@@ -1600,46 +1661,13 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                                  (size_t)SGB_SLOTS * 12 + (size_t)SGB_CAP * 12>>>(av, bv, list_h.as<int32_t>(), n_hash,
                                                                                   (const int32_t *)c->d_rowptrs, c->d_colinds,
                                                                                   (double *)c->d_values, next.as<int32_t>() + 2);
-        if (n_hbm > 0 && use_esc) {
-            Matrix *pm = nullptr, *pt = nullptr, *ps = nullptr;
-            rc = new_matrix(n_hbm, b->ncols, esc_products, 0, CSRK_VAL_F64, &pm);
-            if (rc == CSRK_OK) {
-                sg_esc_rowptr<<<(unsigned)ceil_div(n_hbm + 1, 256), 256>>>(esc_off.as<int64_t>(), n_hbm, (int32_t *)pm->d_rowptrs);
-                sg_esc_expand<FAST><<<(unsigned)n_hbm, 256>>>(av, bv, list_b.as<int32_t>(), esc_off.as<int64_t>(), pm->d_colinds,
-                                                              (double *)pm->d_values);
-                rc = transpose_matrix(pm, 1, &pt, nullptr);
-            }
-            delete pm;
-            if (rc == CSRK_OK) rc = transpose_matrix(pt, 1, &ps, nullptr);
-            delete pt;
-            if (rc == CSRK_OK) {
-                const int32_t n_pos = (int32_t)esc_products, n_tiles = (int32_t)ceil_div(n_pos, SGE_TILE);
-                DevBuf tile_cnt, tile_off, row_cnt, first_run;
-                rc = tile_cnt.alloc((size_t)(n_tiles + 1) * 4);
-                if (rc == CSRK_OK) rc = tile_off.alloc((size_t)(n_tiles + 1) * 4);
-                if (rc == CSRK_OK) rc = row_cnt.alloc((size_t)(n_hbm + 1) * 4);
-                if (rc == CSRK_OK) rc = first_run.alloc((size_t)(n_hbm + 1) * 4);
-                if (rc == CSRK_OK) {
-                    sg_esc_gather_cnt<<<(unsigned)ceil_div(n_hbm, 256), 256>>>(list_b.as<int32_t>(), n_hbm, cnt.as<int32_t>(),
-                                                                               row_cnt.as<int32_t>());
-                    rc = exclusive_scan_i32(row_cnt.as<int32_t>(), first_run.as<int32_t>(), n_hbm, nullptr);
-                }
-                if (rc == CSRK_OK) {
-                    sg_esc_runs<false><<<(unsigned)n_tiles, 256>>>(list_b.as<int32_t>(), n_hbm, (const int32_t *)ps->d_rowptrs,
-                                                                   ps->d_colinds, (const double *)ps->d_values, n_pos,
-                                                                   tile_cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr, nullptr);
-                    rc = exclusive_scan_i32(tile_cnt.as<int32_t>(), tile_off.as<int32_t>(), n_tiles, nullptr);
-                }
-                if (rc == CSRK_OK)
-                    sg_esc_runs<true><<<(unsigned)n_tiles, 256>>>(list_b.as<int32_t>(), n_hbm, (const int32_t *)ps->d_rowptrs,
-                                                                  ps->d_colinds, (const double *)ps->d_values, n_pos, nullptr,
-                                                                  tile_off.as<int32_t>(), first_run.as<int32_t>(),
-                                                                  (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
-                if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;   // the buffers are read by the kernels
-            }
-            if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;      // `ps` is read by the kernel
-            delete ps;
-        } else if (n_hbm > 0)
+        if (n_esc > 0) {
+            // expand-sort-compress, second half: every run of equal columns added front to back into its place in C
+            const int32_t n_pos = (int32_t)esc_products;
+            ESC_RUNS(2, (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
+        }
+#undef ESC_RUNS
+        if (n_hbm > 0)
             sg_dense_kernel<true, FAST><<<grid_dense, SG_THREADS>>>(av, bv, lds_symbolic ? list_b.as<int32_t>() : list.as<int32_t>(),
                                                              n_hbm, work.as<double>(), mark.as<int32_t>(),
                                                              scratch.as<int32_t>(), scratch_len, nullptr,
