@@ -8,19 +8,19 @@
 // every output row its own accumulator so rows run in parallel, by product count (sum over A_i of |B_j|):
 //   * <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or 256-slot hash
 //     table in LDS, rank sort;
-//   * <= 1024 products: one 256-thread workgroup per row, open-addressing hash table of 2048 slots in
-//     LDS (keys by atomicCAS, values by LDS float64 add), compaction + bitonic sort by column;
-//   * more, with at least 4 products per (A entry, 1088-column strip) on average and B's rows ascending
+//   * more than 1024 products, at least 4 per (A entry, 1088-column strip) on average, B's rows ascending
 //     (every A B^T block of a ratings matrix): COLUMN STRIPS -- one wavefront per (row, strip), the
-//     strip's sums in 8.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once by binary
-//     search -- see "column strips";
-//   * the other heavy rows (wide, sparse outputs: power-law times power-law): EXPAND-SORT-COMPRESS --
-//     the products written out in the reference's order, two stable transposes, runs of equal columns
-//     added front to back -- see "expand, sort, compress";
-//   * fallbacks when those do not apply (B unsorted, products beyond the sort's budget): 16384-column
-//     float64 tiles in LDS for nearly full rows, an 8192-slot LDS hash table for rows with at most 4096
-//     distinct outputs, dense float64 work rows in HBM (the reference's `work` / `index` arrays,
-//     multiply.py:62,106) for the rest.
+//     strip's sums in 8.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once -- see
+//     "column strips";
+//   * every other row above 128 products: EXPAND-SORT-COMPRESS -- the products written out in the
+//     reference's order, two stable transposes, runs of equal columns added front to back -- see
+//     "expand, sort, compress";
+//   * fallbacks when those do not apply (B unsorted and the output dense, products beyond the sort's
+//     budget): one 256-thread workgroup per row with a 2048-slot LDS hash table (<= 1024 products),
+//     16384-column float64 tiles in LDS for nearly full rows, an 8192-slot LDS hash table for rows with
+//     at most 4096 distinct outputs, dense float64 work rows in HBM (the reference's `work` / `index`
+//     arrays, multiply.py:62,106) for the rest.
+// sg_list_rows writes every row's route; the kernels of one path skip the others' rows.
 // Like the reference, entries that cancel to exactly 0.0 are KEPT (csr/csr.py:555 filters
 // them afterwards) and C's row pointers are int32 (multiply.py:28).
 // Column order inside a row is ascending here; the reference's order (reverse discovery) is
