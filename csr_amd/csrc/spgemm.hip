@@ -8,9 +8,9 @@
 // every output row its own accumulator so rows run in parallel, by product count (sum over A_i of |B_j|):
 //   * <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or 256-slot hash
 //     table in LDS, rank sort;
-//   * more than 1024 products, at least 4 per (A entry, 1088-column strip) on average, B's rows ascending
+//   * more than 1024 products, at least 4 per (A entry, 832-column strip) on average, B's rows ascending
 //     (every A B^T block of a ratings matrix): COLUMN STRIPS -- one wavefront per (row, strip), the
-//     strip's sums in 8.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once -- see
+//     strip's sums in 6.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once -- see
 //     "column strips";
 //   * every other row above 128 products: EXPAND-SORT-COMPRESS -- the products written out in the
 //     reference's order, two stable transposes, runs of equal columns added front to back -- see
@@ -700,9 +700,13 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
 // binary search (sg_strip_table) -- the table is 4 (S+1) bytes per A entry, which is why only rows with at least
 // SGS_MIN_PER_CELL products per (A entry, strip) on average take this path.
 #ifndef CSRK_SGS_W
-#define CSRK_SGS_W 1088
+#define CSRK_SGS_W 832
 #endif
-constexpr int SGS_W = CSRK_SGS_W;           // columns per strip (17 x 64): 8.5 KiB of sums + a tag byte per column
+// columns per strip (13 x 64): 6.5 KiB of sums + a tag byte per column, 20 wavefronts per CU.  Measured on the ratings
+// blocks (2000 x 20000^T / 500 x 5000^T): 544 -> 1.85 / 1.08 ms, 704 -> 1.68 / 1.17, 832 -> 1.58 / 1.13, 960 -> 1.70 / 1.27,
+// 1088 -> 1.65 / 1.23: narrower strips split the hot columns' ordered adds over more units, wider ones need fewer
+// sub-ranges per product.
+constexpr int SGS_W = CSRK_SGS_W;
 constexpr int SGS_WAVES_PER_CU = 16 * 1088 / SGS_W;
 constexpr int SGS_CHUNKS = SGS_W / WAVE;
 constexpr int SGS_MAX_S = 256;              // strips per row (wider products fall back to the workgroup paths)

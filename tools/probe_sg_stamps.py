@@ -11,7 +11,7 @@ def sub(r1):
 ha, ka = sub(2000); hb, kb = sub(20000)
 for i in range(2):
     c = handle_t(0); check(lib.csrk_spgemm_abt(ha, hb, C.byref(c))); torch.cuda.synchronize(); check(lib.csrk_free(c))
-S = -(-20000 // 1088); n = 2000 * S
+S = -(-20000 // 832); n = 2000 * S
 buf = np.zeros(n * 8, dtype=np.uint64)
 lib.csrk_debug_sg_stamps.argtypes = [C.c_void_p, C.c_int]
 check(lib.csrk_debug_sg_stamps(buf.ctypes.data_as(C.c_void_p), buf.size))
