@@ -273,8 +273,12 @@ template <int SLOTS, bool NUMERIC, bool FAST>
 __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub,
                                                      const unsigned char *__restrict__ route, int lo, int hi,
                                                      int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
-                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs,
+                                                     const int64_t *__restrict__ t_off)
 {
+    // NUMERIC with t_off: ONE pass -- the row's entries go to a temporary at t_off[i] (room for its product count) and
+    // its length to cnt[i]; sg_small_copy moves them once the row pointers exist (a symbolic pass of their own cost these
+    // rows 0.6 of a power-law product's 3.5 ms).
     constexpr int WPB = 256 / WAVE;
     __shared__ int32_t s_key[WPB][SLOTS];
     __shared__ double s_val[NUMERIC ? WPB : 1][NUMERIC ? SLOTS : 1];
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, cons
     }
     __syncthreads();
     if (mine) {
-        const int32_t o0 = c_rp[i];
+        const int64_t o0 = t_off ? t_off[i] : (int64_t)c_rp[i];
+        if (t_off && lane == 0) cnt[i] = n;
         for (int t = lane; t < n; t += WAVE) {
             const int32_t kt = s_ck[w][t];
             int rank = 0;
@@ -338,6 +343,33 @@ __global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, cons
             c_ci[o0 + rank] = kt;
             c_vs[o0 + rank] = s_cv[w][t];
         }
+    }
+}
+
+// room[i] = products of a row the wave-per-row kernels serve, 0 for the others (their temporaries' sizes)
+__global__ void sg_small_room(const int64_t *__restrict__ ub, const unsigned char *__restrict__ route, int32_t nrows,
+                              int32_t *__restrict__ room)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int64_t u = ub[i];
+    room[i] = (u > 0 && u <= SG_WAVE_CAP && route[i] == 0) ? (int32_t)u : 0;
+}
+
+// the wave-per-row kernels' temporaries -> C: 16 lanes per row
+__global__ __launch_bounds__(256) void sg_small_copy(const int32_t *__restrict__ room, int32_t nrows, const int32_t *__restrict__ cnt,
+                                                     const int64_t *__restrict__ t_off, const int32_t *__restrict__ t_ci,
+                                                     const double *__restrict__ t_vs, const int32_t *__restrict__ c_rp,
+                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
+    const int l = threadIdx.x & 15;
+    if (i >= nrows || room[i] == 0) return;
+    const int64_t src = t_off[i], dst = c_rp[i];
+    const int32_t n = cnt[i];
+    for (int32_t t = l; t < n; t += 16) {
+        c_ci[dst + t] = t_ci[src + t];
+        c_vs[dst + t] = t_vs[src + t];
     }
 }
 
@@ -1375,7 +1407,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int grid_dense = 0;
     // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
     DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, route;
-    bool strip_fused = false, hash_rows = true;
+    bool strip_fused = false, hash_rows = true, small_fused = false, small_any = true;
+    DevBuf small_room, small_off, small_tci, small_tvs;
     DevBuf strip_off, strip_tci, strip_tvs;
     // expand-sort-compress rows: their list, the sorted product matrix (kept from the counting step to the write), run numbering
     DevBuf list_e, esc_pu, esc_off, esc_tile_cnt, esc_tile_off, esc_first_run;
@@ -1509,10 +1542,41 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
         }
         // symbolic (rows with no products keep the zero count of the memset)
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
-        CSRK_LAUNCH_CHECK();
-        sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, cnt.as<int32_t>(), nullptr, nullptr, nullptr);
-        CSRK_LAUNCH_CHECK();
+        // the rows of at most SG_WAVE_CAP products: one pass into temporaries when they fit (CSRK_SPGEMM_SMALL_FUSED=0: two passes)
+        {
+            const char *sf_env = getenv("CSRK_SPGEMM_SMALL_FUSED");
+            if (!(sf_env && atoi(sf_env) == 0)) {
+                CSRK_TRY(small_room.alloc((size_t)(nr + 1) * 4));
+                CSRK_TRY(small_off.alloc((size_t)(nr + 1) * 8));
+                sg_small_room<<<g, 256>>>(ub.as<int64_t>(), route.as<unsigned char>(), nr, small_room.as<int32_t>());
+                CSRK_LAUNCH_CHECK();
+                CSRK_TRY(exclusive_scan_i32_to_i64(small_room.as<int32_t>(), small_off.as<int64_t>(), nr, nullptr));
+                int64_t total = 0;
+                CSRK_HIP(hipMemcpy(&total, small_off.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost));
+                small_fused = total > 0 && total * 12 <= SGS_TEMP_BUDGET / 4;
+                if (small_fused) {
+                    CSRK_TRY(small_tci.alloc((size_t)total * 4));
+                    CSRK_TRY(small_tvs.alloc((size_t)total * 8));
+                }
+                small_any = total > 0;
+            }
+        }
+        if (small_fused) {
+            sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(),
+                                                        nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(), small_off.as<int64_t>());
+            CSRK_LAUNCH_CHECK();
+            sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP,
+                                                         cnt.as<int32_t>(), nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(),
+                                                         small_off.as<int64_t>());
+            CSRK_LAUNCH_CHECK();
+        } else if (small_any) {
+            sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(),
+                                                         nullptr, nullptr, nullptr, nullptr);
+            CSRK_LAUNCH_CHECK();
+            sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP,
+                                                          cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr);
+            CSRK_LAUNCH_CHECK();
+        }
         // (with expand-sort-compress taking every row above SG_WAVE_CAP products the workgroup hash kernel has no rows)
         hash_rows = esc_min < 0 || esc_min > SG_WAVE_CAP;
         if (hash_rows) {
@@ -1635,10 +1699,17 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int rc = exclusive_scan_i32(cnt.as<int32_t>(), (int32_t *)c->d_rowptrs, nr, nullptr);
     if (rc == CSRK_OK && nr > 0 && c_nnz > 0) {
         const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
-        sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, nullptr, (const int32_t *)c->d_rowptrs,
-                                              c->d_colinds, (double *)c->d_values);
-        sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, nullptr,
-                                               (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
+        if (small_fused) {
+            sg_small_copy<<<(unsigned)ceil_div((int64_t)nr * 16, 256), 256>>>(small_room.as<int32_t>(), nr, cnt.as<int32_t>(),
+                                                                             small_off.as<int64_t>(), small_tci.as<int32_t>(),
+                                                                             small_tvs.as<double>(), (const int32_t *)c->d_rowptrs,
+                                                                             c->d_colinds, (double *)c->d_values);
+        } else if (small_any) {
+            sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, nullptr,
+                                                        (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values, nullptr);
+            sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, nullptr,
+                                                         (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values, nullptr);
+        }
         if (hash_rows)
             sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), nullptr,
                                                              (const int32_t *)c->d_rowptrs,

@@ -342,7 +342,9 @@ def test_spgemm_deterministic(paths, monkeypatch):
     """
     if paths == 'two-pass strips':          # (the strips' form for products whose temporary exceeds the budget)
         monkeypatch.setenv('CSRK_SPGEMM_STRIP_FUSED', '0')
+        monkeypatch.setenv('CSRK_SPGEMM_SMALL_FUSED', '0')      # (and the wave-per-row kernels in two passes)
     if paths == 'fallbacks':
+        monkeypatch.setenv('CSRK_SPGEMM_SMALL_FUSED', '0')
         monkeypatch.setenv('CSRK_SPGEMM_STRIPS', '0')
         monkeypatch.setenv('CSRK_SPGEMM_ESC', '0')
     from oracle import oracle as O
