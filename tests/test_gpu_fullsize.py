@@ -173,6 +173,48 @@ def test_transpose_config5_full_size():
         check(lib.csrk_trim_cache())
 
 
+def test_mult_abt_config5_large_block():
+    """
+    BASELINE.json configs[4], the mult_abt half, at a block size a caller would use (int32 product pointers,
+    multiply.py:28, force row blocks): A[0:6000] . B[0:20000]^T of the MovieLens-25M-shaped matrix -- 1.2e9 products, 1.2e8
+    outputs -- through csrk_spgemm_abt (transpose + column strips, csrc/spgemm.hip), against the oracle's transpose + SMMP:
+    row pointers, columns (ascending here, reverse discovery there) and VALUES bit for bit -- the strips add every
+    entry's products in the reference's order (multiply.py:117-121).  And the encode/decode property at this size:
+    (A B^T)^T == B A^T entry for entry up to the order of addition, checked through row sums.
+    """
+    from oracle import oracle as O
+    from csr_amd import CSR, synth
+    from csr_amd.kernels import hip as K
+    m = synth.movielens_like(device='cpu')
+    M = CSR(m['nrows'], m['ncols'], int(m['colinds'].numel()), m['rowptrs'].numpy(), m['colinds'].numpy(), m['values'].numpy(),
+            _cast=False)
+    A, B = M.subset_rows(0, 6000), M.subset_rows(0, 20000)
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        ch = K.mult_abt(ah, bh)
+        Cm = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    bt = O.transpose(B.nrows, B.ncols, B.rowptrs, B.colinds, B.values)
+    nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
+    assert (Cm.nrows, Cm.ncols) == (6000, 20000) == (nr, nc)
+    assert np.array_equal(Cm.rowptrs, crp)
+    rows = np.repeat(np.arange(nr, dtype=np.int64), np.diff(crp))
+    o = np.lexsort((cci, rows))
+    assert np.array_equal(Cm.colinds, cci[o])
+    assert np.array_equal(Cm.values.view(np.int64), cvs[o].view(np.int64))
+    # column sums of C against B (A^T 1): sum_i C[i, k] = sum_j B[k, j] * (sum_i A[i, j])
+    colsum_a = np.bincount(A.colinds, weights=A.values, minlength=A.ncols)
+    want = np.add.reduceat(B.values * colsum_a[B.colinds], B.rowptrs[:-1].astype(np.int64))
+    want[np.diff(B.rowptrs) == 0] = 0.0
+    got = np.bincount(Cm.colinds, weights=Cm.values, minlength=Cm.ncols)
+    scale = np.add.reduceat(np.abs(B.values) * np.bincount(A.colinds, weights=np.abs(A.values), minlength=A.ncols)[B.colinds],
+                            B.rowptrs[:-1].astype(np.int64))
+    assert np.all(np.abs(got - want) <= 1e-10 * scale + 1e-300)
+
+
 @pytest.mark.parametrize('collective', ['auto', 'auto-all', 'p2p-k2', 'p2p-split', 'ipc-push'])
 def test_bench_two_ranks_plumbing(collective):
     """
