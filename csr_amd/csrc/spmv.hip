@@ -1422,8 +1422,19 @@ __global__ __launch_bounds__(1024) void acc_reduce_multi_kernel(RedJobs jobs, do
 // Run numbering: run(e) = tile_base[t] - 1 + #{row starts in the tile up to and including e}, with
 // tile_base[t] = index of the row holding the tile's first entry among the non-empty rows, + 1 if that entry
 // is not the row's first.  Needs ncols < 2^30 (two flag bits); otherwise the tile kernel stays in charge.
-constexpr int LS_THREADS = 1024;            // one persistent workgroup per CU
-constexpr int LS_HOT_LDS = 8192;            // packed columns kept in LDS (64 KiB)
+// One persistent workgroup per CU: 8 wavefronts and the 15360 most referenced packed columns in LDS (120 KiB + 8 staging
+// buffers = 152 KiB).  Measured on the headline matrix (stream kernel alone; threads / LDS slots): 1024 / 8192 -> 0.204 ms,
+// 512 / 8192 -> 0.195, 640 / 14336 -> 0.200, 512 / 15360 -> 0.190, 448 / 15872 -> 0.196, 384 / 16384 -> 0.200, 256 / 17408 ->
+// 0.230: the kernel queues on the CU's vector memory path, and eight wavefronts keep it as busy
+// as sixteen while leaving LDS for twice the columns.
+#ifndef CSRK_LS_THREADS
+#define CSRK_LS_THREADS 512
+#endif
+constexpr int LS_THREADS = CSRK_LS_THREADS;
+#ifndef CSRK_LS_HOT_LDS
+#define CSRK_LS_HOT_LDS 15360
+#endif
+constexpr int LS_HOT_LDS = CSRK_LS_HOT_LDS;
 constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile
 #ifndef CSRK_LS_SEQ
 #define CSRK_LS_SEQ 3
