@@ -747,6 +747,10 @@ constexpr int SGS_MAX_S = 256;              // strips per row (wider products fa
 #endif
 constexpr int SGS_G = CSRK_SGS_G;         // sub-ranges requested per round trip
 constexpr int SGS_MIN_PER_CELL = 4;
+#ifndef CSRK_SGS_MIN_PER_UNIT
+#define CSRK_SGS_MIN_PER_UNIT 512
+#endif
+constexpr int SGS_MIN_PER_UNIT = CSRK_SGS_MIN_PER_UNIT;     // products per (row, strip) on average
 constexpr int SGS_HEAVY_J = 1024;           // rows with this many A entries are scheduled first (longest chains)
 constexpr int64_t SGS_TABLE_BUDGET = 2ll << 30;
 constexpr int64_t SGS_TEMP_BUDGET = 24ll << 30;      // bytes of compacted strips held between the one pass and the copy
@@ -786,7 +790,9 @@ __global__ void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t 
     const int64_t u = ub[i];
     if (u <= 0) return;
     const int64_t J = rp_at<FAST>(a, i + 1) - rp_at<FAST>(a, i);
-    const bool dense = s_dense > 0 && u >= (int64_t)SGS_MIN_PER_CELL * J * s_dense;
+    // dense enough for the strips: enough products per table cell, and per (row, strip) unit -- with 241 strips a row of
+    // 10^4 products would be 241 units of 40 products each
+    const bool dense = s_dense > 0 && u >= (int64_t)SGS_MIN_PER_CELL * J * s_dense && u >= (int64_t)SGS_MIN_PER_UNIT * s_dense;
     if (u > SG_CAP && dense && strips_ok) {
         if ((J >= SGS_HEAVY_J) == (pass == 0)) {
             const int32_t q = atomicAdd(&counters[1], 1);
