@@ -142,22 +142,52 @@ constexpr int SG_SLOTS = 2048;
 constexpr int SG_CAP = 1024;      // max products for the LDS hash path (load factor <= 0.5)
 constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take the wave-per-row kernels
 
-// products per output row: ub[i] = sum_{j in A_i} |B_j| (one wavefront per row: a thread per row spent 1.9 ms
-// on 2000 rows of a MovieLens-shaped A, whose rows have up to 7000 entries)
+// products per output row: ub[i] = sum_{j in A_i} |B_j|.  (A thread per row spent 1.9 ms on 2000 rows of a MovieLens-shaped A,
+// whose rows have up to 7000 entries.)  Eight lanes per row (most rows of a sparse product have a handful of entries: a wavefront per row took 159 us for 10^6
+// rows); rows of more than SG_COUNT_LONG entries are listed for sg_count_products_long, a wavefront each.
+constexpr int SG_COUNT_LONG = 64;
 template <bool FAST>
-__global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub)
+__global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub,
+                                                         int32_t *__restrict__ long_list, int32_t *__restrict__ n_long)
 {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (i >= a.nrows) return;
-    const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+    const int l = threadIdx.x & 7;
     int64_t tot = 0;
-    for (int64_t jj = s + lane; jj < e; jj += WAVE) {
-        const int32_t j = a.ci[jj];
-        tot += rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j);
+    bool is_long = false;
+    if (i < a.nrows) {
+        const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
+        is_long = e - s > SG_COUNT_LONG;
+        if (!is_long)
+            for (int64_t jj = s + l; jj < e; jj += 8) {
+                const int32_t j = a.ci[jj];
+                tot += rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j);
+            }
     }
-    for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
-    if (lane == 0) ub[i] = tot;
+    for (int off = 4; off; off >>= 1) tot += __shfl_down(tot, off, 8);
+    if (i < a.nrows && l == 0) {
+        if (is_long) long_list[atomicAdd(n_long, 1)] = (int32_t)i;
+        else ub[i] = tot;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void sg_count_products_long(MatView a, MatView b, int64_t *__restrict__ ub,
+                                                              const int32_t *__restrict__ long_list,
+                                                              const int32_t *__restrict__ n_long)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int32_t n = n_long[0];
+    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; q < n; q += (int64_t)gridDim.x * blockDim.x / WAVE) {
+        const int32_t i = long_list[q];
+        const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
+        int64_t tot = 0;
+        for (int64_t jj = s + lane; jj < e; jj += WAVE) {
+            const int32_t j = a.ci[jj];
+            tot += rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j);
+        }
+        for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
+        if (lane == 0) ub[i] = tot;
+    }
 }
 
 __device__ __forceinline__ uint32_t sg_hash(int32_t k) { return ((uint32_t)k * 2654435761u) >> 21; }   // 11 bits
@@ -786,28 +816,35 @@ __global__ void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t 
                              int32_t *__restrict__ counters)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrows) return;
-    const int64_t u = ub[i];
-    if (u <= 0) return;
-    const int64_t J = rp_at<FAST>(a, i + 1) - rp_at<FAST>(a, i);
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t u = i < nrows ? ub[i] : 0;
+    const int64_t J = u > 0 ? rp_at<FAST>(a, i + 1) - rp_at<FAST>(a, i) : 0;
     // dense enough for the strips: enough products per table cell, and per (row, strip) unit -- with 241 strips a row of
     // 10^4 products would be 241 units of 40 products each
     const bool dense = s_dense > 0 && u >= (int64_t)SGS_MIN_PER_CELL * J * s_dense && u >= (int64_t)SGS_MIN_PER_UNIT * s_dense;
-    if (u > SG_CAP && dense && strips_ok) {
-        if ((J >= SGS_HEAVY_J) == (pass == 0)) {
-            const int32_t q = atomicAdd(&counters[1], 1);
-            list_strip[q] = (int32_t)i;
-            ebase[q] = atomicAdd(&counters[2], (int32_t)J);
-            route[i] = 1;
+    int to = 0;
+    if (u > SG_CAP && dense && strips_ok) to = ((J >= SGS_HEAVY_J) == (pass == 0)) ? 1 : 0;
+    else if (pass != 0 || u <= 0) to = 0;
+    else if (esc_min >= 0 && u > esc_min && !(dense && u > SG_CAP)) to = 2;
+    else if (u > SG_CAP) to = 3;
+    // one atomic per wavefront and list (10^5 rows appending one by one to the same counter took 59 us)
+    if (to == 1) {           // (few rows, and each needs its own A-entry base)
+        const int32_t q = atomicAdd(&counters[1], 1);
+        list_strip[q] = (int32_t)i;
+        ebase[q] = atomicAdd(&counters[2], (int32_t)J);
+        route[i] = 1;
+    }
+#pragma unroll
+    for (int t = 2; t <= 3; t++) {
+        const unsigned long long m = __ballot(to == t);
+        if (m == 0) continue;                                   // uniform
+        int32_t base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&counters[t == 2 ? 3 : 0], (int32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), WAVE);
+        if (to == t) {
+            (t == 2 ? list_esc : list_large)[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+            route[i] = (unsigned char)t;
         }
-    } else if (pass != 0) {
-        return;
-    } else if (esc_min >= 0 && u > esc_min && !(dense && u > SG_CAP)) {
-        list_esc[atomicAdd(&counters[3], 1)] = (int32_t)i;
-        route[i] = 2;
-    } else if (u > SG_CAP) {
-        list_large[atomicAdd(&counters[0], 1)] = (int32_t)i;
-        route[i] = 3;
     }
 }
 
@@ -1428,10 +1465,15 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int32_t n_strip = 0, n_strip_e = 0, strips = 0;
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
-        sg_count_products<FAST><<<(unsigned)ceil_div((int64_t)nr * WAVE, 256), 256>>>(av, bv, ub.as<int64_t>());
-        CSRK_LAUNCH_CHECK();
+        // (list_s / counters are scratch here: the list of long rows and its length)
         CSRK_TRY(counters.alloc(16));
         CSRK_TRY(list_s.alloc((size_t)(nr + 1) * 4));
+        CSRK_HIP(hipMemset(counters.p, 0, 16));
+        sg_count_products<FAST><<<(unsigned)ceil_div((int64_t)nr * 8, 256), 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(),
+                                                                                 counters.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        sg_count_products_long<FAST><<<256, 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(), counters.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
         CSRK_TRY(ebase.alloc((size_t)(nr + 1) * 4));
         const char *strips_env = getenv("CSRK_SPGEMM_STRIPS");      // 0: workgroup paths only (A/B measurements)
         if (FAST && !(strips_env && atoi(strips_env) == 0)) {
