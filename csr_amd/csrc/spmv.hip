@@ -148,7 +148,7 @@ struct SpmvPlan {
     hipEvent_t ev_fork = nullptr, ev_pack = nullptr, ev_aux = nullptr, ev_tier[2] = {nullptr, nullptr};
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
                         // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
-                        // 131072-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
+                        // 262144-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
     LightStream ls;                       // the rows that stay on the row-major path
     LightStream t1s;                      // tier 1 as a stream of (column block, row) runs
     std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
@@ -713,11 +713,11 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
 //     at the chip's L1-miss request rate (~150-170 G 64-B requests/s): every gather is its own L2
 //     round trip, so the gathers themselves had to go.
 //   tier 1 (rows of 128..2047 entries): a (row, block) pair of 4096 columns would hold < 1 entry, so
-//     blocks are 131072 columns (1 MiB of x) and x is gathered from global memory; tiles run
+//     blocks are 262144 columns (2 MiB of x; 131072 until late in round 2) and x is gathered from global memory; tiles run
 //     block-major and block b is served only by workgroups with blockIdx % 8 == b % 8 (one XCD, so ONE
 //     L2 holds the window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.
 constexpr int PANEL_CB0 = 4096;
-constexpr int PANEL_CB1 = 131072;
+constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block, row) pairs of 131072 at the same kernel time, -9 us of partials)
 #ifndef PANEL_T0
 #define PANEL_T0 512      // threads per workgroup, tier 0: same LDS as 256 threads, twice the wavefronts per CU
 #endif
