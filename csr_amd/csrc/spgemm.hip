@@ -6,8 +6,8 @@
 // The reference is a two-pass row-by-row algorithm with a dense marker/work row.  The GPU
 // version keeps the two passes (symbolic count -> exclusive scan -> numeric fill) but gives
 // every output row its own accumulator so rows run in parallel, by product count (sum over A_i of |B_j|):
-//   * <= 128 products: one WAVEFRONT per row (four rows per workgroup), private 64- or 256-slot hash
-//     table in LDS, rank sort;
+//   * <= 128 products: a quarter or half WAVEFRONT per row (16 lanes up to 32 products, 32 lanes up to 128), a private
+//     64- or 256-slot hash table in LDS, rank sort;
 //   * more than 1024 products, at least 4 per (A entry, 832-column strip) on average, B's rows ascending
 //     (every A B^T block of a ratings matrix): COLUMN STRIPS -- one wavefront per (row, strip), the
 //     strip's sums in 6.5 KiB of LDS, sub-range bounds of every (A entry, strip) found once -- see
@@ -140,7 +140,7 @@ __device__ __forceinline__ void sg_walk_products(const MatView &a, const MatView
 constexpr int SG_THREADS = 256;
 constexpr int SG_SLOTS = 2048;
 constexpr int SG_CAP = 1024;      // max products for the LDS hash path (load factor <= 0.5)
-constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take the wave-per-row kernels
+constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take the sub-wavefront kernels (sg_quad_kernel)
 
 // products per output row: ub[i] = sum_{j in A_i} |B_j|.  (A thread per row spent 1.9 ms on 2000 rows of a MovieLens-shaped A,
 // whose rows have up to 7000 entries.)  Eight lanes per row (most rows of a sparse product have a handful of entries: a wavefront per row took 159 us for 10^6
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
     __shared__ int32_t s_n;
     const int i = blockIdx.x, tid = threadIdx.x;
     const int64_t u = ub[i];
-    if (u > SG_CAP || u <= SG_WAVE_CAP || route[i] != 0) return;   // heavy-row paths / wave-per-row path / expand-sort-compress
+    if (u > SG_CAP || u <= SG_WAVE_CAP || route[i] != 0) return;   // heavy-row paths / sub-wavefront kernels / expand-sort-compress
     for (int s = tid; s < SG_SLOTS; s += SG_THREADS) {
         s_key[s] = -1;
         if (NUMERIC) s_val[s] = 0.0;
@@ -295,88 +295,103 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
     }
 }
 
-// One WAVEFRONT per output row for rows with lo < ub <= hi products (hi <= SLOTS / 2): a 256-thread
-// workgroup serves four rows, each with a private SLOTS-entry hash table in LDS.  A workgroup-per-row
-// launch with a 2048-slot table costs ~20 us of fixed work (clear, compact, sort) however few products
-// the row has; most rows of a sparse product have a handful.
-template <int SLOTS, bool NUMERIC, bool FAST>
-__global__ __launch_bounds__(256) void sg_wave_kernel(MatView a, MatView b, const int64_t *__restrict__ ub,
-                                                     const unsigned char *__restrict__ route, int lo, int hi,
-                                                     int32_t *__restrict__ cnt, const int32_t *__restrict__ c_rp,
-                                                     int32_t *__restrict__ c_ci, double *__restrict__ c_vs,
-                                                     const int64_t *__restrict__ t_off)
+// Rows with at most SG_WAVE_CAP products (most rows of a sparse product): a FRACTION of a wavefront per row -- 16 lanes for
+// rows of at most 32 products (four rows per wavefront, sixteen per workgroup), 32 lanes up to 128 products.  A whole
+// wavefront per row spent ~400 instructions on a row with a handful of its 64 lanes busy (10^6 rows: 0.95 ms in the two
+// kernels); here the rows of a wavefront share one instruction stream.  Same table (SLOTS = 2 CAP per row, keys by
+// atomicCAS, values by LDS float64 add) and the same order: a row's lanes take A's entries one at a time, ascending, and
+// the (distinct) columns of one B_j LANES at a time; a wavefront's LDS operations complete in program order, and no
+// two rows share a table, so there is no barrier at all.
+template <int SGQ_LANES, int SGQ_CAP, bool NUMERIC, bool FAST>
+__global__ __launch_bounds__(256) void sg_quad_kernel(MatView a, MatView b, const int64_t *__restrict__ ub, int64_t lo,
+                                                     const unsigned char *__restrict__ route, int32_t *__restrict__ cnt,
+                                                     const int32_t *__restrict__ c_rp, int32_t *__restrict__ c_ci,
+                                                     double *__restrict__ c_vs, const int64_t *__restrict__ t_off)
 {
-    // NUMERIC with t_off: ONE pass -- the row's entries go to a temporary at t_off[i] (room for its product count) and
-    // its length to cnt[i]; sg_small_copy moves them once the row pointers exist (a symbolic pass of their own cost these
-    // rows 0.6 of a power-law product's 3.5 ms).
-    constexpr int WPB = 256 / WAVE;
-    __shared__ int32_t s_key[WPB][SLOTS];
-    __shared__ double s_val[NUMERIC ? WPB : 1][NUMERIC ? SLOTS : 1];
-    __shared__ int32_t s_ck[NUMERIC ? WPB : 1][NUMERIC ? SLOTS / 2 : 1];
-    __shared__ double s_cv[NUMERIC ? WPB : 1][NUMERIC ? SLOTS / 2 : 1];
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    const int64_t i = (int64_t)blockIdx.x * WPB + w;
+    constexpr int SGQ_SLOTS = 2 * SGQ_CAP, SGQ_ROWS = 256 / SGQ_LANES;
+    __shared__ int32_t s_key[SGQ_ROWS][SGQ_SLOTS];
+    __shared__ double s_val[NUMERIC ? SGQ_ROWS : 1][NUMERIC ? SGQ_SLOTS : 1];
+    __shared__ int32_t s_ck[SGQ_ROWS][SGQ_CAP];
+    __shared__ double s_cv[NUMERIC ? SGQ_ROWS : 1][NUMERIC ? SGQ_CAP : 1];
+    const int lane = threadIdx.x & (WAVE - 1), l = threadIdx.x & (SGQ_LANES - 1), r = threadIdx.x / SGQ_LANES;
+    const int grp = lane / SGQ_LANES;                       // this row's place in the wavefront
+    const int64_t i = (int64_t)blockIdx.x * SGQ_ROWS + r;
     const int64_t u = i < a.nrows ? ub[i] : 0;
-    const bool mine = u > lo && u <= hi && route[i] == 0;          // wave-uniform; every wave still reaches the barriers
-    for (int sl = lane; sl < SLOTS; sl += WAVE) {
-        s_key[w][sl] = -1;
-        if (NUMERIC) s_val[w][sl] = 0.0;
+    const bool mine = u > lo && u <= SGQ_CAP && route[i] == 0;
+    for (int sl = l; sl < SGQ_SLOTS; sl += SGQ_LANES) {
+        s_key[r][sl] = -1;
+        if (NUMERIC) s_val[r][sl] = 0.0;
     }
-    __syncthreads();
-    int found = 0;
+    int64_t jj0 = 0, ae = 0;
     if (mine) {
-        const int64_t as = rp_at<FAST>(a, i), ae = rp_at<FAST>(a, i + 1);
-        sg_walk_products<FAST, WAVE, 4, NUMERIC>(
-            a, b, as, ae, lane,
-            [&](int32_t k, double av, double bv) {
-                uint32_t slot = ((uint32_t)k * 2654435761u) & (SLOTS - 1);
-                for (;;) {
-                    int32_t old = atomicCAS(&s_key[w][slot], -1, k);
-                    if (old == -1 || old == k) {
-                        if (NUMERIC) atomicAdd(&s_val[w][slot], __dmul_rn(av, bv));
-                        else if (old == -1) found++;
-                        break;
+        jj0 = rp_at<FAST>(a, i);
+        ae = rp_at<FAST>(a, i + 1);
+    }
+    const int64_t last = b.nnz - 1;
+    while (__any(jj0 < ae)) {                               // uniform: A's entries, LANES of every row at a time
+        // lane l fetches (a_ij, extent of B_j) of entry jj0 + l: two round trips per LANES entries instead of per entry
+        const bool have = jj0 + l < ae;
+        const int64_t jm = have ? jj0 + l : 0;
+        const int32_t j_m = a.ci[jm];
+        const double av_m = NUMERIC ? val_at<FAST>(a, jm) : 0.0;
+        const int64_t bs_m = have ? rp_at<FAST>(b, j_m) : 0;
+        const int64_t be_m = have ? rp_at<FAST>(b, j_m + 1) : 0;
+        const int nb = jj0 < ae ? (int)(ae - jj0 < SGQ_LANES ? ae - jj0 : SGQ_LANES) : 0;
+        for (int st = 0; __any(st < nb); st++) {            // uniform: one A entry of every row per step
+            const int64_t bs = __shfl(bs_m, st, SGQ_LANES);
+            const int64_t be = st < nb ? __shfl(be_m, st, SGQ_LANES) : bs;
+            const double av = NUMERIC ? __shfl(av_m, st, SGQ_LANES) : 0.0;
+            int64_t kk = bs + l;
+            while (__any(kk < be)) {                        // uniform: LANES entries of each row's B_j per pass
+                const bool in = kk < be;
+                const int64_t kc = in ? kk : last;
+                const int32_t k = b.ci[kc];
+                const double bv = NUMERIC ? val_at<FAST>(b, kc) : 0.0;
+                if (in) {
+                    uint32_t slot = ((uint32_t)k * 2654435761u) & (SGQ_SLOTS - 1);
+                    for (;;) {
+                        const int32_t old = atomicCAS(&s_key[r][slot], -1, k);
+                        if (old == -1 || old == k) {
+                            if (NUMERIC) atomicAdd(&s_val[r][slot], __dmul_rn(av, bv));
+                            break;
+                        }
+                        slot = (slot + 1) & (SGQ_SLOTS - 1);
                     }
-                    slot = (slot + 1) & (SLOTS - 1);
                 }
-            },
-            [&]() {});      // one wavefront: its LDS operations complete in order
+                kk += SGQ_LANES;
+            }
+        }
+        jj0 += SGQ_LANES;
     }
-    __syncthreads();
-    if (!NUMERIC) {
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) found += __shfl_down(found, off, WAVE);
-        if (mine && lane == 0) cnt[i] = found;
-        return;
-    }
-    // compact the occupied slots, then rank-sort by column (keys are unique)
+    // compact the occupied slots (a row's 16 bits of the wavefront's ballot), then rank-sort by column (keys are unique)
     int n = 0;
-    for (int s0 = 0; s0 < SLOTS; s0 += WAVE) {
-        const int32_t k = s_key[w][s0 + lane];
+    for (int s0 = 0; s0 < SGQ_SLOTS; s0 += SGQ_LANES) {
+        const int32_t k = s_key[r][s0 + l];
         const bool occ = mine && k != -1;
-        const unsigned long long bal = __ballot(occ);
+        const unsigned bits = (unsigned)((__ballot(occ) >> (grp * SGQ_LANES)) & (SGQ_LANES == 32 ? 0xffffffffull : 0xffffull));
         if (occ) {
-            const int o = n + __popcll(bal & ((1ull << lane) - 1ull));
-            s_ck[w][o] = k;
-            s_cv[w][o] = s_val[w][s0 + lane];
+            const int o = n + __popc(bits & ((1u << l) - 1u));
+            s_ck[r][o] = k;
+            if (NUMERIC) s_cv[r][o] = s_val[r][s0 + l];
         }
-        n += __popcll(bal);
+        n += __popc(bits);
     }
-    __syncthreads();
-    if (mine) {
-        const int64_t o0 = t_off ? t_off[i] : (int64_t)c_rp[i];
-        if (t_off && lane == 0) cnt[i] = n;
-        for (int t = lane; t < n; t += WAVE) {
-            const int32_t kt = s_ck[w][t];
-            int rank = 0;
-            for (int q = 0; q < n; q++) rank += s_ck[w][q] < kt;
-            c_ci[o0 + rank] = kt;
-            c_vs[o0 + rank] = s_cv[w][t];
-        }
+    if (!mine) return;
+    if (!NUMERIC || t_off) {
+        if (l == 0) cnt[i] = n;
+        if (!NUMERIC) return;
+    }
+    const int64_t o0 = t_off ? t_off[i] : (int64_t)c_rp[i];
+    for (int t = l; t < n; t += SGQ_LANES) {
+        const int32_t kt = s_ck[r][t];
+        int rank = 0;
+        for (int q = 0; q < n; q++) rank += s_ck[r][q] < kt;
+        c_ci[o0 + rank] = kt;
+        c_vs[o0 + rank] = s_cv[r][t];
     }
 }
 
-// room[i] = products of a row the wave-per-row kernels serve, 0 for the others (their temporaries' sizes)
+// room[i] = products of a row the sub-wavefront kernels serve, 0 for the others (their temporaries' sizes)
 __global__ void sg_small_room(const int64_t *__restrict__ ub, const unsigned char *__restrict__ route, int32_t nrows,
                               int32_t *__restrict__ room)
 {
@@ -386,7 +401,7 @@ __global__ void sg_small_room(const int64_t *__restrict__ ub, const unsigned cha
     room[i] = (u > 0 && u <= SG_WAVE_CAP && route[i] == 0) ? (int32_t)u : 0;
 }
 
-// the wave-per-row kernels' temporaries -> C: 16 lanes per row
+// the sub-wavefront kernels' temporaries -> C: 16 lanes per row
 __global__ __launch_bounds__(256) void sg_small_copy(const int32_t *__restrict__ room, int32_t nrows, const int32_t *__restrict__ cnt,
                                                      const int64_t *__restrict__ t_off, const int32_t *__restrict__ t_ci,
                                                      const double *__restrict__ t_vs, const int32_t *__restrict__ c_rp,
@@ -801,7 +816,7 @@ __global__ void sg_sorted_check(const int32_t *__restrict__ rp, const int32_t *_
     if ((int64_t)rp[lo] != k) bad[0] = 1;
 }
 
-// Where every row with products goes (route[i]; 0 = the wave-per-row kernels, <= SG_WAVE_CAP products, or the workgroup hash
+// Where every row with products goes (route[i]; 0 = the sub-wavefront kernels, <= SG_WAVE_CAP products, or the workgroup hash
 // kernel, <= SG_CAP):
 //   1 strips          more than SG_CAP products, at least SGS_MIN_PER_CELL per (A entry, strip) on average, strips usable
 //                     (counters[1]; their A entries numbered from counters[2]);
@@ -1589,7 +1604,7 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             CSRK_LAUNCH_CHECK();
         }
         // symbolic (rows with no products keep the zero count of the memset)
-        const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
+        const unsigned gq = (unsigned)ceil_div(nr, 16), gq2 = (unsigned)ceil_div(nr, 8);
         // the rows of at most SG_WAVE_CAP products: one pass into temporaries when they fit (CSRK_SPGEMM_SMALL_FUSED=0: two passes)
         {
             const char *sf_env = getenv("CSRK_SPGEMM_SMALL_FUSED");
@@ -1610,19 +1625,20 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             }
         }
         if (small_fused) {
-            sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(),
-                                                        nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(), small_off.as<int64_t>());
+            sg_quad_kernel<16, 32, true, FAST><<<gq, 256>>>(av, bv, ub.as<int64_t>(), 0, route.as<unsigned char>(), cnt.as<int32_t>(),
+                                                            nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(),
+                                                            small_off.as<int64_t>());
             CSRK_LAUNCH_CHECK();
-            sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP,
-                                                         cnt.as<int32_t>(), nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(),
-                                                         small_off.as<int64_t>());
+            sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
+                                                                      cnt.as<int32_t>(), nullptr, small_tci.as<int32_t>(),
+                                                                      small_tvs.as<double>(), small_off.as<int64_t>());
             CSRK_LAUNCH_CHECK();
         } else if (small_any) {
-            sg_wave_kernel<64, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, cnt.as<int32_t>(),
-                                                         nullptr, nullptr, nullptr, nullptr);
+            sg_quad_kernel<16, 32, false, FAST><<<gq, 256>>>(av, bv, ub.as<int64_t>(), 0, route.as<unsigned char>(), cnt.as<int32_t>(),
+                                                             nullptr, nullptr, nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
-            sg_wave_kernel<256, false, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP,
-                                                          cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr);
+            sg_quad_kernel<32, SG_WAVE_CAP, false, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
+                                                                       cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
         }
         // (with expand-sort-compress taking every row above SG_WAVE_CAP products the workgroup hash kernel has no rows)
@@ -1746,17 +1762,18 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     CSRK_TRY(new_matrix(nr, b->ncols, c_nnz, 0, CSRK_VAL_F64, &c));
     int rc = exclusive_scan_i32(cnt.as<int32_t>(), (int32_t *)c->d_rowptrs, nr, nullptr);
     if (rc == CSRK_OK && nr > 0 && c_nnz > 0) {
-        const unsigned gw = (unsigned)ceil_div(nr, 256 / WAVE);
         if (small_fused) {
             sg_small_copy<<<(unsigned)ceil_div((int64_t)nr * 16, 256), 256>>>(small_room.as<int32_t>(), nr, cnt.as<int32_t>(),
                                                                              small_off.as<int64_t>(), small_tci.as<int32_t>(),
                                                                              small_tvs.as<double>(), (const int32_t *)c->d_rowptrs,
                                                                              c->d_colinds, (double *)c->d_values);
         } else if (small_any) {
-            sg_wave_kernel<64, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 0, 32, nullptr,
-                                                        (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values, nullptr);
-            sg_wave_kernel<256, true, FAST><<<gw, 256>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), 32, SG_WAVE_CAP, nullptr,
-                                                         (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values, nullptr);
+            sg_quad_kernel<16, 32, true, FAST><<<(unsigned)ceil_div(nr, 16), 256>>>(av, bv, ub.as<int64_t>(), 0, route.as<unsigned char>(),
+                                                                                    nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds,
+                                                                                    (double *)c->d_values, nullptr);
+            sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<(unsigned)ceil_div(nr, 8), 256>>>(
+                av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(), nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds,
+                (double *)c->d_values, nullptr);
         }
         if (hash_rows)
             sg_hash_kernel<true, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), nullptr,
