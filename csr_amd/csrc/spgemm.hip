@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void sg_strip_copy(const int32_t *__restrict__
 // work row in HBM per workgroup, a barrier per A entry: 7.5 ms of a 200k x 200k product's 13.8.)
 constexpr int64_t SGE_BUDGET_PRODUCTS = 200ll << 20;     // above this the round-1 heavy-row paths are used instead
 #ifndef CSRK_SGE_MIN
-#define CSRK_SGE_MIN 128
+#define CSRK_SGE_MIN 32
 #endif
 constexpr int64_t SGE_MIN = CSRK_SGE_MIN;                // rows with more products than this (and not dense enough for strips)
 
@@ -1465,7 +1465,7 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     int grid_dense = 0;
     // strip rows (FAST operands only): their list, A-entry numbering, sub-range table, per-unit counts and occupancy words
     DevBuf list_s, ebase, emap, table, cnt_s, occ_s, counters, sorted_bad, route;
-    bool strip_fused = false, hash_rows = true, small_fused = false, small_any = true;
+    bool strip_fused = false, hash_rows = true, mid_rows = true, small_fused = false, small_any = true;
     DevBuf small_room, small_off, small_tci, small_tvs;
     DevBuf strip_off, strip_tci, strip_tvs;
     // expand-sort-compress rows: their list, the sorted product matrix (kept from the counting step to the write), run numbering
@@ -1544,6 +1544,9 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             break;
         }
         n_esc = cnts[3];
+        // (with expand-sort-compress taking every row above 32 products, the 32-lane and workgroup-hash kernels have no rows)
+        hash_rows = esc_min < 0 || esc_min > SG_WAVE_CAP;
+        mid_rows = esc_min < 0 || esc_min > 32;
         n_large = cnts[0];
         n_strip = cnts[1];
         n_strip_e = cnts[2];
@@ -1629,7 +1632,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                                                             nullptr, small_tci.as<int32_t>(), small_tvs.as<double>(),
                                                             small_off.as<int64_t>());
             CSRK_LAUNCH_CHECK();
-            sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
+            if (mid_rows)
+                sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
                                                                       cnt.as<int32_t>(), nullptr, small_tci.as<int32_t>(),
                                                                       small_tvs.as<double>(), small_off.as<int64_t>());
             CSRK_LAUNCH_CHECK();
@@ -1637,12 +1641,11 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             sg_quad_kernel<16, 32, false, FAST><<<gq, 256>>>(av, bv, ub.as<int64_t>(), 0, route.as<unsigned char>(), cnt.as<int32_t>(),
                                                              nullptr, nullptr, nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
-            sg_quad_kernel<32, SG_WAVE_CAP, false, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
+            if (mid_rows)
+                sg_quad_kernel<32, SG_WAVE_CAP, false, FAST><<<gq2, 256>>>(av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(),
                                                                        cnt.as<int32_t>(), nullptr, nullptr, nullptr, nullptr);
             CSRK_LAUNCH_CHECK();
         }
-        // (with expand-sort-compress taking every row above SG_WAVE_CAP products the workgroup hash kernel has no rows)
-        hash_rows = esc_min < 0 || esc_min > SG_WAVE_CAP;
         if (hash_rows) {
             sg_hash_kernel<false, FAST><<<(unsigned)nr, SG_THREADS>>>(av, bv, ub.as<int64_t>(), route.as<unsigned char>(), cnt.as<int32_t>(),
                                                                      nullptr, nullptr, nullptr);
@@ -1771,7 +1774,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             sg_quad_kernel<16, 32, true, FAST><<<(unsigned)ceil_div(nr, 16), 256>>>(av, bv, ub.as<int64_t>(), 0, route.as<unsigned char>(),
                                                                                     nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds,
                                                                                     (double *)c->d_values, nullptr);
-            sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<(unsigned)ceil_div(nr, 8), 256>>>(
+            if (mid_rows)
+                sg_quad_kernel<32, SG_WAVE_CAP, true, FAST><<<(unsigned)ceil_div(nr, 8), 256>>>(
                 av, bv, ub.as<int64_t>(), 32, route.as<unsigned char>(), nullptr, (const int32_t *)c->d_rowptrs, c->d_colinds,
                 (double *)c->d_values, nullptr);
         }
