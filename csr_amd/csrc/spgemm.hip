@@ -1372,7 +1372,23 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
     int32_t q = lo, q_end = t0 < n_pos ? p_rp[q + 1] : 0;
     int32_t prev = t0 > 0 && t0 <= n_pos ? p_ci[t0 - 1] : -1;
     bool start[4];
-    int32_t qx[4], kx[4];
+    int32_t qx[4], kx[4], kin[4] = {-1, -1, -1, -1};
+    double vx[4] = {0.0, 0.0, 0.0, 0.0};
+    // the thread's four positions with 16-byte loads (the arrays come from the pool: 256-byte aligned)
+    if (t0 + 3 < n_pos) {
+        const int4 k4 = *reinterpret_cast<const int4 *>(p_ci + t0);
+        kin[0] = k4.x, kin[1] = k4.y, kin[2] = k4.z, kin[3] = k4.w;
+        if (MODE == 2) {
+            const double2 va = *reinterpret_cast<const double2 *>(p_vs + t0), vb = *reinterpret_cast<const double2 *>(p_vs + t0 + 2);
+            vx[0] = va.x, vx[1] = va.y, vx[2] = vb.x, vx[3] = vb.y;
+        }
+    } else {
+        for (int x = 0; x < 4; x++)
+            if (t0 + x < n_pos) {
+                kin[x] = p_ci[t0 + x];
+                if (MODE == 2) vx[x] = p_vs[t0 + x];
+            }
+    }
     int n = 0;
 #pragma unroll
     for (int x = 0; x < 4; x++) {
@@ -1385,12 +1401,26 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
                 q++;
                 q_end = p_rp[q + 1];
             }
-            const int32_t k = p_ci[t];
+            const int32_t k = kin[x];
             start[x] = t == p_rp[q] || k != prev;
             qx[x] = q;
             kx[x] = k;
             prev = k;
             n += start[x] ? 1 : 0;
+        }
+    }
+    // (write pass: the tile's values and run-start flags go through LDS, so that a run that leaves its thread's four
+    // positions is still summed without a look at memory -- with a dependent load per such run nearly every wavefront
+    // waited two memory round trips: 0.33 ms against the counting pass's 0.07.  Only a run that leaves the TILE reads on.)
+    __shared__ unsigned char s_f[MODE == 2 ? SGE_TILE : 1];
+    __shared__ double s_v[MODE == 2 ? SGE_TILE : 1];
+    __shared__ int32_t s_ok[MODE == 2 ? SGE_TILE : 1], s_oq[MODE == 2 ? SGE_TILE : 1];
+    __shared__ double s_ov[MODE == 2 ? SGE_TILE : 1];
+    if (MODE == 2) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s_f[tid * 4 + x] = (start[x] || t0 + x >= n_pos) ? 1 : 0;      // (positions past the end close the last run)
+            s_v[tid * 4 + x] = vx[x];
         }
     }
     int64_t total;
@@ -1409,13 +1439,36 @@ __global__ __launch_bounds__(256) void sg_esc_runs(const int32_t *__restrict__ l
             g++;
             continue;
         }
-        double sum = 0.0 + p_vs[t];                   // (the reference's work[k] starts from +0.0: -0.0 products)
-        for (int32_t u = t + 1; u < e && p_ci[u] == kx[x]; u++) sum += p_vs[u];
-        const int64_t o = (int64_t)c_rp[list[qx[x]]] + (g - first_run[qx[x]]);
-        c_ci[o] = kx[x];
-        c_vs[o] = sum;
+        double sum = 0.0 + vx[x];                     // (the reference's work[k] starts from +0.0: -0.0 products)
+        int pl = tid * 4 + x + 1;
+        for (; pl < SGE_TILE && !s_f[pl]; pl++) sum += s_v[pl];
+        if (pl == SGE_TILE)                           // the run may go on in the next tile
+            for (int32_t u = blockIdx.x * SGE_TILE + SGE_TILE; u < e && p_ci[u] == kx[x]; u++) sum += p_vs[u];
+        // staged through LDS by run number, so that consecutive lanes store consecutive entries of C below
+        const int li = g - tile_off[blockIdx.x];
+        s_ok[li] = kx[x];
+        s_ov[li] = sum;
+        s_oq[li] = qx[x];
         g++;
     }
+    if (MODE == 2) {
+        __syncthreads();
+        for (int li = tid; li < (int)total; li += 256) {
+            // (first_run holds c_rp[row] - the row's first run: sg_esc_rowbase)
+            const int64_t o = (int64_t)first_run[s_oq[li]] + tile_off[blockIdx.x] + li;
+            c_ci[o] = s_ok[li];
+            c_vs[o] = s_ov[li];
+        }
+    }
+}
+
+// first_run[q] <- c_rp[row q] - first_run[q]: where run g of the sorted products goes in C is then first_run[q] + g (three
+// dependent gathers per output entry in the write pass were 0.2 of its 0.42 ms)
+__global__ void sg_esc_rowbase(const int32_t *__restrict__ list, int32_t n, const int32_t *__restrict__ c_rp,
+                               int32_t *__restrict__ first_run)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) first_run[q] = c_rp[list[q]] - first_run[q];
 }
 
 // cnt[row] = runs of the row = first_run of the next row (the total after the last) - its own
@@ -1821,6 +1874,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
         if (n_esc > 0) {
             // expand-sort-compress, second half: every run of equal columns added front to back into its place in C
             const int32_t n_pos = (int32_t)esc_products;
+            sg_esc_rowbase<<<(unsigned)ceil_div(n_esc, 256), 256>>>(list_e.as<int32_t>(), n_esc, (const int32_t *)c->d_rowptrs,
+                                                                    esc_first_run.as<int32_t>());
             ESC_RUNS(2, (const int32_t *)c->d_rowptrs, c->d_colinds, (double *)c->d_values);
         }
 #undef ESC_RUNS
