@@ -3382,6 +3382,34 @@ int spmv_tier0_view(Matrix *m, Tier0View *out)
 
 }  // namespace csrk
 
+namespace csrk {
+
+// float32 values times a float32 x: the reference's loop (csr/kernels/numba/__init__.py:55-67) is typed by Numba with a
+// float32 product -- ONE rounding -- that is then added to the float64 accumulator.  One wavefront per row, lanes take the
+// entries 64 apart, ordered tree over the lanes.  (A parity path: float32 matrices are the reference's test inputs, not the
+// headline workload; every other dtype combination multiplies in float64, which the planned kernels do.)
+template <class P>
+__global__ __launch_bounds__(256) void spmv_f32x_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                       const float *__restrict__ vs, const float *__restrict__ x, int32_t nrows,
+                                                       double *__restrict__ y)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (i >= nrows) return;
+    double acc = 0.0;
+    for (int64_t k = (int64_t)rp[i] + lane, e = (int64_t)rp[i + 1]; k < e; k += WAVE) acc += (double)__fmul_rn(x[ci[k]], vs[k]);
+    for (int off = WAVE / 2; off; off >>= 1) acc += __shfl_down(acc, off, WAVE);
+    if (lane == 0) y[i] = acc;
+}
+
+__global__ void widen_f32_kernel(const float *__restrict__ in, double *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+}  // namespace csrk
+
 using namespace csrk;
 
 extern "C" {
@@ -3432,6 +3460,39 @@ int csrk_spmv(csrk_handle_t h, const double *x, double *y)
     CSRK_TRY(dy.alloc((size_t)m->nrows * 8));
     if (m->ncols) CSRK_HIP(hipMemcpy(dx.p, x, (size_t)m->ncols * 8, hipMemcpyHostToDevice));
     CSRK_TRY(spmv_dispatch(m, dx.as<double>(), dy.as<double>(), nullptr));
+    CSRK_HIP(hipMemcpy(y, dy.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost));
+    return CSRK_OK;
+}
+
+int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE((x || m->ncols == 0) && (y || m->nrows == 0), "x or y is NULL");
+    if (m->nrows == 0) return CSRK_OK;
+    DevBuf dx32, dx, dy;
+    CSRK_TRY(dx32.alloc((size_t)m->ncols * 4 + 4));
+    CSRK_TRY(dy.alloc((size_t)m->nrows * 8));
+    if (m->ncols) CSRK_HIP(hipMemcpy(dx32.p, x, (size_t)m->ncols * 4, hipMemcpyHostToDevice));
+    if (m->val_type == CSRK_VAL_F32) {
+        // float32 x float32: the product is rounded to float32 (the reference's arithmetic), outside the planned kernels
+        const unsigned g = (unsigned)ceil_div((int64_t)m->nrows * WAVE, 256);
+        if (m->ptr64)
+            spmv_f32x_kernel<int64_t><<<g, 256>>>((const int64_t *)m->d_rowptrs, m->d_colinds, (const float *)m->d_values,
+                                                  dx32.as<float>(), m->nrows, dy.as<double>());
+        else
+            spmv_f32x_kernel<int32_t><<<g, 256>>>((const int32_t *)m->d_rowptrs, m->d_colinds, (const float *)m->d_values,
+                                                  dx32.as<float>(), m->nrows, dy.as<double>());
+        CSRK_LAUNCH_CHECK();
+    } else {
+        // float64 (or absent) values: Numba widens x, the product is float64 -- the usual kernels on the widened vector
+        CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
+        if (m->ncols) {
+            widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256>>>(dx32.as<float>(), dx.as<double>(), m->ncols);
+            CSRK_LAUNCH_CHECK();
+        }
+        CSRK_TRY(spmv_dispatch(m, dx.as<double>(), dy.as<double>(), nullptr));
+    }
     CSRK_HIP(hipMemcpy(y, dy.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost));
     return CSRK_OK;
 }

@@ -290,12 +290,20 @@ def order_columns(h):
 def mult_vec(h, v):
     """
     csr/kernels/numba/__init__.py:55-67: y = A v as a fresh float64[nrows].
-    v may be any real dtype of shape (ncols,); it is widened to float64 (exact for f4).
+    v may be any real dtype of shape (ncols,).  A float32 v goes to the library as float32: Numba types the reference's
+    loop by its operands, so float32 values times a float32 v is a float32 product (one rounding) added to the float64
+    accumulator (csrk_spmv_f32x does the same; with float64 or absent values it widens v).  Everything else is widened to
+    float64 here (exact).
     """
-    x = np.ascontiguousarray(v, dtype=np.float64)
-    if x.shape != (h.ncols,):
-        raise ValueError(f'vector has shape {x.shape}, expected ({h.ncols},)')
+    v = np.asarray(v)
+    if v.shape != (h.ncols,):
+        raise ValueError(f'vector has shape {v.shape}, expected ({h.ncols},)')
     y = np.empty(h.nrows, dtype=np.float64)
+    if v.dtype == np.float32:
+        x = np.ascontiguousarray(v)
+        check(lib.csrk_spmv_f32x(_live(h), ptr(x), ptr(y)))
+        return y
+    x = np.ascontiguousarray(v, dtype=np.float64)
     check(lib.csrk_spmv(_live(h), ptr(x), ptr(y)))
     return y
 

@@ -111,6 +111,10 @@ CSRK_API int csrk_device_ptrs(csrk_handle_t h, void **d_rowptrs, void **d_colind
  * entries, y receives nrows float64 entries (every entry is written; empty rows get 0).
  * Structure-only matrices multiply with implicit 1.0 (csr/csr.py:254-262).            */
 CSRK_API int csrk_spmv(csrk_handle_t h, const double *x, double *y);
+/* The same with x given as float32 (host pointers).  Numba types the reference's loop by its operands
+ * (csr/kernels/numba/__init__.py:55-67): float32 values times float32 x is a float32 product -- one rounding -- added to the
+ * float64 accumulator; with float64 or absent values x is widened and the product is float64 (= csrk_spmv). */
+CSRK_API int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y);
 CSRK_API int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stream);
 /* The same product in two parts, for callers that ship y elsewhere while it is being completed (csr_amd/dist.py:
  * the row-partitioned multi-GPU form of csr/csr.py:584-590, where a rank's slice travels to its peers):

@@ -90,12 +90,9 @@ def test_spmv_golden(golden, algo):
         m = Mat(g, f'c{c}_')
         x = g[f'c{c}_x']
         y = _mult_vec(m, x, algo)
-        f4f4 = m.values is not None and m.values.dtype == np.float32 and x.dtype == np.float32
-        bound = _abs_bound(m, x)
-        if f4f4:   # the reference rounds f4*f4 products to f4; the kernel multiplies in f8
-            assert np.all(np.abs(y - g[f'c{c}_y']) <= 1e-6 * bound + 1e-300)
-        else:
-            _check(y, g[f'c{c}_y'], bound)
+        # (float32 values times a float32 x: the reference's products are float32 -- csrk_spmv_f32x rounds them the same
+        # way, so this case meets the same bar as the others)
+        _check(y, g[f'c{c}_y'], _abs_bound(m, x))
 
 
 @pytest.mark.parametrize('algo', ALGOS)
