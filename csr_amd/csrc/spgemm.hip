@@ -67,6 +67,15 @@ __device__ __forceinline__ double val_at(const MatView &m, int64_t k)
     return m.vt == CSRK_VAL_F64 ? ((const double *)m.vs)[k] : (double)((const float *)m.vs)[k];
 }
 
+// one product a_ij * b_jk as the reference takes it (multiply.py:120, typed by Numba / NumPy by its operands): float32 times
+// float32 is a float32 product -- one rounding -- before it is added to the float64 work array; everything else float64
+template <bool FAST>
+__device__ __forceinline__ double sg_mul(const MatView &a, const MatView &b, double av, double bv)
+{
+    if (!FAST && a.vt == CSRK_VAL_F32 && b.vt == CSRK_VAL_F32) return (double)__fmul_rn((float)av, (float)bv);
+    return __dmul_rn(av, bv);
+}
+
 static MatView view_of(const Matrix *m)
 {
     return MatView{m->d_rowptrs, m->d_colinds, m->d_values, m->ptr64, m->val_type, m->nrows, m->ncols, m->nnz};
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_hash_kernel(MatView a, MatView 
                 int32_t old = atomicCAS(&s_key[slot], -1, k);
                 if (old == -1 || old == k) {
                     if (NUMERIC)
-                        atomicAdd(&s_val[slot], __dmul_rn(av, bv));
+                        atomicAdd(&s_val[slot], sg_mul<FAST>(a, b, av, bv));
                     else if (old == -1)
                         atomicAdd(&s_n, 1);
                     break;
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void sg_quad_kernel(MatView a, MatView b, cons
                     for (;;) {
                         const int32_t old = atomicCAS(&s_key[r][slot], -1, k);
                         if (old == -1 || old == k) {
-                            if (NUMERIC) atomicAdd(&s_val[r][slot], __dmul_rn(av, bv));
+                            if (NUMERIC) atomicAdd(&s_val[r][slot], sg_mul<FAST>(a, b, av, bv));
                             break;
                         }
                         slot = (slot + 1) & (SGQ_SLOTS - 1);
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_dense_kernel(MatView a, MatView
         sg_walk_products<FAST, SG_THREADS, 4, NUMERIC>(
             a, b, as, ae, tid,
             [&](int32_t k, double av, double bv) {
-                if (NUMERIC) atomicAdd(&work[k], __dmul_rn(av, bv));
+                if (NUMERIC) atomicAdd(&work[k], sg_mul<FAST>(a, b, av, bv));
                 if (NUMERIC && sweep) {
                     mark[k] = 1;                       // the sweep only needs the marker
                 } else if (atomicExch(&mark[k], 1) == 0) {
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_lds_numeric_kernel(MatView a, 
                 a, b, as, ae, tid,
                 [&](int32_t k, double av, double bv) {
                     if (k >= t0 && k < t1) {
-                        atomicAdd(&s_work[k - t0], __dmul_rn(av, bv));
+                        atomicAdd(&s_work[k - t0], sg_mul<FAST>(a, b, av, bv));
                         atomicOr(&s_bits[(k - t0) >> 5], 1u << ((k - t0) & 31));
                     }
                 },
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(SGL_THREADS) void sg_hash_big_kernel(MatView a, Mat
                 for (;;) {
                     const int32_t old = atomicCAS(&s_key[slot], -1, k);
                     if (old == -1 || old == k) {
-                        atomicAdd(&s_val[slot], __dmul_rn(av, bv));
+                        atomicAdd(&s_val[slot], sg_mul<FAST>(a, b, av, bv));
                         break;
                     }
                     slot = (slot + 1) & (SGB_SLOTS - 1);
@@ -1327,7 +1336,7 @@ __global__ __launch_bounds__(256) void sg_esc_expand(MatView a, MatView b, const
             }
             const int64_t kk = s_bs[lo] + (p - s_off[lo]);
             p_ci[out + p] = b.ci[kk];
-            p_vs[out + p] = __dmul_rn(s_av[lo], val_at<FAST>(b, kk));
+            p_vs[out + p] = sg_mul<FAST>(a, b, s_av[lo], val_at<FAST>(b, kk));
         }
         out += total;
         __syncthreads();

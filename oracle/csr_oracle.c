@@ -182,8 +182,10 @@ ORC_EXPORT int orc_num_mm(int32_t a_nrows, int32_t a_ncols,
                           const int64_t *a_rp, const int32_t *a_ci, const double *a_vs,
                           int32_t b_ncols,
                           const int64_t *b_rp, const int32_t *b_ci, const double *b_vs,
-                          const int32_t *c_rp, const int32_t *c_ci, double *c_vs)
+                          const int32_t *c_rp, const int32_t *c_ci, double *c_vs, int round32)
 {
+    /* round32: both operands' values are float32 (widened exactly by the caller): `av * b_h.values[kk]`
+     * (multiply.py:120) is then a float32 product -- one rounding -- added to the float64 work array */
     int64_t wlen = a_nrows;
     if (a_ncols > wlen) wlen = a_ncols;
     if (b_ncols > wlen) wlen = b_ncols;
@@ -194,7 +196,7 @@ ORC_EXPORT int orc_num_mm(int32_t a_nrows, int32_t a_ncols,
             int32_t j = a_ci[jj];
             double av = a_vs[jj];
             for (int64_t kk = b_rp[j]; kk < b_rp[j + 1]; kk++)
-                work[b_ci[kk]] += av * b_vs[kk];
+                work[b_ci[kk]] += round32 ? (double)((float)av * (float)b_vs[kk]) : av * b_vs[kk];
         }
         for (int32_t jj = c_rp[i]; jj < c_rp[i + 1]; jj++) {
             int32_t j = c_ci[jj];
@@ -210,7 +212,7 @@ ORC_EXPORT int64_t orc_mult_ab(int32_t a_nrows, int32_t a_ncols, int64_t a_nnz,
                                const int64_t *a_rp, const int32_t *a_ci, const double *a_vs,
                                int32_t b_ncols, int64_t b_nnz,
                                const int64_t *b_rp, const int32_t *b_ci, const double *b_vs,
-                               int32_t *c_rp, int32_t **c_ci_out, double **c_vs_out)
+                               int32_t *c_rp, int32_t **c_ci_out, double **c_vs_out, int round32)
 {
     int32_t *c_ci = NULL;
     int64_t c_nnz = orc_sym_mm(a_nrows, a_ncols, a_nnz, a_rp, a_ci, b_ncols, b_nnz, b_rp, b_ci,
@@ -219,7 +221,7 @@ ORC_EXPORT int64_t orc_mult_ab(int32_t a_nrows, int32_t a_ncols, int64_t a_nnz,
     double *c_vs = (double *)calloc((size_t)(c_nnz > 0 ? c_nnz : 1), sizeof(double));
     if (!c_vs) { free(c_ci); return -1; }
     if (orc_num_mm(a_nrows, a_ncols, a_rp, a_ci, a_vs, b_ncols, b_rp, b_ci, b_vs,
-                   c_rp, c_ci, c_vs) != 0) {
+                   c_rp, c_ci, c_vs, round32) != 0) {
         free(c_ci); free(c_vs); return -1;
     }
     *c_ci_out = c_ci;

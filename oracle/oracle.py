@@ -119,6 +119,8 @@ def mult_ab(a, b):
     assert anc == bnr
     arp, brp = _rp64(arp), _rp64(brp)
     aci, bci = _ci(aci), _ci(bci)
+    # float32 times float32 is a float32 product in the reference (multiply.py:120): the C loop rounds it that way
+    round32 = int(np.asarray(avs).dtype == np.float32 and np.asarray(bvs).dtype == np.float32)
     avs = np.ascontiguousarray(avs, dtype=np.float64)
     bvs = np.ascontiguousarray(bvs, dtype=np.float64)
     c_rp = np.zeros(anr + 1, dtype=np.int32)
@@ -129,7 +131,7 @@ def mult_ab(a, b):
                       _p(arp, _i64p), _p(aci, _i32p), _p(avs, _f64p),
                       C.c_int32(bnc), C.c_int64(int(brp[bnr])),
                       _p(brp, _i64p), _p(bci, _i32p), _p(bvs, _f64p),
-                      _p(c_rp, _i32p), C.byref(ci_out), C.byref(vs_out))
+                      _p(c_rp, _i32p), C.byref(ci_out), C.byref(vs_out), C.c_int(round32))
     if n < 0:
         raise MemoryError('oracle mult_ab')
     c_ci = np.ctypeslib.as_array(ci_out, shape=(max(n, 1),))[:n].copy()

@@ -232,6 +232,9 @@ def test_spgemm_golden(golden):
         rci, rvs = sort_within_rows(raw.rowptrs, raw.colinds, raw.values)
         assert np.array_equal(C.colinds, rci), c
         assert np.all(np.abs(C.values - rvs) <= bound[np.repeat(np.arange(C.nrows), np.diff(C.rowptrs)), C.colinds]), c
+        if _rows_hold_no_column_twice(B):
+            # the reference's order of addition AND its product precision (f4 * f4 rounded to f4, multiply.py:120): the same bits
+            assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64)), c
         # CSR.multiply: filtered product (csr/csr.py:555), tests/test_multiply.py:14-44
         P = _csr(A).multiply(_csr(B))
         ab = Mat(g, f'c{c}_ab_')

@@ -144,23 +144,14 @@ def test_spgemm_golden(golden):
         assert np.array_equal(cci, raw.colinds)            # reference column order reproduced
         srp, sci = O.sym_mm(A.tup(), B.tup())
         assert np.array_equal(srp, raw.rowptrs) and np.array_equal(sci, raw.colinds)
-        # f4 inputs: the reference rounds each product to f4 (NumPy promotion) before the f8
-        # accumulate; the oracle multiplies in f8.  Bound: 1e-6 * sum |a||b| per entry.
-        bound = 1e-6 * (np.abs(A.dense()) @ np.abs(B.dense()))
-        if f8:
-            assert np.array_equal(cvs, raw.values)         # same accumulation order: bit-identical
-        else:
-            diff = np.abs(_dense_of(nr, nc, crp, cci, cvs) - raw.dense())
-            assert np.all(diff <= bound)
+        # same accumulation order and the same product precision (f4 * f4 rounded to f4, multiply.py:120): bit-identical
+        assert np.array_equal(cvs, raw.values)
         # CSR.multiply = mult_ab + _filter_zeros (csr/csr.py:555)
         ab = Mat(g, f'c{c}_ab_')
         frp, fci, fvs = O.filter_zeros(nr, crp, cci, cvs)
         assert np.all(fvs != 0)
-        if f8:
-            assert np.array_equal(frp, ab.rowptrs) and np.array_equal(fci, ab.colinds)
-            assert np.array_equal(fvs, ab.values)
-        else:
-            assert np.all(np.abs(_dense_of(nr, nc, frp, fci, fvs) - ab.dense()) <= bound)
+        assert np.array_equal(frp, ab.rowptrs) and np.array_equal(fci, ab.colinds)
+        assert np.array_equal(fvs, ab.values)
         # mult_abt = mult_ab(A, transpose(Bt)) (multiply.py:41-57)
         Bt = Mat(g, f'c{c}_bt_')
         abt = Mat(g, f'c{c}_abt_')
