@@ -511,3 +511,28 @@ def test_handle_cache_reaches_the_plan():
     K.invalidate(A)
     check(A.mult_vec(x))
     K.flush_handle_cache()
+
+
+@pytest.mark.parametrize('vals', ['f4', 'f8', 'none'])
+def test_spmv_float32_vector(vals):
+    """
+    A float32 x (csr/kernels/numba/__init__.py:55-67 as Numba types it): with float32 values every product is a float32
+    -- one rounding -- added to the float64 accumulator; with float64 or absent values x is widened.  csrk_spmv_f32x
+    against the oracle's restatement of each case (orc_mult_vec_f32f32 / the float64 loops), rows up to 5000 entries,
+    int64 row pointers in the float32 case.
+    """
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, 40, 3000)
+    lens[::97] = 5000
+    m = _random_csr(rng, 3000, 20000, lens, dtype=np.float32 if vals == 'f4' else np.float64, ptr64=vals == 'f4')
+    if vals == 'none':
+        m.values = None
+    x = rng.uniform(-1, 1, size=m.ncols).astype(np.float32)
+    y = _mult_vec(m, x, 'merge')
+    ref = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x)
+    _check(y, ref, _abs_bound(m, x))
+    if vals == 'f4':
+        # and it is NOT the float64 product: the two differ by ~1e-8 of the terms
+        ref64 = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x.astype(np.float64))
+        assert np.max(np.abs(ref64 - ref)) > 1e-10
