@@ -1695,9 +1695,10 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                 int64_t total = 0;
                 CSRK_HIP(hipMemcpy(&total, small_off.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost));
                 small_fused = total > 0 && total * 12 <= SGS_TEMP_BUDGET / 4;
-                if (small_fused) {
-                    CSRK_TRY(small_tci.alloc((size_t)total * 4));
-                    CSRK_TRY(small_tvs.alloc((size_t)total * 8));
+                if (small_fused && (small_tci.alloc((size_t)total * 4) != CSRK_OK || small_tvs.alloc((size_t)total * 8) != CSRK_OK)) {
+                    small_tci.release();             // no room for the temporary: two passes
+                    small_tvs.release();
+                    small_fused = false;
                 }
                 small_any = total > 0;
             }
@@ -1774,9 +1775,11 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                     int64_t total_cap = 0;
                     CSRK_HIP(hipMemcpy(&total_cap, strip_off.as<int64_t>() + n_units, 8, hipMemcpyDeviceToHost));
                     strip_fused = total_cap * 12 <= SGS_TEMP_BUDGET;
-                    if (strip_fused) {
-                        CSRK_TRY(strip_tci.alloc((size_t)(total_cap + 1) * 4));
-                        CSRK_TRY(strip_tvs.alloc((size_t)(total_cap + 1) * 8));
+                    if (strip_fused &&
+                        (strip_tci.alloc((size_t)(total_cap + 1) * 4) != CSRK_OK || strip_tvs.alloc((size_t)(total_cap + 1) * 8) != CSRK_OK)) {
+                        strip_tci.release();         // no room for the temporary on this device now: two passes
+                        strip_tvs.release();
+                        strip_fused = false;
                     }
                 }
                 if (strip_fused) {
