@@ -87,6 +87,13 @@ struct Panel {
     DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y;
 };
 
+// one segment of an accumulator-form workgroup's tile range (see "long rows, accumulator form")
+struct AccSeg {
+    int64_t tile0;    // first tile of the segment
+    int32_t ntiles;   // <= ACC_SEG_TILES, all in one column block
+    int32_t blk;
+};
+
 // Tier 0 in accumulator form: one group of <= ACC_MAXROWS heavy rows (see "long rows, accumulator form")
 struct AccPanel {
     int32_t nrow = 0, nb = 0, n_wg = 0;
@@ -112,6 +119,11 @@ struct LightStream {
     // tile-major staging (build_cold_stage, default): the staged values of tile t are xg[tile_cold[t] .. tile_cold[t + 1]),
     // and a cold entry's index word holds its offset inside that range; empty: positions are absolute (round-major form)
     DevBuf tile_cold;
+    // round-in-LDS staging (build_cold_stage, LS_RND): a workgroup takes `stage_tiles` consecutive tiles per round, copies
+    // the round's staged values xg[round_start[r] .. round_start[r + 1]) into LDS, and a cold entry's index word holds its
+    // offset inside that range
+    int32_t stage_tiles = 0;
+    DevBuf round_start;
 };
 
 struct SpmvPlan {
@@ -151,6 +163,10 @@ struct SpmvPlan {
                         // 262144-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
     LightStream ls;                       // the rows that stay on the row-major path
     LightStream t1s;                      // tier 1 as a stream of (column block, row) runs
+    LightStream t1h;                      // tier 1's entries on the LDS-resident packed columns: a hot-window stream (16-bit index words)
+    std::vector<int32_t> t1_rows;         // tier-1 rows (ascending) and their entries: build_tiers
+    int64_t t1_nnz = 0, t1h_nnz = 0;      // (t1h_nnz: of which in the hot-window stream)
+    int32_t t1h_cap = 0;                  // slots below this are the hot-window stream's
     std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
     std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths: source of either form
     std::vector<int64_t> t0_lens;
@@ -725,10 +741,18 @@ constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block
 #define PANEL_T1 256
 #endif
 
+// slot_map / hot_cap (optional): entries on the packed columns of slot < hot_cap are left out of the panel (they are
+// served by the hot-window stream, build_tier1_hot)
+__device__ __forceinline__ bool panel_keeps(const int32_t *__restrict__ slot_map, int32_t hot_cap, int32_t col)
+{
+    return !slot_map || (uint32_t)slot_map[col] >= (uint32_t)hot_cap;      // (unpacked columns map to -1)
+}
+
 template <class P>
 __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int32_t cb, int64_t *__restrict__ cnt)
+                                   int32_t cb, int64_t *__restrict__ cnt, const int32_t *__restrict__ slot_map,
+                                   int32_t hot_cap)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -737,14 +761,20 @@ __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__re
     const int64_t s = rp[r], e = rp[r + 1];
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
     const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * cb);
-    cnt[i] = hi - lo;
+    int64_t n = hi - lo;
+    if (slot_map) {
+        n = 0;
+        for (int64_t k = lo; k < hi; k++) n += panel_keeps(slot_map, hot_cap, ci[k]) ? 1 : 0;
+    }
+    cnt[i] = n;
 }
 
 template <class P, int VT, class PP>
 __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
                                   int32_t cb, const int64_t *__restrict__ off, PP *__restrict__ prp,
-                                  int32_t *__restrict__ pci, double *__restrict__ pvs)
+                                  int32_t *__restrict__ pci, double *__restrict__ pvs,
+                                  const int32_t *__restrict__ slot_map, int32_t hot_cap)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pairs = (int64_t)n_heavy * n_blocks;
@@ -757,9 +787,13 @@ __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__res
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
     const int64_t n = off[i + 1] - off[i];
     int64_t o = off[i];
-    for (int64_t k = lo; k < lo + n; k++, o++) {
-        pci[o] = ci[k];
+    const int64_t o_end = o + n;
+    for (int64_t k = lo; o < o_end; k++) {
+        const int32_t col = ci[k];
+        if (!panel_keeps(slot_map, hot_cap, col)) continue;
+        pci[o] = col;
         pvs[o] = ValLoad<VT>::at(vs, k);
+        o++;
     }
 }
 
@@ -1034,12 +1068,6 @@ constexpr uint32_t ACC_COL_MASK = (1u << ACC_ROW_SHIFT) - 1;
 constexpr int ACC_MAXSTEP = 7;
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-struct AccSeg {
-    int64_t tile0;    // first tile of the segment
-    int32_t ntiles;   // <= ACC_SEG_TILES, all in one column block
-    int32_t blk;
-};
 
 // physical slot of logical entry e (0..511) of a tile: lane = e / 8, j = e % 8
 __host__ __device__ __forceinline__ int acc_val_slot(int e)
@@ -1435,6 +1463,13 @@ constexpr int LS_THREADS = CSRK_LS_THREADS;
 #define CSRK_LS_HOT_LDS 15360
 #endif
 constexpr int LS_HOT_LDS = CSRK_LS_HOT_LDS;
+// round-in-LDS form of the stream kernel (LS_RND): LDS = LS_RND_HOT hot slots + the LS_RND_CAP staged values of the
+// workgroup's current round + the run-sum buffers
+#ifndef CSRK_LS_RND_CAP
+#define CSRK_LS_RND_CAP 8192
+#endif
+constexpr int LS_RND_CAP = CSRK_LS_RND_CAP, LS_RND_MAXTILES = 64;
+constexpr int LS_RND_HOT = (160 * 1024 - (CSRK_LS_THREADS / 64) * (512 + 2) * 8) / 8 - LS_RND_CAP;      // 8176 with the defaults
 constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile
 #ifndef CSRK_LS_SEQ
 #define CSRK_LS_SEQ 3
@@ -1442,6 +1477,7 @@ constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead
 constexpr int LS_SEQ = CSRK_LS_SEQ;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
 constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
 constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
+constexpr uint32_t LS16_PAD = 0x7fffu, LS16_START = 0x8000u;      // 16-bit index words of the hot-window stream (build_tier1_hot)
 
 // smallest r in [0, nrows) with rpv[r + 1] > L (the row holding view entry L); L < rpv[nrows]
 template <class P>
@@ -1563,33 +1599,62 @@ __device__ unsigned long long g_ls_stamps[4096 * LS_NSTAMP];
 // instead of one per value (a gather lane that misses L1 costs its CU ~4 clocks of line fill wherever the line comes
 // from).  The buffer is the run-sum staging buffer s_out: the gathers of a tile are over before
 // its run sums are written, and a wavefront's LDS operations complete in order.
-template <bool XGT>
+// MODE: LS_PLAIN; LS_XGT (above); LS_H16 = hot-window stream (build_tier1_hot): 16-bit index words, every x value in LDS;
+// LS_RND = round-in-LDS staging: the workgroup walks ROUNDS of `stage_tiles` consecutive tiles (wavefront w takes tiles
+// w, w + 8, ... of the round); `x` is xg and tile_cold[r] the start of round r's staged values in it, which the workgroup
+// copies into LDS with coalesced loads (requested one round ahead, into registers) -- a cold entry's index word holds its
+// offset there.  The copy pass can then use rounds of 64 tiles (its store transactions are per (round, column block)
+// bucket: 0.049 ms against 0.065 at 8 tiles) without the stream side paying for it in L1 lines (0.257 ms at 64 tiles when
+// the round's range is read by gathers).  Two workgroup barriers per round.
+constexpr int LS_PLAIN = 0, LS_XGT = 1, LS_H16 = 2, LS_RND = 3;
+template <int MODE>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
     const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
     double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
-    const int32_t *__restrict__ tile_cold)
+    const int32_t *__restrict__ tile_cold, int32_t stage_tiles)
 {
     // No FMA contraction in this kernel: the reference rounds every product before adding it.  (HIP's rounding
     // intrinsics for multiply and add are plain * and + inside inline functions compiled with
     // -ffp-contract=fast and fuse after inlining -- measured: 2041 instead of 75 rows of BASELINE configs[0]
     // differed in the last bits; the pragma governs the operators written in this body.)
 #pragma clang fp contract(off)
+    constexpr bool XGT = MODE == LS_XGT, H16 = MODE == LS_H16, RND = MODE == LS_RND;
+    constexpr int NIX = H16 ? 1 : 2;      // 16-B index loads per lane and tile
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // wave-uniform: tile numbers and bases stay scalar
-    double *s_out = s_hot + LS_HOT_LDS + wv * (ACC_TILE + 2);
+    double *s_rnd = s_hot + LS_RND_HOT;                    // RND: the round's staged values
+    double *s_out = s_hot + (RND ? LS_RND_HOT + LS_RND_CAP : LS_HOT_LDS) + wv * (ACC_TILE + 2);
     for (int i = threadIdx.x; i < n_lds; i += LS_THREADS) s_hot[i] = xh[i];
     __syncthreads();
 
-    const int64_t wave0 = (int64_t)blockIdx.x * (LS_THREADS / WAVE) + wv;
-    const int64_t n_waves = (int64_t)gridDim.x * (LS_THREADS / WAVE);
+    // A workgroup walks rounds R = blockIdx, blockIdx + grid, ...; wavefront w takes tiles R * nt_round + w + k * NW,
+    // k < KB.  Without RND a round is one tile per wavefront (KB = 1): tile = wavefront number + multiples of the grid's
+    // wavefront count.
+    constexpr int NW = LS_THREADS / WAVE;
+    const int nt_round = RND ? stage_tiles : NW;
+    const int KB = RND ? stage_tiles / NW : 1;
+    const int64_t n_rounds = (n_tiles + nt_round - 1) / nt_round;
+    const int64_t wave0 = (int64_t)blockIdx.x * nt_round + wv;
     f64x2_t v[4], vn[4];
     u32x4_t ix[2], ixn[2];
     int32_t tb = 0, tbn = 0;
     int32_t cb = 0, cn = 0, cbn = 0, cnn = 0;      // XGT: this tile's range of xg (start, length), and the next tile's
+    constexpr int RQ = LS_RND_CAP / 2 / LS_THREADS;      // RND: 16-B loads per thread that cover a round's staged values
+    f64x2_t rv[RND ? RQ : 1];
+    auto round_request = [&](int64_t R_) {      // the staged values of round R_ -> registers (pairs past its count re-read its first)
+        const int32_t r0 = tile_cold[R_];
+        const int32_t rn = tile_cold[R_ + 1] - r0;
+#pragma unroll
+        for (int q = 0; q < RQ; q++) {
+            const int k = 2 * (q * LS_THREADS + (int)threadIdx.x);
+            rv[q] = *(const F64x2 *)(x + r0 + (k < rn ? k : 0));
+        }
+    };
+    if (RND && blockIdx.x < n_rounds) round_request(blockIdx.x);
     int64_t t = wave0;
 #ifdef CSRK_LS_STAMPS
     unsigned long long stamp_acc[LS_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1597,20 +1662,43 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #endif
     if (t < n_tiles) {
         const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
-        const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
+        const u32x4_t *ip = H16 ? (const u32x4_t *)((const uint16_t *)sidx + t * ACC_TILE) : (const u32x4_t *)(sidx + t * ACC_TILE);
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
 #pragma unroll
-        for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        for (int q = 0; q < NIX; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
         tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
         if (XGT) {
             cb = __builtin_amdgcn_readfirstlane(tile_cold[t]);
             cn = __builtin_amdgcn_readfirstlane(tile_cold[t + 1]) - cb;
         }
     }
-    for (; t < n_tiles; t += n_waves) {
-        const bool more = t + n_waves < n_tiles;
-        const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
+    for (int64_t R = blockIdx.x; R < n_rounds; R += gridDim.x) {
+    if (RND) {
+        __syncthreads();      // every wavefront is done with the previous round's values
+#pragma unroll
+        for (int q = 0; q < RQ; q++) ((f64x2_t *)s_rnd)[q * LS_THREADS + threadIdx.x] = rv[q];
+        __syncthreads();
+        if (R + gridDim.x < n_rounds) round_request(R + gridDim.x);      // in flight across this round's tiles
+    }
+    for (int kq = 0; kq < KB; kq++) {
+        t = R * nt_round + kq * NW + wv;
+        if (t >= n_tiles) break;
+        // the wavefront's next tile: in this round, else the first of the workgroup's next round, else none (itself)
+        int64_t t_next = kq + 1 < KB ? t + NW : (R + gridDim.x) * nt_round + wv;
+        if (t_next >= n_tiles) t_next = t;
+        uint32_t e[ACC_K];
+        if (H16) {      // 16-bit words -> the 32-bit form: a packed column of slot < n_lds, the row-start flag, or padding
+            const uint32_t w[ACC_K] = {ix[0].x & 0xffffu, ix[0].x >> 16, ix[0].y & 0xffffu, ix[0].y >> 16,
+                                       ix[0].z & 0xffffu, ix[0].z >> 16, ix[0].w & 0xffffu, ix[0].w >> 16};
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++)
+                e[j] = (w[j] & LS16_PAD) == LS16_PAD ? LS_PAD : (LS_HOT_BIT | ((w[j] & LS16_START) << 15) | (w[j] & LS16_PAD));
+        } else {
+            const uint32_t w[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[NIX - 1].x, ix[NIX - 1].y, ix[NIX - 1].z, ix[NIX - 1].w};
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) e[j] = w[j];
+        }
         const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
         // Issue order matters: vmcnt retires loads in issue order, so whatever is requested BEFORE the loads this tile
         // waits for is waited for too.  This tile's own loads (staged values / gathers, row ids) therefore go first and
@@ -1634,6 +1722,22 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             for (int j = 0; j < ACC_K; j++) {
                 const uint32_t c = e[j] & LS_COL_MASK;
                 const bool hot = (e[j] & LS_HOT_BIT) != 0;
+                gv[j] = 0.0;
+                if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
+            }
+        } else if (H16) {
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                inl[j] = e[j] != LS_PAD;      // every entry is on an LDS-resident column (a padding slot multiplies 0 * 0)
+                gv[j] = 0.0;
+            }
+        } else if (RND) {
+            // packed columns beyond the LDS slots: gathered from the pack; everything else is in LDS
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const uint32_t c = e[j] & LS_COL_MASK;
+                const bool hot = (e[j] & LS_HOT_BIT) != 0;
+                inl[j] = e[j] != LS_PAD && (!hot || (int32_t)c < n_lds);      // (a padding slot multiplies 0 * 0)
                 gv[j] = 0.0;
                 if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
             }
@@ -1662,12 +1766,12 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             // The next tile's stream loads stay in flight while this one is gathered and reduced.  UNCONDITIONAL (the
             // last tile re-requests itself): behind an `if (more)` the compiler cannot count the loads in flight at the
             // join and waits for all of them (s_waitcnt vmcnt(0)) before this tile's first multiply.
-            const int64_t tn = more ? t + n_waves : t;
+            const int64_t tn = t_next;
             const f64x2_t *vp = (const f64x2_t *)(svals + tn * ACC_TILE);
-            const u32x4_t *ip = (const u32x4_t *)(sidx + tn * ACC_TILE);
+            const u32x4_t *ip = H16 ? (const u32x4_t *)((const uint16_t *)sidx + tn * ACC_TILE) : (const u32x4_t *)(sidx + tn * ACC_TILE);
             // (index words first: the next tile's gathers need them at its very top, the values only at its multiplies)
 #pragma unroll
-            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+            for (int q = 0; q < NIX; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
 #pragma unroll
             for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
             tbn = tile_base[tn];
@@ -1697,6 +1801,14 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 const bool cold = !hot && e[j] != LS_PAD;
                 inl[j] = lds_hot || cold;                       // served from LDS: the hot slots or the staged range
                 const double *src = cold ? s_out + c : s_hot + (lds_hot ? c : 0);
+                lv[j] = *src;
+            }
+        } else if (RND) {
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) {
+                const uint32_t c = e[j] & LS_COL_MASK;
+                const bool cold = !(e[j] & LS_HOT_BIT) && e[j] != LS_PAD;
+                const double *src = cold ? s_rnd + c : s_hot + (inl[j] ? c : 0);
                 lv[j] = *src;
             }
         } else {
@@ -1828,16 +1940,18 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = vn[q];
 #pragma unroll
-        for (int q = 0; q < 2; q++) ix[q] = ixn[q];
+        for (int q = 0; q < NIX; q++) ix[q] = ixn[q];
         tb = __builtin_amdgcn_readfirstlane(tbn);
         if (XGT) {
             cb = __builtin_amdgcn_readfirstlane(cbn);
             cn = __builtin_amdgcn_readfirstlane(cnn);
         }
     }
+    }
 #ifdef CSRK_LS_STAMPS
-    if (lane == 0 && wave0 < 4096)
-        for (int i = 0; i < LS_NSTAMP; i++) g_ls_stamps[wave0 * LS_NSTAMP + i] = stamp_acc[i];
+    const int64_t wave_id = (int64_t)blockIdx.x * NW + wv;
+    if (lane == 0 && wave_id < 4096)
+        for (int i = 0; i < LS_NSTAMP; i++) g_ls_stamps[wave_id * LS_NSTAMP + i] = stamp_acc[i];
 #endif
 }
 
@@ -1960,7 +2074,8 @@ constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (s
 // with blockIdx % 8 == b % 8.
 template <class P, int VT>
 static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
-                       bool window, int tpw, bool xcd_streams, hipStream_t s)
+                       bool window, int tpw, bool xcd_streams, hipStream_t s, const int32_t *slot_map = nullptr,
+                       int32_t hot_cap = 0)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t n = (int32_t)rows.size();
@@ -1971,9 +2086,14 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     DevBuf off, bends;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
     const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
-    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>());
+    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>(),
+                                           slot_map, hot_cap);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
+    if (slot_map) {      // entries were left out: the panel holds what the counts add up to
+        CSRK_HIP(hipMemcpyAsync(&nnz_rows, off.as<int64_t>() + pairs, 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+    }
     pn->p64 = nnz_rows > INT32_MAX;
     CSRK_TRY(pn->rp.alloc((size_t)(pairs + 1) * (pn->p64 ? 8 : 4)));
     CSRK_TRY(pn->ci.alloc((size_t)nnz_rows * 4));
@@ -1981,11 +2101,11 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     if (pn->p64)
         panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
                                                           cb, off.as<int64_t>(), pn->rp.as<int64_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>(), slot_map, hot_cap);
     else
         panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
                                                           cb, off.as<int64_t>(), pn->rp.as<int32_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>(), slot_map, hot_cap);
     CSRK_LAUNCH_CHECK();
     // tiles per block (host: nb is at most a few thousand)
     CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
@@ -2038,7 +2158,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     CSRK_HIP(hipMemcpyAsync(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
     CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
-    CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
+    CSRK_TRY(pn->y.alloc((size_t)(pairs + n) * 8));      // (+ one more "block": the hot-window stream's row sums, tier 1)
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
     pn->on = true;
     pn->window = window;
@@ -2239,12 +2359,11 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->heavy_min = HEAVY_MIN;
     std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
     std::vector<int64_t> len0;
-    int64_t nnz0 = 0, nnz1 = 0;
+    int64_t nnz1 = 0;
     for (int32_t c = 0; c < n_cut; c++) {
         if (lens[c] >= HEAVY_MIN) {
             r0.push_back(rows[c]);
             len0.push_back(lens[c]);
-            nnz0 += lens[c];
         } else {
             r1.push_back(rows[c]);
             nnz1 += lens[c];
@@ -2256,6 +2375,32 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     if (pairs0 > pair_cap) return CSRK_OK;                       // pair table too large: keep one path
     if (pairs1 > pair_cap && tier1) return build_heavy_split<P>(m, p, s, false);
 
+    p->n_heavy = n_cut;
+    p->nnz_light = m->nnz - nnz_cut;
+    p->t0_rows = r0;
+    p->t0_lens = len0;
+    p->t1_rows = r1;
+    p->t1_nnz = nnz1;
+    p->view_min = acc_form ? (base_heavy_min > p->heavy_min ? base_heavy_min : p->heavy_min) : p->heavy_min;
+    return CSRK_OK;
+}
+
+template <class P, int VT>
+static int build_tier1_hot(Matrix *m, SpmvPlan *p, hipStream_t s);
+
+// Build the tiers of the rows build_heavy_split cut out.  Runs after build_hot_cache: tier 1 leaves its entries on the
+// LDS-resident packed columns to a hot-window stream (build_tier1_hot) and keeps the others in the pair panel.
+template <class P>
+static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    if (!p->n_heavy) return CSRK_OK;
+    const char *t0env = getenv("CSRK_SPMV_TIER0");
+    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
+    const std::vector<int32_t> &r0 = p->t0_rows, &r1 = p->t1_rows;
+    const std::vector<int64_t> &len0 = p->t0_lens;
+    int64_t nnz0 = 0;
+    for (int64_t l : len0) nnz0 += l;
+    const int64_t nnz1 = p->t1_nnz;
     int tpw0 = 8, tpw1 = 1;
     if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
     if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
@@ -2272,17 +2417,17 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
             p->acc.push_back(ap);                                                                                  \
             CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
         }                                                                                                          \
-        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
+        if (!r1.empty()) {                                                                                         \
+            CSRK_TRY((build_tier1_hot<P, VT>(m, p, s)));                                                           \
+            CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s,                \
+                                         p->t1h.on ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr,         \
+                                         p->t1h.on ? p->t1h_cap : 0)));                                            \
+        }                                                                                                          \
     } while (0)
     if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
     else if (m->val_type == CSRK_VAL_F32) BUILD(CSRK_VAL_F32);
     else BUILD(CSRK_VAL_NONE);
 #undef BUILD
-    p->n_heavy = n_cut;
-    p->nnz_light = m->nnz - nnz_cut;
-    p->t0_rows = r0;
-    p->t0_lens = len0;
-    p->view_min = acc_form ? (base_heavy_min > p->heavy_min ? base_heavy_min : p->heavy_min) : p->heavy_min;
     return CSRK_OK;
 }
 
@@ -2452,9 +2597,13 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
     int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_H16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
     const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
@@ -2497,13 +2646,13 @@ __device__ __forceinline__ bool ls_is_cold(uint32_t ix) { return !(ix & LS_HOT_B
 
 // per index word: count into the (round, block) bucket; the old count is the entry's place inside the bucket
 __global__ __launch_bounds__(256) void ls_cold_count_kernel(const uint32_t *__restrict__ sidx, int64_t n_words, int32_t nblk, int32_t W,
-                                                           int32_t *__restrict__ cnt, int32_t *__restrict__ off)
+                                                           int32_t stage_tiles, int32_t *__restrict__ cnt, int32_t *__restrict__ off)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const int64_t r = w / ((int64_t)ACC_TILE * stage_tiles);
     const int32_t b = (int32_t)((ix & LS_COL_MASK) / (uint32_t)W);
     off[w] = atomicAdd(&cnt[r * nblk + b], 1);
 }
@@ -2518,8 +2667,10 @@ __global__ void ls_cold_transpose_kernel(const int32_t *__restrict__ cnt, int32_
 
 // position in xg = bucket base in (round, block) order + place; position in the copy list = bucket base in
 // (block, round) order + place
+// (rel: the index word keeps the position relative to the round's start -- the round-in-LDS form)
 __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
-                                                           int32_t nblk, int32_t W, const int32_t *__restrict__ base_rb,
+                                                           int32_t nblk, int32_t W, int32_t stage_tiles, int rel,
+                                                           const int32_t *__restrict__ base_rb,
                                                            const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
                                                            uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
 {
@@ -2527,14 +2678,22 @@ __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const int64_t r = w / ((int64_t)ACC_TILE * stage_tiles);
     const uint32_t c = ix & LS_COL_MASK;
     const int32_t b = (int32_t)(c / (uint32_t)W);
     const int32_t pos = base_rb[r * nblk + b] + off[w];
     const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
     a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);      // offset inside the block's window
     a_dst[pa] = pos;
-    sidx[w] = (ix & LS_START_BIT) | (uint32_t)pos;
+    sidx[w] = (ix & LS_START_BIT) | (uint32_t)(rel ? pos - base_rb[r * nblk] : pos);
+}
+
+// round_start[r] = position in xg of round r's first staged value, r = 0 .. nround_ls (the last = n_cold)
+__global__ void ls_round_start_kernel(const int32_t *__restrict__ base_rb, int32_t nround_ls, int32_t nblk,
+                                      int32_t *__restrict__ round_start)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= nround_ls) round_start[r] = base_rb[(int64_t)r * nblk];
 }
 
 // Tile-major staging.  The positions above put the staged values of one workgroup ROUND (16 tiles) side by side, ordered
@@ -2587,7 +2746,7 @@ __global__ __launch_bounds__(256) void ls_cold_place_tile_kernel(uint32_t *__res
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);
+    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);      // (tile-major: always built with LS_STAGE_TILES per round)
     const uint32_t c = ix & LS_COL_MASK;
     const int32_t b = (int32_t)(c / (uint32_t)W);
     const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
@@ -2637,7 +2796,7 @@ __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double
         }
 #pragma unroll
         for (int q = 0; q < LS_STAGE_IPT; q++)
-            if (c[q] >= 0) xg[d[q]] = s_x[c[q]];
+            if (c[q] >= 0) xg[d[q]] = s_x[c[q]];      // (non-temporal stores: 0.299 instead of 0.073 ms -- the runs no longer merge in L2)
         if (kn < k1) {
 #pragma unroll
             for (int q = 0; q < LS_STAGE_IPT; q++) c[q] = cn[q], d[q] = dn[q];
@@ -2672,14 +2831,26 @@ __global__ void ls_pack_place_kernel(const int32_t *__restrict__ hot_cols, int32
     a_dst[pa] = n_cold + k;
 }
 
+// Round-in-LDS form (default; CSRK_LS_RND=0 for the round-major form read by gathers): the round is the largest number
+// of tiles (a multiple of the workgroup's wavefronts, at most LS_RND_MAXTILES) whose staged values fit LS_RND_CAP in
+// every round.
+
+__global__ void ls_round_total_kernel(const int64_t *__restrict__ tot, int32_t nround_ls, int32_t nblk, int64_t *__restrict__ out)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= nround_ls) out[r] = tot[(int64_t)r * nblk];
+}
+
 static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols, int32_t n_hot, hipStream_t s)
 {
     ls->n_cold = 0;
+    ls->stage_tiles = 0;
     const char *env = getenv("CSRK_LS_STAGE");
     if (env && env[0] == '0') return CSRK_OK;
+    const char *xgt_env = getenv("CSRK_LS_XGT"), *rnd_env = getenv("CSRK_LS_RND");
+    const bool xgt = xgt_env && xgt_env[0] == '1';
+    bool rnd = !xgt && !(rnd_env && rnd_env[0] == '0');
     const int64_t n_words = ls->n_tiles * ACC_TILE;
-    const int64_t nround_ls = ceil_div(ls->n_tiles, LS_STAGE_TILES);
-    const int64_t nround = nround_ls + 1;      // + the virtual round of the packed columns
     // a number of column blocks that fills the chip a whole number of times (two workgroups per CU), each window
     // at most LS_STAGE_WMAX columns
     int cus = 0;
@@ -2688,35 +2859,68 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     const int64_t nblk_goal = wave_of_wgs * ceil_div((int64_t)m->ncols, wave_of_wgs * LS_STAGE_WMAX);
     const int64_t W = ceil_div(ceil_div((int64_t)m->ncols, nblk_goal), 16) * 16;
     const int64_t nblk = ceil_div((int64_t)m->ncols, W);
-    const int64_t nb = nround * nblk;
-    if (nb < 1 || nb > (int64_t)1 << 26 || nround > INT32_MAX) return CSRK_OK;
+    const int64_t nb_max = (ceil_div(ls->n_tiles, LS_STAGE_TILES) + 1) * nblk;      // (the smallest round has the most buckets)
+    if (nb_max < 1 || nb_max > (int64_t)1 << 26) return CSRK_OK;
     size_t mfree = 0, mtotal = 0;
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if ((size_t)n_words * 20 + (size_t)nb * 16 + (64u << 20) > mfree) return CSRK_OK;
-    DevBuf cnt, cntT, off, offp;
+    if ((size_t)n_words * 20 + (size_t)nb_max * 16 + (64u << 20) > mfree) return CSRK_OK;
+    DevBuf cnt, cntT, off, offp, tot;
     CSRK_TRY(offp.alloc((size_t)n_hot * 4));
-    CSRK_TRY(cnt.alloc((size_t)(nb + 1) * 4));
-    CSRK_TRY(cntT.alloc((size_t)(nb + 1) * 4));
+    CSRK_TRY(cnt.alloc((size_t)(nb_max + 1) * 4));
+    CSRK_TRY(cntT.alloc((size_t)(nb_max + 1) * 4));
     CSRK_TRY(off.alloc((size_t)n_words * 4));
-    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nb + 1) * 4, s));
-    CSRK_HIP(hipMemsetAsync(cntT.p, 0, (size_t)(nb + 1) * 4, s));
+    CSRK_TRY(tot.alloc((size_t)(nb_max + 1) * 8));
     const unsigned gw = (unsigned)ceil_div(n_words, 256);
-    ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
-                                           off.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
+    int stage_tiles = LS_STAGE_TILES;
+    int64_t nround_ls = 0, nround = 0, nb = 0, n_cold = 0;      // n_cold = where the virtual round starts
+    // counts per (round, block) bucket for rounds of `nt` tiles; the old count is an entry's place inside its bucket
+    auto count_pass = [&](int nt, int64_t *max_round) -> int {
+        stage_tiles = nt;
+        nround_ls = ceil_div(ls->n_tiles, nt);
+        nround = nround_ls + 1;      // + the virtual round of the packed columns
+        nb = nround * nblk;
+        CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nb + 1) * 4, s));
+        ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, nt, cnt.as<int32_t>(),
+                                               off.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        // the counts are 32-bit: total them in 64 bits before trusting the 32-bit scans
+        CSRK_TRY(exclusive_scan_i32_to_i64(cnt.as<int32_t>(), tot.as<int64_t>(), nround_ls * nblk, s));
+        std::vector<int64_t> rs((size_t)nround_ls + 1);
+        DevBuf drs;
+        CSRK_TRY(drs.alloc((size_t)(nround_ls + 1) * 8));
+        ls_round_total_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(tot.as<int64_t>(), (int32_t)nround_ls, (int32_t)nblk,
+                                                                                   drs.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipMemcpyAsync(rs.data(), drs.p, (size_t)(nround_ls + 1) * 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        n_cold = rs[(size_t)nround_ls];
+        *max_round = 0;
+        for (int64_t r = 0; r < nround_ls; r++) *max_round = std::max(*max_round, rs[(size_t)r + 1] - rs[(size_t)r]);
+        return CSRK_OK;
+    };
+    int64_t max_round = 0;
+    if (rnd) {
+        int nt0 = LS_RND_MAXTILES;
+        if (const char *e = getenv("CSRK_LS_RND_TILES")) nt0 = atoi(e) >= LS_STAGE_TILES ? atoi(e) / LS_STAGE_TILES * LS_STAGE_TILES : nt0;
+        rnd = false;
+        for (int nt = nt0; nt >= LS_STAGE_TILES; nt -= LS_STAGE_TILES) {
+            CSRK_TRY(count_pass(nt, &max_round));
+            if (max_round <= LS_RND_CAP) {
+                rnd = true;
+                break;
+            }
+        }
+    }
+    if (!rnd) CSRK_TRY(count_pass(LS_STAGE_TILES, &max_round));
+    if (nround > INT32_MAX) return CSRK_OK;
+    CSRK_HIP(hipMemsetAsync(cnt.as<int32_t>() + nround_ls * nblk, 0, (size_t)(nblk + 1) * 4, s));
     ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
                                                                        cnt.as<int32_t>() + nround_ls * nblk, offp.as<int32_t>());
     CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipMemsetAsync(cntT.p, 0, (size_t)(nb + 1) * 4, s));
     ls_cold_transpose_kernel<<<(unsigned)ceil_div(nb, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
                                                                        cntT.as<int32_t>());
     CSRK_LAUNCH_CHECK();
-    // the counts are 32-bit: total them in 64 bits before trusting the 32-bit scans
-    DevBuf tot;
-    CSRK_TRY(tot.alloc((size_t)(nb + 1) * 8));
-    CSRK_TRY(exclusive_scan_i32_to_i64(cnt.as<int32_t>(), tot.as<int64_t>(), nb + 1, s));
-    int64_t n_cold = 0;      // = where the virtual round starts
-    CSRK_HIP(hipMemcpyAsync(&n_cold, tot.as<int64_t>() + nround_ls * nblk, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
     const int64_t n_all = n_cold + n_hot;
     // worth a pass of its own only when the cold columns cannot live in L2 anyway and there are enough of them
     if (n_cold < 1 || n_all >= (int64_t)LS_PAD || (!(env && env[0] == '1') && n_cold * 16 < n_words)) return CSRK_OK;
@@ -2729,8 +2933,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     // 0.178 ms (its cold gathers were a fifth of its L1 line fills) but the copy pass from 0.064 to 0.125 ms -- every value
     // it writes is then a store transaction of its own (~13 ps each chip-wide; the round-major form averages 0.55 per
     // value) -- so it stays opt-in (CSRK_LS_XGT=1) until the copy is done in two coalesced passes.
-    const char *xgt_env = getenv("CSRK_LS_XGT");
-    if (xgt_env && xgt_env[0] == '1') {
+    if (xgt) {
         // tile-major positions (see ls_cold_rank_kernel); the copy list keeps its (block, round) order
         DevBuf rank;
         CSRK_TRY(rank.alloc((size_t)n_words * 2));
@@ -2746,10 +2949,16 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipStreamSynchronize(s));      // `rank` is freed here
     } else {
-    ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, cnt.as<int32_t>(),
-                                           cntT.as<int32_t>(), off.as<int32_t>(), ls->a_col.as<uint16_t>(),
-                                           ls->a_dst.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
+        if (rnd) {
+            CSRK_TRY(ls->round_start.alloc((size_t)(nround_ls + 1) * 4));
+            ls_round_start_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround_ls, (int32_t)nblk,
+                                                                                       ls->round_start.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+        }
+        ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, stage_tiles,
+                                               rnd ? 1 : 0, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
+                                               ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
     }
     ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
                                                                        cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
@@ -2764,6 +2973,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
     CSRK_HIP(hipStreamSynchronize(s));      // the temporaries are freed on return
     ls->n_cold = n_cold;
+    ls->stage_tiles = stage_tiles;
     return CSRK_OK;
 }
 
@@ -2798,7 +3008,135 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     sg.ent0[0] = 0;
     CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles, nullptr, m->nrows,
                                   slot_map, s)));
-    if (p->ls.on && p->n_hot) CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
+    if (p->ls.on && p->n_hot) {
+        CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
+        // (round-in-LDS form: the round's staged values take the place of the hot window's tail)
+        if (p->ls.n_cold && p->ls.round_start.p && p->n_hot_lds > LS_RND_HOT) p->n_hot_lds = LS_RND_HOT;
+    }
+    return CSRK_OK;
+}
+
+// ---- tier 1, hot-window stream ---------------------------------------------------------------------------------
+// On a power-law matrix the packed columns the light stream keeps in LDS (the n_hot_lds most referenced: 60 % of a
+// Zipf(1) column mass) hold the same share of tier 1's entries.  In the pair panel every one of them costs what a cold
+// entry costs (a gather and a line into L1, ~4.8 ps); here they become a stream of their own whose x values ALL come
+// from LDS: the tier-1 rows' entries on those columns, row after row, in the light stream's tile form with 16-bit index
+// words (bit 15 = first entry of its row, low 15 bits = slot; 0x7fff = padding) -- 10 B per entry, no gather.  Its row
+// sums go to one more "block" of the pair panel's partials (y'[nb][h]), which the tier's ordered reduce adds last.
+
+// one wavefront per tier-1 row: entries on LDS-resident packed columns
+template <class P>
+__global__ __launch_bounds__(256) void t1h_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                       const int32_t *__restrict__ rows, int32_t n,
+                                                       const int32_t *__restrict__ slot_map, int32_t hot_cap,
+                                                       int64_t *__restrict__ cnt)
+{
+    const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (h >= n) return;
+    const int64_t s = rp[rows[h]], e = rp[rows[h] + 1];
+    int c = 0;
+    for (int64_t k = s + lane; k < e; k += WAVE) c += (uint32_t)slot_map[ci[k]] < (uint32_t)hot_cap ? 1 : 0;
+    for (int off = WAVE / 2; off > 0; off >>= 1) c += __shfl_down(c, off, WAVE);
+    if (lane == 0) cnt[h] = c;
+}
+
+// ... copied in storage order into a compact CSR over the tier-1 rows: (slot, float64 value)
+template <class P, int VT>
+__global__ __launch_bounds__(256) void t1h_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                      const void *__restrict__ vs, const int32_t *__restrict__ rows,
+                                                      int32_t n, const int32_t *__restrict__ slot_map, int32_t hot_cap,
+                                                      const int64_t *__restrict__ rph, int32_t *__restrict__ cih,
+                                                      double *__restrict__ vsh)
+{
+    const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (h >= n) return;
+    const int64_t s = rp[rows[h]], e = rp[rows[h] + 1];
+    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
+    int64_t o = rph[h];
+    for (int64_t k0 = s; k0 < e; k0 += WAVE) {
+        const int64_t k = k0 + lane;
+        int32_t sl = -1;
+        if (k < e) sl = slot_map[ci[k]];
+        const bool hot = (uint32_t)sl < (uint32_t)hot_cap;
+        const unsigned long long mk = __ballot(hot);
+        if (hot) {
+            const int64_t q = o + __popcll(mk & below);
+            cih[q] = sl;
+            vsh[q] = ValLoad<VT>::at(vs, k);
+        }
+        o += __popcll(mk);
+    }
+}
+
+// the stream's 32-bit index words (build_stream) -> 16-bit words in logical order (lane l of a tile reads the eight words
+// of its entries with one 16-B load)
+__global__ __launch_bounds__(256) void ls_idx16_kernel(const uint32_t *__restrict__ sidx, int64_t n_slots,
+                                                      uint16_t *__restrict__ out)
+{
+    const int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= n_slots) return;
+    const uint32_t ix = sidx[(L / ACC_TILE) * ACC_TILE + acc_idx_slot((int)(L % ACC_TILE))];
+    const uint32_t c = ix & LS_COL_MASK;
+    out[L] = (uint16_t)(c == LS_PAD ? LS16_PAD : (c | ((ix & LS_START_BIT) ? LS16_START : 0u)));
+}
+
+template <class P, int VT>
+static int build_tier1_hot(Matrix *m, SpmvPlan *p, hipStream_t s)
+{
+    p->t1h.on = false;
+    const char *env = getenv("CSRK_SPMV_T1H");
+    if (!(env && env[0] == '1')) return CSRK_OK;
+    const int32_t n = (int32_t)p->t1_rows.size();
+    const int32_t cap = p->n_hot_lds;
+    p->t1h_cap = cap;
+    // needs the pack (filled per call by the staging pass or hot_pack_kernel) and slots that fit 15 bits
+    if (n < 1 || !p->n_hot || cap < 1 || cap >= (int32_t)LS16_PAD || !p->hot_slot.p) return CSRK_OK;
+    const P *rp = (const P *)m->d_rowptrs;
+    DevBuf rows, rph, cih, vsh;
+    CSRK_TRY(rows.alloc((size_t)n * 4));
+    CSRK_TRY(rph.alloc((size_t)(n + 2) * 8));
+    CSRK_HIP(hipMemcpyAsync(rows.p, p->t1_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    const unsigned gw = (unsigned)ceil_div((int64_t)n * WAVE, 256);
+    t1h_count_kernel<P><<<gw, 256, 0, s>>>(rp, m->d_colinds, rows.as<int32_t>(), n, p->hot_slot.as<int32_t>(), cap,
+                                          rph.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(rph.as<int64_t>(), rph.as<int64_t>(), n, s));
+    int64_t n_hot_ent = 0;
+    CSRK_HIP(hipMemcpyAsync(&n_hot_ent, rph.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    CSRK_HIP(hipStreamSynchronize(s));
+    // worth a launch of its own only when a good part of the tier is on those columns
+    if (n_hot_ent * 8 < p->t1_nnz && !(env && env[0] == '1')) return CSRK_OK;
+    if (n_hot_ent < 1) return CSRK_OK;
+    const int64_t n_tiles = ceil_div(n_hot_ent, ACC_TILE);
+    size_t mfree = 0, mtotal = 0;
+    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if ((size_t)n_hot_ent * 12 + (size_t)n_tiles * ACC_TILE * 14 + (64u << 20) > mfree) return CSRK_OK;
+    CSRK_TRY(cih.alloc((size_t)n_hot_ent * 4));
+    CSRK_TRY(vsh.alloc((size_t)n_hot_ent * 8));
+    t1h_fill_kernel<P, VT><<<gw, 256, 0, s>>>(rp, m->d_colinds, m->d_values, rows.as<int32_t>(), n,
+                                              p->hot_slot.as<int32_t>(), cap, rph.as<int64_t>(), cih.as<int32_t>(),
+                                              vsh.as<double>());
+    CSRK_LAUNCH_CHECK();
+    LsSegs sg;
+    sg.n = 1;
+    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles * ACC_TILE, sg.ent0[k] = n_hot_ent;
+    sg.slot0[0] = 0;
+    sg.ent0[0] = 0;
+    CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1h, rph.as<int64_t>(), rph.as<int64_t>(), n, cih.as<int32_t>(), vsh.p,
+                                                   sg, n_tiles, nullptr, n, nullptr, s)));
+    if (!p->t1h.on) return CSRK_OK;
+    p->t1h_nnz = n_hot_ent;
+    DevBuf i16;
+    CSRK_TRY(i16.alloc((size_t)n_tiles * ACC_TILE * 2));
+    ls_idx16_kernel<<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(p->t1h.idx.as<uint32_t>(), n_tiles * ACC_TILE,
+                                                                              i16.as<uint16_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipStreamSynchronize(s));      // the temporaries and the 32-bit words are freed here
+    p->t1h.idx.release();
+    p->t1h.idx.bytes = i16.bytes;
+    p->t1h.idx.p = i16.take();
     return CSRK_OK;
 }
 
@@ -2942,7 +3280,7 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
         p->split_considered = allow_split;
         PlanTrace tr;
         if (allow_split) CSRK_TRY(build_heavy_split<P>(m, p, s));
-        tr.lap("heavy split + tiers");
+        tr.lap("heavy split");
         const P *rp_path = p->n_heavy ? p->rp_light.as<P>() : rp;
         int64_t total = (int64_t)m->nrows + p->nnz_light;
         p->n_tiles = ceil_div(total, MERGE_ITEMS);
@@ -2964,6 +3302,8 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
         if (allow_split) {
             CSRK_TRY(build_hot_cache<P>(m, p, s));
             tr.lap("hot-column census + pack");
+            CSRK_TRY(build_tiers<P>(m, p, s));
+            tr.lap("tiers");
             const char *ax = getenv("CSRK_SPMV_AUX");
             // (measured on the headline matrix: 0.753 ms with the auxiliary stream, 0.727 without -- the event
             // hand-overs cost more than the overlap of ~25 us of small kernels gains; off unless CSRK_SPMV_AUX=1)
@@ -3143,6 +3483,26 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             }
             kh.stop();
         }
+        if (do_heavy && p->n_heavy && p->t1h.on && p->tier[1].on) {
+            // tier 1's entries on the LDS-resident packed columns: hot-window stream -> the extra block of the pair partials.
+            // Reads the pack: filled by the staging pass / hot_pack_kernel of this product's short-row part (a product
+            // launched in two parts runs part 1 first: csrk_spmv_device_part).
+            if (aux && p->n_hot && do_light) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
+            constexpr size_t h_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
+            LightStream &t = p->t1h;
+            Panel *pn = &p->tier[1];
+            double *y1h = pn->y.as<double>() + pn->rows;
+            KernelTimer kh(p, s, 2);
+            spmv_lstream_kernel<LS_H16><<<t.grid, LS_THREADS, h_lds, s>>>(
+                t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
+                (const int32_t *)nullptr, d_x,
+                (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(), p->t1h_cap,
+                t.n_tiles, t.n_runs, t.n_out, y1h, t.carry_row.as<int32_t>(), t.carry_val.as<double>(),
+                (const int32_t *)nullptr, 0);
+            kh.stop();
+            CSRK_LAUNCH_CHECK();
+            CSRK_TRY(add_fix(t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, y1h));
+        }
         for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
@@ -3150,12 +3510,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 constexpr size_t t1_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                 LightStream &t = p->t1s;
                 KernelTimer kh(p, s, 2);
-                spmv_lstream_kernel<false><<<t.grid, LS_THREADS, t1_lds, s>>>(
+                spmv_lstream_kernel<LS_PLAIN><<<t.grid, LS_THREADS, t1_lds, s>>>(
                     t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
                     t.carry_idx.as<int32_t>(), d_x,
                     (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(),
                     p->n_hot ? p->n_hot_lds : 0, t.n_tiles, t.n_runs, t.n_out,
-                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr);
+                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr, 0);
                 kh.stop();
                 CSRK_LAUNCH_CHECK();
                 if (aux) {
@@ -3215,11 +3575,15 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #define LS_ARGS                                                                                                       \
     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),      \
         (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
-        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.tile_cold.as<int32_t>()
-                if (p->ls.n_cold && p->ls.tile_cold.p)
-                    spmv_lstream_kernel<true><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS);
+        p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>()
+                if (p->ls.n_cold && p->ls.round_start.p) {
+                    constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
+                    spmv_lstream_kernel<LS_RND><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(LS_ARGS, p->ls.round_start.as<int32_t>(),
+                                                                                          p->ls.stage_tiles);
+                } else if (p->ls.n_cold && p->ls.tile_cold.p)
+                    spmv_lstream_kernel<LS_XGT><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), 0);
                 else
-                    spmv_lstream_kernel<false><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS);
+                    spmv_lstream_kernel<LS_PLAIN><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, (const int32_t *)nullptr, 0);
 #undef LS_ARGS
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
@@ -3266,7 +3630,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             // y[row] = sum over column blocks of the (block, row) partials, in block order
-            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb));
+            // (tier 1 with a hot-window stream: one more block, the stream's row sums)
+            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb + (q == 1 && p->t1h.on ? 1 : 0)));
         }
         CSRK_TRY(flush_red());      // the ordered reduces of the tiers, one launch
         break;
@@ -3625,20 +3990,22 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
             for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y}) add(*b);
         for (const AccPanel *ap : p->acc)
             for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
-        for (const LightStream *l : {&p->ls, &p->t1s})
+        for (const LightStream *l : {&p->ls, &p->t1s, &p->t1h})
             for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
                                     &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold})
                 add(*b);
     }
-    const int64_t v[26] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    // [26] tier-1 entries served by the hot-window stream, [27] tiles per staging round when the round is held in LDS (else 0)
+    const int64_t v[28] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
                            af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
-                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes};
-    for (int i = 0; i < n && i < 26; i++) out[i] = v[i];
+                           p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
+                           p->t1h.on ? p->t1h_nnz : 0, p->ls.round_start.p ? p->ls.stage_tiles : 0};
+    for (int i = 0; i < n && i < 28; i++) out[i] = v[i];
     return CSRK_OK;
 }
 
