@@ -85,6 +85,9 @@ struct Panel {
     int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
     DevBuf row_list;                             // int32[nrow]: original row ids, ascending
     DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y;
+    // the tiles' carries, listed per long row (static: a tile's carry belongs to the pair its last row end falls in):
+    // carries of long row h = carry_val[cidx[crp[h] .. crp[h + 1])], in tile order -- added by the tier's ordered reduce
+    DevBuf crp, cidx;
 };
 
 // one segment of an accumulator-form workgroup's tile range (see "long rows, accumulator form")
@@ -119,11 +122,11 @@ struct LightStream {
     // tile-major staging (build_cold_stage, default): the staged values of tile t are xg[tile_cold[t] .. tile_cold[t + 1]),
     // and a cold entry's index word holds its offset inside that range; empty: positions are absolute (round-major form)
     DevBuf tile_cold;
-    // round-in-LDS staging (build_cold_stage, LS_RND): a workgroup takes `stage_tiles` consecutive tiles per round, copies
-    // the round's staged values xg[round_start[r] .. round_start[r + 1]) into LDS, and a cold entry's index word holds its
-    // offset inside that range
+    // round-in-LDS staging (build_cold_stage, LS_RND): workgroup b walks rounds wg_round0[b] .. wg_round0[b + 1]; round r =
+    // tiles round_tile0[r] .. round_tile0[r + 1] (at most `stage_tiles`), whose staged values xg[round_start[r] ..
+    // round_start[r + 1]) the workgroup copies into LDS; a cold entry's index word holds its offset inside that range
     int32_t stage_tiles = 0;
-    DevBuf round_start;
+    DevBuf round_start, round_tile0, wg_round0;
 };
 
 struct SpmvPlan {
@@ -156,17 +159,13 @@ struct SpmvPlan {
     DevBuf hot_slot;    // int32[ncols]: slot of a packed column, -1 otherwise (kept until the stream / ci_hot is built)
     DevBuf hot_cols;    // int32[n_hot]: column of each slot
     DevBuf xh;          // double[n_hot]
-    hipStream_t aux = nullptr;    // auxiliary stream: hot pack, tier-1 fix-up/reduce1 beside the streaming kernels
-    hipEvent_t ev_fork = nullptr, ev_pack = nullptr, ev_aux = nullptr, ev_tier[2] = {nullptr, nullptr};
     Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
                         // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
                         // 262144-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
     LightStream ls;                       // the rows that stay on the row-major path
     LightStream t1s;                      // tier 1 as a stream of (column block, row) runs
-    LightStream t1h;                      // tier 1's entries on the LDS-resident packed columns: a hot-window stream (16-bit index words)
     std::vector<int32_t> t1_rows;         // tier-1 rows (ascending) and their entries: build_tiers
-    int64_t t1_nnz = 0, t1h_nnz = 0;      // (t1h_nnz: of which in the hot-window stream)
-    int32_t t1h_cap = 0;                  // slots below this are the hot-window stream's
+    int64_t t1_nnz = 0;
     std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
     std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths: source of either form
     std::vector<int64_t> t0_lens;
@@ -187,9 +186,6 @@ struct SpmvPlan {
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        if (aux) (void)hipStreamDestroy(aux);
-        for (hipEvent_t e : {ev_fork, ev_pack, ev_aux, ev_tier[0], ev_tier[1]})
-            if (e) (void)hipEventDestroy(e);
         for (AccPanel *a : acc) delete a;
     }
 };
@@ -741,18 +737,10 @@ constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block
 #define PANEL_T1 256
 #endif
 
-// slot_map / hot_cap (optional): entries on the packed columns of slot < hot_cap are left out of the panel (they are
-// served by the hot-window stream, build_tier1_hot)
-__device__ __forceinline__ bool panel_keeps(const int32_t *__restrict__ slot_map, int32_t hot_cap, int32_t col)
-{
-    return !slot_map || (uint32_t)slot_map[col] >= (uint32_t)hot_cap;      // (unpacked columns map to -1)
-}
-
 template <class P>
 __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int32_t cb, int64_t *__restrict__ cnt, const int32_t *__restrict__ slot_map,
-                                   int32_t hot_cap)
+                                   int32_t cb, int64_t *__restrict__ cnt)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -761,20 +749,14 @@ __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__re
     const int64_t s = rp[r], e = rp[r + 1];
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
     const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * cb);
-    int64_t n = hi - lo;
-    if (slot_map) {
-        n = 0;
-        for (int64_t k = lo; k < hi; k++) n += panel_keeps(slot_map, hot_cap, ci[k]) ? 1 : 0;
-    }
-    cnt[i] = n;
+    cnt[i] = hi - lo;
 }
 
 template <class P, int VT, class PP>
 __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
                                   int32_t cb, const int64_t *__restrict__ off, PP *__restrict__ prp,
-                                  int32_t *__restrict__ pci, double *__restrict__ pvs,
-                                  const int32_t *__restrict__ slot_map, int32_t hot_cap)
+                                  int32_t *__restrict__ pci, double *__restrict__ pvs)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pairs = (int64_t)n_heavy * n_blocks;
@@ -787,13 +769,9 @@ __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__res
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
     const int64_t n = off[i + 1] - off[i];
     int64_t o = off[i];
-    const int64_t o_end = o + n;
-    for (int64_t k = lo; o < o_end; k++) {
-        const int32_t col = ci[k];
-        if (!panel_keeps(slot_map, hot_cap, col)) continue;
-        pci[o] = col;
+    for (int64_t k = lo; k < lo + n; k++, o++) {
+        pci[o] = ci[k];
         pvs[o] = ValLoad<VT>::at(vs, k);
-        o++;
     }
 }
 
@@ -1362,69 +1340,71 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
     for (int h = tid; h < H; h += PT) partial[(int64_t)blockIdx.x * H + h] = s_acc[h];
 }
 
-// (The ordered reduce -- y[row_list[h]] = sum over workgroups / column blocks w of partial[w][h], in order: 64
-// rows per workgroup, 16 lane groups each summing a contiguous range of w, joined in order through LDS -- is
-// acc_reduce_multi_kernel below.)
-// The per-SpMV epilogue work is a handful of tiny kernels (carry fix-ups of the light stream and of tier 1,
-// ordered reduces of tier 0 and tier 1: ~5 us each, mostly launch latency).  They are issued as ONE fix-up
-// launch and ONE reduce launch, each covering up to four jobs (a job = a contiguous range of workgroups).
-struct FixJob {
+// The per-SpMV epilogue -- the carry fix-up of the light stream, the ordered reduces of tier 0 (over the accumulator
+// kernel's workgroups) and of tier 1 (over the column blocks, plus the pair kernel's carries) -- is ONE launch covering up
+// to six jobs (a job = a contiguous range of 1024-thread workgroups).  As separate launches the two small kernels took
+// 5.4 + 14.7 us of a 0.553 ms SpMV, mostly launch latency and exposed round trips.
+//   fix:    y[row] += the carries of the tiles that end inside `row`, in tile order (one thread per tile; the first tile of a
+//           run of equal carry_row adds the whole run).
+//   reduce: y[row_list[h]] = sum over w < n_wg of partial[w][h], in order, then the row's listed carries (crp/cidx: the
+//           tiles of the pair kernel whose last row end falls in a pair of long row h), in tile order.  A workgroup takes
+//           1024 / (64 G) sets of 64 rows; the G wavefronts of a set each sum a contiguous range of w, joined in order
+//           through LDS.  G = 16 for tier 0 (256 partials per row), 2 for tier 1 (38): 240 + 135 + 78 workgroups on the
+//           headline matrix, all resident at once (two per CU) -- 588 of them (G = 4) ran as two rounds: 21.9 us.
+struct EpiJob {
+    int32_t kind, blocks;      // 0 = fix, 1 = reduce
+    // fix
     const int32_t *carry_row;
     const double *carry_val;
     int64_t n;
-    double *y;
-    int32_t blocks;
-};
-struct RedJob {
+    double *fy;
+    // reduce
     const double *partial;
     const int32_t *row_list;
-    int32_t H, n_wg, blocks;
+    int32_t H, n_wg, G;
+    const int32_t *crp, *cidx;      // optional (nullptr: no carries to add)
+    const double *cval;
 };
-struct FixJobs {
-    FixJob j[4];
+struct EpiJobs {
+    EpiJob j[6];
     int32_t n;
 };
-struct RedJobs {
-    RedJob j[4];
-    int32_t n;
-};
+constexpr int EPI_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void spmv_fixup_multi_kernel(FixJobs jobs)
+__global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs, double *__restrict__ y)
 {
+    __shared__ double s_p[EPI_THREADS / WAVE][WAVE];
     int b = blockIdx.x, q = 0;
     while (q + 1 < jobs.n && b >= jobs.j[q].blocks) b -= jobs.j[q++].blocks;
-    const FixJob &J = jobs.j[q];
-    const int64_t t = (int64_t)b * 256 + threadIdx.x;
-    if (t >= J.n) return;
-    const int32_t row = J.carry_row[t];
-    if (row < 0) return;
-    if (t > 0 && J.carry_row[t - 1] == row) return;
-    double acc = J.carry_val[t];
-    for (int64_t u = t + 1; u < J.n && J.carry_row[u] == row; u++) acc += J.carry_val[u];
-    J.y[row] = acc + J.y[row];
-}
-
-__global__ __launch_bounds__(1024) void acc_reduce_multi_kernel(RedJobs jobs, double *__restrict__ y)
-{
-    __shared__ double s_p[16][WAVE];
-    int b = blockIdx.x, q = 0;
-    while (q + 1 < jobs.n && b >= jobs.j[q].blocks) b -= jobs.j[q++].blocks;
-    const RedJob &J = jobs.j[q];
-    const int lane = threadIdx.x & (WAVE - 1), g = threadIdx.x / WAVE;
-    const int h = b * WAVE + lane;
-    const int per = (J.n_wg + 15) / 16;
+    const EpiJob &J = jobs.j[q];
+    if (J.kind == 0) {
+        const int64_t t = (int64_t)b * EPI_THREADS + threadIdx.x;
+        if (t >= J.n) return;
+        const int32_t row = J.carry_row[t];
+        if (row < 0) return;
+        if (t > 0 && J.carry_row[t - 1] == row) return;
+        double acc = J.carry_val[t];
+        for (int64_t u = t + 1; u < J.n && J.carry_row[u] == row; u++) acc += J.carry_val[u];
+        J.fy[row] = acc + J.fy[row];
+        return;
+    }
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int G = J.G, set = wv / G, g = wv % G;                      // G divides 16
+    const int h = (b * (EPI_THREADS / WAVE / G) + set) * WAVE + lane;
+    const int per = (J.n_wg + G - 1) / G;
     const int w0 = g * per, w1 = w0 + per < J.n_wg ? w0 + per : J.n_wg;
     double acc = 0.0;
     if (h < J.H) {
 #pragma unroll 8
         for (int w = w0; w < w1; w++) acc += J.partial[(int64_t)w * J.H + h];
     }
-    s_p[g][lane] = acc;
+    s_p[wv][lane] = acc;
     __syncthreads();
     if (g == 0 && h < J.H) {
-        double tot = s_p[0][lane];
-#pragma unroll
-        for (int u = 1; u < 16; u++) tot += s_p[u][lane];
+        double tot = s_p[wv][lane];
+        for (int u = 1; u < G; u++) tot += s_p[wv + u][lane];
+        if (J.crp)
+            for (int32_t k = J.crp[h]; k < J.crp[h + 1]; k++) tot += J.cval[J.cidx[k]];
         y[J.row_list[h]] = tot;
     }
 }
@@ -1468,7 +1448,7 @@ constexpr int LS_HOT_LDS = CSRK_LS_HOT_LDS;
 #ifndef CSRK_LS_RND_CAP
 #define CSRK_LS_RND_CAP 8192
 #endif
-constexpr int LS_RND_CAP = CSRK_LS_RND_CAP, LS_RND_MAXTILES = 64;
+constexpr int LS_RND_CAP = CSRK_LS_RND_CAP, LS_RND_MAXTILES = 128;
 constexpr int LS_RND_HOT = (160 * 1024 - (CSRK_LS_THREADS / 64) * (512 + 2) * 8) / 8 - LS_RND_CAP;      // 8176 with the defaults
 constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile
 #ifndef CSRK_LS_SEQ
@@ -1477,7 +1457,6 @@ constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead
 constexpr int LS_SEQ = CSRK_LS_SEQ;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
 constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
 constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
-constexpr uint32_t LS16_PAD = 0x7fffu, LS16_START = 0x8000u;      // 16-bit index words of the hot-window stream (build_tier1_hot)
 
 // smallest r in [0, nrows) with rpv[r + 1] > L (the row holding view entry L); L < rpv[nrows]
 template <class P>
@@ -1599,29 +1578,28 @@ __device__ unsigned long long g_ls_stamps[4096 * LS_NSTAMP];
 // instead of one per value (a gather lane that misses L1 costs its CU ~4 clocks of line fill wherever the line comes
 // from).  The buffer is the run-sum staging buffer s_out: the gathers of a tile are over before
 // its run sums are written, and a wavefront's LDS operations complete in order.
-// MODE: LS_PLAIN; LS_XGT (above); LS_H16 = hot-window stream (build_tier1_hot): 16-bit index words, every x value in LDS;
+// MODE: LS_PLAIN; LS_XGT (above);
 // LS_RND = round-in-LDS staging: the workgroup walks ROUNDS of `stage_tiles` consecutive tiles (wavefront w takes tiles
 // w, w + 8, ... of the round); `x` is xg and tile_cold[r] the start of round r's staged values in it, which the workgroup
 // copies into LDS with coalesced loads (requested one round ahead, into registers) -- a cold entry's index word holds its
 // offset there.  The copy pass can then use rounds of 64 tiles (its store transactions are per (round, column block)
 // bucket: 0.049 ms against 0.065 at 8 tiles) without the stream side paying for it in L1 lines (0.257 ms at 64 tiles when
 // the round's range is read by gathers).  Two workgroup barriers per round.
-constexpr int LS_PLAIN = 0, LS_XGT = 1, LS_H16 = 2, LS_RND = 3;
+constexpr int LS_PLAIN = 0, LS_XGT = 1, LS_RND = 2;
 template <int MODE>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
     const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
     double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
-    const int32_t *__restrict__ tile_cold, int32_t stage_tiles)
+    const int32_t *__restrict__ tile_cold, const int32_t *__restrict__ round_tile0, const int32_t *__restrict__ wg_round0)
 {
     // No FMA contraction in this kernel: the reference rounds every product before adding it.  (HIP's rounding
     // intrinsics for multiply and add are plain * and + inside inline functions compiled with
     // -ffp-contract=fast and fuse after inlining -- measured: 2041 instead of 75 rows of BASELINE configs[0]
     // differed in the last bits; the pragma governs the operators written in this body.)
 #pragma clang fp contract(off)
-    constexpr bool XGT = MODE == LS_XGT, H16 = MODE == LS_H16, RND = MODE == LS_RND;
-    constexpr int NIX = H16 ? 1 : 2;      // 16-B index loads per lane and tile
+    constexpr bool XGT = MODE == LS_XGT, RND = MODE == LS_RND;
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1631,14 +1609,20 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     for (int i = threadIdx.x; i < n_lds; i += LS_THREADS) s_hot[i] = xh[i];
     __syncthreads();
 
-    // A workgroup walks rounds R = blockIdx, blockIdx + grid, ...; wavefront w takes tiles R * nt_round + w + k * NW,
-    // k < KB.  Without RND a round is one tile per wavefront (KB = 1): tile = wavefront number + multiples of the grid's
-    // wavefront count.
+    // A workgroup walks ROUNDS; wavefront w takes tiles w, w + NW, ... of a round.  RND: the workgroup's rounds are
+    // wg_round0[b] .. wg_round0[b + 1], round R = tiles round_tile0[R] .. round_tile0[R + 1] (equal shares of the tiles per
+    // workgroup, cut into rounds: build_cold_stage).  Otherwise a round is one tile per wavefront and workgroup b takes
+    // rounds b, b + grid, ...
     constexpr int NW = LS_THREADS / WAVE;
-    const int nt_round = RND ? stage_tiles : NW;
-    const int KB = RND ? stage_tiles / NW : 1;
-    const int64_t n_rounds = (n_tiles + nt_round - 1) / nt_round;
-    const int64_t wave0 = (int64_t)blockIdx.x * nt_round + wv;
+    const int64_t R_begin = RND ? (int64_t)wg_round0[blockIdx.x] : (int64_t)blockIdx.x;
+    const int64_t R_end = RND ? (int64_t)wg_round0[blockIdx.x + 1] : (n_tiles + NW - 1) / NW;
+    const int64_t R_step = RND ? 1 : (int64_t)gridDim.x;
+    auto round_t0 = [&](int64_t R_) -> int64_t { return RND ? (int64_t)round_tile0[R_] : R_ * NW; };
+    auto round_t1 = [&](int64_t R_) -> int64_t {
+        if (RND) return (int64_t)round_tile0[R_ + 1];
+        return (R_ + 1) * NW < n_tiles ? (R_ + 1) * NW : n_tiles;
+    };
+    const int64_t wave0 = R_begin < R_end ? round_t0(R_begin) + wv : n_tiles;
     f64x2_t v[4], vn[4];
     u32x4_t ix[2], ixn[2];
     int32_t tb = 0, tbn = 0;
@@ -1654,51 +1638,46 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             rv[q] = *(const F64x2 *)(x + r0 + (k < rn ? k : 0));
         }
     };
-    if (RND && blockIdx.x < n_rounds) round_request(blockIdx.x);
+    if (RND && R_begin < R_end) round_request(R_begin);
     int64_t t = wave0;
 #ifdef CSRK_LS_STAMPS
     unsigned long long stamp_acc[LS_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    if (t < n_tiles) {
+    if (R_begin < R_end && t < round_t1(R_begin)) {
         const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
-        const u32x4_t *ip = H16 ? (const u32x4_t *)((const uint16_t *)sidx + t * ACC_TILE) : (const u32x4_t *)(sidx + t * ACC_TILE);
+        const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
 #pragma unroll
-        for (int q = 0; q < NIX; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
         tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
         if (XGT) {
             cb = __builtin_amdgcn_readfirstlane(tile_cold[t]);
             cn = __builtin_amdgcn_readfirstlane(tile_cold[t + 1]) - cb;
         }
     }
-    for (int64_t R = blockIdx.x; R < n_rounds; R += gridDim.x) {
+    for (int64_t R = R_begin; R < R_end; R += R_step) {
     if (RND) {
         __syncthreads();      // every wavefront is done with the previous round's values
 #pragma unroll
         for (int q = 0; q < RQ; q++) ((f64x2_t *)s_rnd)[q * LS_THREADS + threadIdx.x] = rv[q];
         __syncthreads();
-        if (R + gridDim.x < n_rounds) round_request(R + gridDim.x);      // in flight across this round's tiles
+        if (R + R_step < R_end) round_request(R + R_step);      // in flight across this round's tiles
     }
-    for (int kq = 0; kq < KB; kq++) {
-        t = R * nt_round + kq * NW + wv;
-        if (t >= n_tiles) break;
-        // the wavefront's next tile: in this round, else the first of the workgroup's next round, else none (itself)
-        int64_t t_next = kq + 1 < KB ? t + NW : (R + gridDim.x) * nt_round + wv;
-        if (t_next >= n_tiles) t_next = t;
-        uint32_t e[ACC_K];
-        if (H16) {      // 16-bit words -> the 32-bit form: a packed column of slot < n_lds, the row-start flag, or padding
-            const uint32_t w[ACC_K] = {ix[0].x & 0xffffu, ix[0].x >> 16, ix[0].y & 0xffffu, ix[0].y >> 16,
-                                       ix[0].z & 0xffffu, ix[0].z >> 16, ix[0].w & 0xffffu, ix[0].w >> 16};
-#pragma unroll
-            for (int j = 0; j < ACC_K; j++)
-                e[j] = (w[j] & LS16_PAD) == LS16_PAD ? LS_PAD : (LS_HOT_BIT | ((w[j] & LS16_START) << 15) | (w[j] & LS16_PAD));
-        } else {
-            const uint32_t w[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[NIX - 1].x, ix[NIX - 1].y, ix[NIX - 1].z, ix[NIX - 1].w};
-#pragma unroll
-            for (int j = 0; j < ACC_K; j++) e[j] = w[j];
+    const int64_t rt1 = round_t1(R);
+    for (t = round_t0(R) + wv; t < rt1; t += NW) {
+        // the wavefront's next tile: in this round, else in the workgroup's next round (every round but a workgroup's last
+        // is a whole number of tiles per wavefront), else none (itself)
+        int64_t t_next = t + NW;
+        if (t_next >= rt1) {
+            t_next = t;
+            if (R + R_step < R_end) {
+                const int64_t tf = round_t0(R + R_step) + wv;
+                if (tf < round_t1(R + R_step)) t_next = tf;
+            }
         }
+        const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
         const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
         // Issue order matters: vmcnt retires loads in issue order, so whatever is requested BEFORE the loads this tile
         // waits for is waited for too.  This tile's own loads (staged values / gathers, row ids) therefore go first and
@@ -1724,12 +1703,6 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 const bool hot = (e[j] & LS_HOT_BIT) != 0;
                 gv[j] = 0.0;
                 if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
-            }
-        } else if (H16) {
-#pragma unroll
-            for (int j = 0; j < ACC_K; j++) {
-                inl[j] = e[j] != LS_PAD;      // every entry is on an LDS-resident column (a padding slot multiplies 0 * 0)
-                gv[j] = 0.0;
             }
         } else if (RND) {
             // packed columns beyond the LDS slots: gathered from the pack; everything else is in LDS
@@ -1768,10 +1741,10 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             // join and waits for all of them (s_waitcnt vmcnt(0)) before this tile's first multiply.
             const int64_t tn = t_next;
             const f64x2_t *vp = (const f64x2_t *)(svals + tn * ACC_TILE);
-            const u32x4_t *ip = H16 ? (const u32x4_t *)((const uint16_t *)sidx + tn * ACC_TILE) : (const u32x4_t *)(sidx + tn * ACC_TILE);
+            const u32x4_t *ip = (const u32x4_t *)(sidx + tn * ACC_TILE);
             // (index words first: the next tile's gathers need them at its very top, the values only at its multiplies)
 #pragma unroll
-            for (int q = 0; q < NIX; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
 #pragma unroll
             for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
             tbn = tile_base[tn];
@@ -1940,7 +1913,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = vn[q];
 #pragma unroll
-        for (int q = 0; q < NIX; q++) ix[q] = ixn[q];
+        for (int q = 0; q < 2; q++) ix[q] = ixn[q];
         tb = __builtin_amdgcn_readfirstlane(tbn);
         if (XGT) {
             cb = __builtin_amdgcn_readfirstlane(cbn);
@@ -2074,8 +2047,7 @@ constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (s
 // with blockIdx % 8 == b % 8.
 template <class P, int VT>
 static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
-                       bool window, int tpw, bool xcd_streams, hipStream_t s, const int32_t *slot_map = nullptr,
-                       int32_t hot_cap = 0)
+                       bool window, int tpw, bool xcd_streams, hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t n = (int32_t)rows.size();
@@ -2086,14 +2058,9 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     DevBuf off, bends;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
     const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
-    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>(),
-                                           slot_map, hot_cap);
+    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
-    if (slot_map) {      // entries were left out: the panel holds what the counts add up to
-        CSRK_HIP(hipMemcpyAsync(&nnz_rows, off.as<int64_t>() + pairs, 8, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-    }
     pn->p64 = nnz_rows > INT32_MAX;
     CSRK_TRY(pn->rp.alloc((size_t)(pairs + 1) * (pn->p64 ? 8 : 4)));
     CSRK_TRY(pn->ci.alloc((size_t)nnz_rows * 4));
@@ -2101,11 +2068,11 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     if (pn->p64)
         panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
                                                           cb, off.as<int64_t>(), pn->rp.as<int64_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>(), slot_map, hot_cap);
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
     else
         panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
                                                           cb, off.as<int64_t>(), pn->rp.as<int32_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>(), slot_map, hot_cap);
+                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
     CSRK_LAUNCH_CHECK();
     // tiles per block (host: nb is at most a few thousand)
     CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
@@ -2153,12 +2120,29 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
         for (size_t i = 0; i < longest; i++)
             for (int q = 0; q < HEAVY_STREAMS; q++) groups.push_back(i < st[q].size() ? st[q][i] : pad);
     }
+    // the tiles' carries per long row (a tile's carry belongs to the pair holding its last, unfinished row end: static)
+    {
+        std::vector<PanelTile> ht((size_t)n_tiles);
+        CSRK_HIP(hipMemcpy(ht.data(), pn->tile.p, (size_t)n_tiles * sizeof(PanelTile), hipMemcpyDeviceToHost));
+        std::vector<int32_t> crp((size_t)n + 1, 0), cidx;
+        for (int64_t t = 0; t < n_tiles; t++)
+            if ((int64_t)ht[(size_t)t].i1 < pairs) crp[(size_t)(ht[(size_t)t].i1 % n) + 1]++;
+        for (int32_t h = 0; h < n; h++) crp[(size_t)h + 1] += crp[(size_t)h];
+        cidx.resize((size_t)crp[(size_t)n] + 1);
+        std::vector<int32_t> cur(crp.begin(), crp.end() - 1);
+        for (int64_t t = 0; t < n_tiles; t++)      // ascending tiles: each row's list comes out in tile order
+            if ((int64_t)ht[(size_t)t].i1 < pairs) cidx[(size_t)cur[(size_t)(ht[(size_t)t].i1 % n)]++] = (int32_t)t;
+        CSRK_TRY(pn->crp.alloc(crp.size() * 4));
+        CSRK_TRY(pn->cidx.alloc(cidx.size() * 4));
+        CSRK_HIP(hipMemcpy(pn->crp.p, crp.data(), crp.size() * 4, hipMemcpyHostToDevice));
+        CSRK_HIP(hipMemcpy(pn->cidx.p, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice));
+    }
     pn->groups = (int64_t)groups.size();
     CSRK_TRY(pn->group.alloc(groups.size() * sizeof(PanelGroup)));
     CSRK_HIP(hipMemcpyAsync(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
     CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
-    CSRK_TRY(pn->y.alloc((size_t)(pairs + n) * 8));      // (+ one more "block": the hot-window stream's row sums, tier 1)
+    CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
     pn->on = true;
     pn->window = window;
@@ -2385,11 +2369,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     return CSRK_OK;
 }
 
-template <class P, int VT>
-static int build_tier1_hot(Matrix *m, SpmvPlan *p, hipStream_t s);
-
-// Build the tiers of the rows build_heavy_split cut out.  Runs after build_hot_cache: tier 1 leaves its entries on the
-// LDS-resident packed columns to a hot-window stream (build_tier1_hot) and keeps the others in the pair panel.
+// Build the tiers of the rows build_heavy_split cut out.
 template <class P>
 static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
 {
@@ -2417,12 +2397,7 @@ static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
             p->acc.push_back(ap);                                                                                  \
             CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
         }                                                                                                          \
-        if (!r1.empty()) {                                                                                         \
-            CSRK_TRY((build_tier1_hot<P, VT>(m, p, s)));                                                           \
-            CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s,                \
-                                         p->t1h.on ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr,         \
-                                         p->t1h.on ? p->t1h_cap : 0)));                                            \
-        }                                                                                                          \
+        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
     } while (0)
     if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
     else if (m->val_type == CSRK_VAL_F32) BUILD(CSRK_VAL_F32);
@@ -2601,8 +2576,6 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
                                  (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_H16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
@@ -2646,13 +2619,14 @@ __device__ __forceinline__ bool ls_is_cold(uint32_t ix) { return !(ix & LS_HOT_B
 
 // per index word: count into the (round, block) bucket; the old count is the entry's place inside the bucket
 __global__ __launch_bounds__(256) void ls_cold_count_kernel(const uint32_t *__restrict__ sidx, int64_t n_words, int32_t nblk, int32_t W,
-                                                           int32_t stage_tiles, int32_t *__restrict__ cnt, int32_t *__restrict__ off)
+                                                           const int32_t *__restrict__ tile_round, int32_t *__restrict__ cnt,
+                                                           int32_t *__restrict__ off)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * stage_tiles);
+    const int64_t r = tile_round[w / ACC_TILE];
     const int32_t b = (int32_t)((ix & LS_COL_MASK) / (uint32_t)W);
     off[w] = atomicAdd(&cnt[r * nblk + b], 1);
 }
@@ -2669,7 +2643,7 @@ __global__ void ls_cold_transpose_kernel(const int32_t *__restrict__ cnt, int32_
 // (block, round) order + place
 // (rel: the index word keeps the position relative to the round's start -- the round-in-LDS form)
 __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
-                                                           int32_t nblk, int32_t W, int32_t stage_tiles, int rel,
+                                                           int32_t nblk, int32_t W, const int32_t *__restrict__ tile_round, int rel,
                                                            const int32_t *__restrict__ base_rb,
                                                            const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
                                                            uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
@@ -2678,7 +2652,7 @@ __global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * stage_tiles);
+    const int64_t r = tile_round[w / ACC_TILE];
     const uint32_t c = ix & LS_COL_MASK;
     const int32_t b = (int32_t)(c / (uint32_t)W);
     const int32_t pos = base_rb[r * nblk + b] + off[w];
@@ -2737,7 +2711,8 @@ __global__ __launch_bounds__(256) void ls_cold_rank_kernel(const uint32_t *__res
 
 // tile-major form of ls_cold_place_kernel: position = the tile's start + the rank; the index word keeps the rank
 __global__ __launch_bounds__(256) void ls_cold_place_tile_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
-                                                                int32_t W, const int32_t *__restrict__ tile_cold,
+                                                                int32_t W, const int32_t *__restrict__ tile_round,
+                                                                const int32_t *__restrict__ tile_cold,
                                                                 const uint16_t *__restrict__ rank,
                                                                 const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
                                                                 uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
@@ -2746,7 +2721,7 @@ __global__ __launch_bounds__(256) void ls_cold_place_tile_kernel(uint32_t *__res
     if (w >= n_words) return;
     const uint32_t ix = sidx[w];
     if (!ls_is_cold(ix)) return;
-    const int64_t r = w / ((int64_t)ACC_TILE * LS_STAGE_TILES);      // (tile-major: always built with LS_STAGE_TILES per round)
+    const int64_t r = tile_round[w / ACC_TILE];
     const uint32_t c = ix & LS_COL_MASK;
     const int32_t b = (int32_t)(c / (uint32_t)W);
     const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
@@ -2835,6 +2810,23 @@ __global__ void ls_pack_place_kernel(const int32_t *__restrict__ hot_cols, int32
 // of tiles (a multiple of the workgroup's wavefronts, at most LS_RND_MAXTILES) whose staged values fit LS_RND_CAP in
 // every round.
 
+// tile_round[t] = the round that holds tile t (round r = tiles round_tile0[r] .. round_tile0[r + 1])
+__global__ void ls_tile_round_kernel(const int32_t *__restrict__ round_tile0, int32_t n_rounds, int64_t n_tiles,
+                                     int32_t *__restrict__ tile_round)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int32_t lo = 0, hi = n_rounds - 1;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo + 1) >> 1);
+        if ((int64_t)round_tile0[mid] <= t)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    tile_round[t] = lo;
+}
+
 __global__ void ls_round_total_kernel(const int64_t *__restrict__ tot, int32_t nround_ls, int32_t nblk, int64_t *__restrict__ out)
 {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2859,12 +2851,16 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     const int64_t nblk_goal = wave_of_wgs * ceil_div((int64_t)m->ncols, wave_of_wgs * LS_STAGE_WMAX);
     const int64_t W = ceil_div(ceil_div((int64_t)m->ncols, nblk_goal), 16) * 16;
     const int64_t nblk = ceil_div((int64_t)m->ncols, W);
-    const int64_t nb_max = (ceil_div(ls->n_tiles, LS_STAGE_TILES) + 1) * nblk;      // (the smallest round has the most buckets)
+    // (the smallest rounds make the most buckets; a balanced layout adds at most one round per workgroup)
+    const int64_t nb_max = (ceil_div(ls->n_tiles, LS_STAGE_TILES < LS_THREADS / WAVE ? LS_STAGE_TILES : LS_THREADS / WAVE) + (int64_t)ls->grid + 2) * nblk;
     if (nb_max < 1 || nb_max > (int64_t)1 << 26) return CSRK_OK;
     size_t mfree = 0, mtotal = 0;
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
     if ((size_t)n_words * 20 + (size_t)nb_max * 16 + (64u << 20) > mfree) return CSRK_OK;
-    DevBuf cnt, cntT, off, offp, tot;
+    if (ls->n_tiles >= INT32_MAX) return CSRK_OK;
+    DevBuf cnt, cntT, off, offp, tot, tile_round, d_rt0;
+    CSRK_TRY(tile_round.alloc((size_t)ls->n_tiles * 4));
+    CSRK_TRY(d_rt0.alloc((size_t)(ls->n_tiles + 2) * 4));
     CSRK_TRY(offp.alloc((size_t)n_hot * 4));
     CSRK_TRY(cnt.alloc((size_t)(nb_max + 1) * 4));
     CSRK_TRY(cntT.alloc((size_t)(nb_max + 1) * 4));
@@ -2874,14 +2870,41 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     int stage_tiles = LS_STAGE_TILES;
     int64_t nround_ls = 0, nround = 0, nb = 0, n_cold = 0;      // n_cold = where the virtual round starts
     // counts per (round, block) bucket for rounds of `nt` tiles; the old count is an entry's place inside its bucket
-    auto count_pass = [&](int nt, int64_t *max_round) -> int {
+    // Rounds of at most `nt` tiles.  balanced: every workgroup of the stream's persistent grid gets an equal share of the
+    // tiles, cut into equal rounds (whole tiles per wavefront); else rounds of `nt` tiles from tile 0 on.
+    std::vector<int32_t> h_rt0, h_wr0;
+    constexpr int NW_ = LS_THREADS / WAVE;
+    auto count_pass = [&](int nt, bool balanced, int64_t *max_round) -> int {
         stage_tiles = nt;
-        nround_ls = ceil_div(ls->n_tiles, nt);
+        h_rt0.clear();
+        h_wr0.clear();
+        if (balanced) {
+            const int64_t G = ls->grid;
+            for (int64_t w = 0; w < G; w++) {
+                const int64_t tb = ls->n_tiles * w / G, te = ls->n_tiles * (w + 1) / G;
+                h_wr0.push_back((int32_t)h_rt0.size());
+                if (te > tb) {
+                    const int64_t k = ceil_div(te - tb, nt);
+                    const int64_t per = ceil_div(ceil_div(te - tb, k), NW_) * NW_;
+                    for (int64_t t = tb; t < te; t += per) h_rt0.push_back((int32_t)t);
+                }
+            }
+            h_wr0.push_back((int32_t)h_rt0.size());
+        } else {
+            for (int64_t t = 0; t < ls->n_tiles; t += nt) h_rt0.push_back((int32_t)t);
+        }
+        nround_ls = (int64_t)h_rt0.size();
+        h_rt0.push_back((int32_t)ls->n_tiles);
         nround = nround_ls + 1;      // + the virtual round of the packed columns
         nb = nround * nblk;
+        if (nb > nb_max) return CSRK_ERR_INVALID;      // (cannot happen: a round holds at least LS_STAGE_TILES or NW tiles)
+        CSRK_HIP(hipMemcpyAsync(d_rt0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
+        ls_tile_round_kernel<<<(unsigned)ceil_div(ls->n_tiles, 256), 256, 0, s>>>(d_rt0.as<int32_t>(), (int32_t)nround_ls, ls->n_tiles,
+                                                                                tile_round.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nb + 1) * 4, s));
-        ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, nt, cnt.as<int32_t>(),
-                                               off.as<int32_t>());
+        ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, tile_round.as<int32_t>(),
+                                               cnt.as<int32_t>(), off.as<int32_t>());
         CSRK_LAUNCH_CHECK();
         // the counts are 32-bit: total them in 64 bits before trusting the 32-bit scans
         CSRK_TRY(exclusive_scan_i32_to_i64(cnt.as<int32_t>(), tot.as<int64_t>(), nround_ls * nblk, s));
@@ -2900,18 +2923,19 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     };
     int64_t max_round = 0;
     if (rnd) {
-        int nt0 = LS_RND_MAXTILES;
-        if (const char *e = getenv("CSRK_LS_RND_TILES")) nt0 = atoi(e) >= LS_STAGE_TILES ? atoi(e) / LS_STAGE_TILES * LS_STAGE_TILES : nt0;
+        constexpr int NW = LS_THREADS / WAVE;      // a round is a whole number of tiles per wavefront
+        int nt0 = LS_RND_MAXTILES / NW * NW;
+        if (const char *e = getenv("CSRK_LS_RND_TILES")) nt0 = atoi(e) >= NW ? atoi(e) / NW * NW : nt0;
         rnd = false;
-        for (int nt = nt0; nt >= LS_STAGE_TILES; nt -= LS_STAGE_TILES) {
-            CSRK_TRY(count_pass(nt, &max_round));
+        for (int nt = nt0; nt >= NW; nt -= NW) {
+            CSRK_TRY(count_pass(nt, true, &max_round));
             if (max_round <= LS_RND_CAP) {
                 rnd = true;
                 break;
             }
         }
     }
-    if (!rnd) CSRK_TRY(count_pass(LS_STAGE_TILES, &max_round));
+    if (!rnd) CSRK_TRY(count_pass(LS_STAGE_TILES, false, &max_round));
     if (nround > INT32_MAX) return CSRK_OK;
     CSRK_HIP(hipMemsetAsync(cnt.as<int32_t>() + nround_ls * nblk, 0, (size_t)(nblk + 1) * 4, s));
     ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
@@ -2944,7 +2968,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         CSRK_LAUNCH_CHECK();
         CSRK_TRY(exclusive_scan_i32(ls->tile_cold.as<int32_t>(), ls->tile_cold.as<int32_t>(), ls->n_tiles, s));
         ls_cold_place_tile_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)W,
-                                                    ls->tile_cold.as<int32_t>(), rank.as<uint16_t>(), cntT.as<int32_t>(),
+                                                    tile_round.as<int32_t>(), ls->tile_cold.as<int32_t>(), rank.as<uint16_t>(), cntT.as<int32_t>(),
                                                     off.as<int32_t>(), ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipStreamSynchronize(s));      // `rank` is freed here
@@ -2955,8 +2979,14 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
                                                                                        ls->round_start.as<int32_t>());
             CSRK_LAUNCH_CHECK();
         }
-        ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W, stage_tiles,
-                                               rnd ? 1 : 0, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
+        if (rnd) {
+            CSRK_TRY(ls->round_tile0.alloc(h_rt0.size() * 4));
+            CSRK_TRY(ls->wg_round0.alloc(h_wr0.size() * 4));
+            CSRK_HIP(hipMemcpyAsync(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
+            CSRK_HIP(hipMemcpyAsync(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, hipMemcpyHostToDevice, s));
+        }
+        ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W,
+                                               tile_round.as<int32_t>(), rnd ? 1 : 0, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
                                                ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
         CSRK_LAUNCH_CHECK();
     }
@@ -3013,130 +3043,6 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
         // (round-in-LDS form: the round's staged values take the place of the hot window's tail)
         if (p->ls.n_cold && p->ls.round_start.p && p->n_hot_lds > LS_RND_HOT) p->n_hot_lds = LS_RND_HOT;
     }
-    return CSRK_OK;
-}
-
-// ---- tier 1, hot-window stream ---------------------------------------------------------------------------------
-// On a power-law matrix the packed columns the light stream keeps in LDS (the n_hot_lds most referenced: 60 % of a
-// Zipf(1) column mass) hold the same share of tier 1's entries.  In the pair panel every one of them costs what a cold
-// entry costs (a gather and a line into L1, ~4.8 ps); here they become a stream of their own whose x values ALL come
-// from LDS: the tier-1 rows' entries on those columns, row after row, in the light stream's tile form with 16-bit index
-// words (bit 15 = first entry of its row, low 15 bits = slot; 0x7fff = padding) -- 10 B per entry, no gather.  Its row
-// sums go to one more "block" of the pair panel's partials (y'[nb][h]), which the tier's ordered reduce adds last.
-
-// one wavefront per tier-1 row: entries on LDS-resident packed columns
-template <class P>
-__global__ __launch_bounds__(256) void t1h_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                       const int32_t *__restrict__ rows, int32_t n,
-                                                       const int32_t *__restrict__ slot_map, int32_t hot_cap,
-                                                       int64_t *__restrict__ cnt)
-{
-    const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (h >= n) return;
-    const int64_t s = rp[rows[h]], e = rp[rows[h] + 1];
-    int c = 0;
-    for (int64_t k = s + lane; k < e; k += WAVE) c += (uint32_t)slot_map[ci[k]] < (uint32_t)hot_cap ? 1 : 0;
-    for (int off = WAVE / 2; off > 0; off >>= 1) c += __shfl_down(c, off, WAVE);
-    if (lane == 0) cnt[h] = c;
-}
-
-// ... copied in storage order into a compact CSR over the tier-1 rows: (slot, float64 value)
-template <class P, int VT>
-__global__ __launch_bounds__(256) void t1h_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                      const void *__restrict__ vs, const int32_t *__restrict__ rows,
-                                                      int32_t n, const int32_t *__restrict__ slot_map, int32_t hot_cap,
-                                                      const int64_t *__restrict__ rph, int32_t *__restrict__ cih,
-                                                      double *__restrict__ vsh)
-{
-    const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (h >= n) return;
-    const int64_t s = rp[rows[h]], e = rp[rows[h] + 1];
-    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
-    int64_t o = rph[h];
-    for (int64_t k0 = s; k0 < e; k0 += WAVE) {
-        const int64_t k = k0 + lane;
-        int32_t sl = -1;
-        if (k < e) sl = slot_map[ci[k]];
-        const bool hot = (uint32_t)sl < (uint32_t)hot_cap;
-        const unsigned long long mk = __ballot(hot);
-        if (hot) {
-            const int64_t q = o + __popcll(mk & below);
-            cih[q] = sl;
-            vsh[q] = ValLoad<VT>::at(vs, k);
-        }
-        o += __popcll(mk);
-    }
-}
-
-// the stream's 32-bit index words (build_stream) -> 16-bit words in logical order (lane l of a tile reads the eight words
-// of its entries with one 16-B load)
-__global__ __launch_bounds__(256) void ls_idx16_kernel(const uint32_t *__restrict__ sidx, int64_t n_slots,
-                                                      uint16_t *__restrict__ out)
-{
-    const int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= n_slots) return;
-    const uint32_t ix = sidx[(L / ACC_TILE) * ACC_TILE + acc_idx_slot((int)(L % ACC_TILE))];
-    const uint32_t c = ix & LS_COL_MASK;
-    out[L] = (uint16_t)(c == LS_PAD ? LS16_PAD : (c | ((ix & LS_START_BIT) ? LS16_START : 0u)));
-}
-
-template <class P, int VT>
-static int build_tier1_hot(Matrix *m, SpmvPlan *p, hipStream_t s)
-{
-    p->t1h.on = false;
-    const char *env = getenv("CSRK_SPMV_T1H");
-    if (!(env && env[0] == '1')) return CSRK_OK;
-    const int32_t n = (int32_t)p->t1_rows.size();
-    const int32_t cap = p->n_hot_lds;
-    p->t1h_cap = cap;
-    // needs the pack (filled per call by the staging pass or hot_pack_kernel) and slots that fit 15 bits
-    if (n < 1 || !p->n_hot || cap < 1 || cap >= (int32_t)LS16_PAD || !p->hot_slot.p) return CSRK_OK;
-    const P *rp = (const P *)m->d_rowptrs;
-    DevBuf rows, rph, cih, vsh;
-    CSRK_TRY(rows.alloc((size_t)n * 4));
-    CSRK_TRY(rph.alloc((size_t)(n + 2) * 8));
-    CSRK_HIP(hipMemcpyAsync(rows.p, p->t1_rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    const unsigned gw = (unsigned)ceil_div((int64_t)n * WAVE, 256);
-    t1h_count_kernel<P><<<gw, 256, 0, s>>>(rp, m->d_colinds, rows.as<int32_t>(), n, p->hot_slot.as<int32_t>(), cap,
-                                          rph.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(rph.as<int64_t>(), rph.as<int64_t>(), n, s));
-    int64_t n_hot_ent = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_hot_ent, rph.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    // worth a launch of its own only when a good part of the tier is on those columns
-    if (n_hot_ent * 8 < p->t1_nnz && !(env && env[0] == '1')) return CSRK_OK;
-    if (n_hot_ent < 1) return CSRK_OK;
-    const int64_t n_tiles = ceil_div(n_hot_ent, ACC_TILE);
-    size_t mfree = 0, mtotal = 0;
-    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if ((size_t)n_hot_ent * 12 + (size_t)n_tiles * ACC_TILE * 14 + (64u << 20) > mfree) return CSRK_OK;
-    CSRK_TRY(cih.alloc((size_t)n_hot_ent * 4));
-    CSRK_TRY(vsh.alloc((size_t)n_hot_ent * 8));
-    t1h_fill_kernel<P, VT><<<gw, 256, 0, s>>>(rp, m->d_colinds, m->d_values, rows.as<int32_t>(), n,
-                                              p->hot_slot.as<int32_t>(), cap, rph.as<int64_t>(), cih.as<int32_t>(),
-                                              vsh.as<double>());
-    CSRK_LAUNCH_CHECK();
-    LsSegs sg;
-    sg.n = 1;
-    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles * ACC_TILE, sg.ent0[k] = n_hot_ent;
-    sg.slot0[0] = 0;
-    sg.ent0[0] = 0;
-    CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1h, rph.as<int64_t>(), rph.as<int64_t>(), n, cih.as<int32_t>(), vsh.p,
-                                                   sg, n_tiles, nullptr, n, nullptr, s)));
-    if (!p->t1h.on) return CSRK_OK;
-    p->t1h_nnz = n_hot_ent;
-    DevBuf i16;
-    CSRK_TRY(i16.alloc((size_t)n_tiles * ACC_TILE * 2));
-    ls_idx16_kernel<<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(p->t1h.idx.as<uint32_t>(), n_tiles * ACC_TILE,
-                                                                              i16.as<uint16_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipStreamSynchronize(s));      // the temporaries and the 32-bit words are freed here
-    p->t1h.idx.release();
-    p->t1h.idx.bytes = i16.bytes;
-    p->t1h.idx.p = i16.take();
     return CSRK_OK;
 }
 
@@ -3304,14 +3210,6 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
             tr.lap("hot-column census + pack");
             CSRK_TRY(build_tiers<P>(m, p, s));
             tr.lap("tiers");
-            const char *ax = getenv("CSRK_SPMV_AUX");
-            // (measured on the headline matrix: 0.753 ms with the auxiliary stream, 0.727 without -- the event
-            // hand-overs cost more than the overlap of ~25 us of small kernels gains; off unless CSRK_SPMV_AUX=1)
-            if ((p->n_heavy || p->n_hot) && ax && ax[0] == '1') {
-                CSRK_HIP(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-                for (hipEvent_t *e : {&p->ev_fork, &p->ev_pack, &p->ev_aux, &p->ev_tier[0], &p->ev_tier[1]})
-                    CSRK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-            }
             CSRK_TRY(build_tier1_stream(m, p, s));
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
@@ -3410,49 +3308,49 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     if (algo != CSRK_SPMV_MERGE && !do_light) return CSRK_OK;      // no tiers outside the merge algorithm
     switch (algo) {
     case CSRK_SPMV_MERGE: {
-        // Small kernels that do not depend on the big ones' results -- the hot-column pack (needs only x),
-        // the tier-1 carry fix-up and first reduce (need only the tier-1 kernel) -- run on the plan's auxiliary
-        // stream beside the streaming kernels; everything that writes y stays in order on `s`.
-        const bool aux = p->aux != nullptr;
-        hipStream_t sa = aux ? p->aux : s;
-        // epilogue jobs, launched together at the end (immediately and separately with the auxiliary stream)
-        FixJobs fix;
-        RedJobs red;
-        fix.n = red.n = 0;
-        auto flush_fix = [&]() -> int {
-            if (fix.n == 0) return CSRK_OK;
+        // epilogue jobs, one launch at the end
+        EpiJobs epi;
+        epi.n = 0;
+        auto flush_epi = [&]() -> int {
+            if (epi.n == 0) return CSRK_OK;
             unsigned g = 0;
-            for (int i = 0; i < fix.n; i++) g += (unsigned)fix.j[i].blocks;
-            spmv_fixup_multi_kernel<<<g, 256, 0, s>>>(fix);
+            for (int i = 0; i < epi.n; i++) g += (unsigned)epi.j[i].blocks;
+            spmv_epilogue_kernel<<<g, EPI_THREADS, 0, s>>>(epi, d_y);
             CSRK_LAUNCH_CHECK();
-            fix.n = 0;
+            epi.n = 0;
             return CSRK_OK;
         };
         auto add_fix = [&](const int32_t *cr, const double *cv, int64_t n, double *yy) -> int {
             if (n <= 0) return CSRK_OK;
-            if (fix.n == 4) CSRK_TRY(flush_fix());
-            fix.j[fix.n++] = FixJob{cr, cv, n, yy, (int32_t)ceil_div(n, 256)};
+            if (epi.n == 6) CSRK_TRY(flush_epi());
+            EpiJob J = {};
+            J.kind = 0;
+            J.blocks = (int32_t)ceil_div(n, EPI_THREADS);
+            J.carry_row = cr;
+            J.carry_val = cv;
+            J.n = n;
+            J.fy = yy;
+            epi.j[epi.n++] = J;
             return CSRK_OK;
         };
-        auto flush_red = [&]() -> int {
-            if (red.n == 0) return CSRK_OK;
-            unsigned g = 0;
-            for (int i = 0; i < red.n; i++) g += (unsigned)red.j[i].blocks;
-            acc_reduce_multi_kernel<<<g, 1024, 0, s>>>(red, d_y);
-            CSRK_LAUNCH_CHECK();
-            red.n = 0;
-            return CSRK_OK;
-        };
-        auto add_red = [&](const double *part, const int32_t *rows, int32_t H, int32_t n_wg) -> int {
+        auto add_red = [&](const double *part, const int32_t *rows, int32_t H, int32_t n_wg, int G, const int32_t *crp,
+                           const int32_t *cidx, const double *cval) -> int {
             if (H <= 0) return CSRK_OK;
-            if (red.n == 4) CSRK_TRY(flush_red());
-            red.j[red.n++] = RedJob{part, rows, H, n_wg, (int32_t)ceil_div(H, WAVE)};
+            if (epi.n == 6) CSRK_TRY(flush_epi());
+            EpiJob J = {};
+            J.kind = 1;
+            J.blocks = (int32_t)ceil_div(H, WAVE * (EPI_THREADS / WAVE / G));
+            J.partial = part;
+            J.row_list = rows;
+            J.H = H;
+            J.n_wg = n_wg;
+            J.G = G;
+            J.crp = crp;
+            J.cidx = cidx;
+            J.cval = cval;
+            epi.j[epi.n++] = J;
             return CSRK_OK;
         };
-        if (aux) {
-            CSRK_HIP(hipEventRecord(p->ev_fork, s));
-            CSRK_HIP(hipStreamWaitEvent(sa, p->ev_fork, 0));
-        }
         // cold staging (ls_stage_kernel) fills xg and the pack; it runs first, so that the x it has just read is still in
         // the Infinity Cache when the accumulator kernel fetches its windows
         static const bool stage_first = [] { const char *e = getenv("CSRK_LS_STAGE_FIRST"); return !(e && e[0] == '0'); }();
@@ -3468,10 +3366,9 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         };
         if (do_light && p->ls.on && p->ls.n_cold && stage_first) CSRK_TRY(launch_stage());
         if (do_light && p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
-            hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, sa>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
-                                                                             p->xh.as<double>());
+            hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
+                                                                            p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
-            if (aux) CSRK_HIP(hipEventRecord(p->ev_pack, sa));
         }
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
@@ -3482,26 +3379,6 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 CSRK_LAUNCH_CHECK();
             }
             kh.stop();
-        }
-        if (do_heavy && p->n_heavy && p->t1h.on && p->tier[1].on) {
-            // tier 1's entries on the LDS-resident packed columns: hot-window stream -> the extra block of the pair partials.
-            // Reads the pack: filled by the staging pass / hot_pack_kernel of this product's short-row part (a product
-            // launched in two parts runs part 1 first: csrk_spmv_device_part).
-            if (aux && p->n_hot && do_light) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
-            constexpr size_t h_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-            LightStream &t = p->t1h;
-            Panel *pn = &p->tier[1];
-            double *y1h = pn->y.as<double>() + pn->rows;
-            KernelTimer kh(p, s, 2);
-            spmv_lstream_kernel<LS_H16><<<t.grid, LS_THREADS, h_lds, s>>>(
-                t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
-                (const int32_t *)nullptr, d_x,
-                (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(), p->t1h_cap,
-                t.n_tiles, t.n_runs, t.n_out, y1h, t.carry_row.as<int32_t>(), t.carry_val.as<double>(),
-                (const int32_t *)nullptr, 0);
-            kh.stop();
-            CSRK_LAUNCH_CHECK();
-            CSRK_TRY(add_fix(t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, y1h));
         }
         for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
@@ -3515,16 +3392,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                     t.carry_idx.as<int32_t>(), d_x,
                     (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(),
                     p->n_hot ? p->n_hot_lds : 0, t.n_tiles, t.n_runs, t.n_out,
-                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr, 0);
+                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr,
+                    (const int32_t *)nullptr, (const int32_t *)nullptr);
                 kh.stop();
                 CSRK_LAUNCH_CHECK();
-                if (aux) {
-                    spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, sa>>>(
-                        t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
-                    CSRK_LAUNCH_CHECK();
-                } else {
-                    CSRK_TRY(add_fix(t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>()));
-                }
+                // (the stream form's carries go into the pair partials before the reduce reads them: a launch of their own)
+                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, s>>>(
+                    t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
+                CSRK_LAUNCH_CHECK();
                 continue;
             }
             KernelTimer kh(p, s, 1 + q);
@@ -3543,17 +3418,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
-            if (aux) {
-                CSRK_HIP(hipEventRecord(p->ev_tier[q], s));
-                CSRK_HIP(hipStreamWaitEvent(sa, p->ev_tier[q], 0));
-                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(pn->tiles, 256), 256, 0, sa>>>(
-                    pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>());
-                CSRK_LAUNCH_CHECK();
-            } else {
-                CSRK_TRY(add_fix(pn->carry_row.as<int32_t>(), pn->carry_val.as<double>(), pn->tiles, pn->y.as<double>()));
-            }
+            // (the pair kernel's carries are added by the tier's reduce: Panel::crp)
         }
-        if (aux && p->n_hot && do_light) CSRK_HIP(hipStreamWaitEvent(s, p->ev_pack, 0));
         if (do_light) {
 #define MERGE_ARGS_LIGHT(CI)                                                                                        \
     p->rp_light.as<P>(), CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, p->nnz_light,                \
@@ -3579,11 +3445,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 if (p->ls.n_cold && p->ls.round_start.p) {
                     constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                     spmv_lstream_kernel<LS_RND><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(LS_ARGS, p->ls.round_start.as<int32_t>(),
-                                                                                          p->ls.stage_tiles);
+                                                                                          p->ls.round_tile0.as<int32_t>(),
+                                                                                          p->ls.wg_round0.as<int32_t>());
                 } else if (p->ls.n_cold && p->ls.tile_cold.p)
-                    spmv_lstream_kernel<LS_XGT><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), 0);
+                    spmv_lstream_kernel<LS_XGT><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), (const int32_t *)nullptr,
+                                                                                          (const int32_t *)nullptr);
                 else
-                    spmv_lstream_kernel<LS_PLAIN><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, (const int32_t *)nullptr, 0);
+                    spmv_lstream_kernel<LS_PLAIN><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                                                                                            (const int32_t *)nullptr);
 #undef LS_ARGS
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
@@ -3618,22 +3487,19 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_LAUNCH_CHECK();
             }
         }
-        if (aux) {      // join: the reduces below read what the auxiliary stream produced
-            CSRK_HIP(hipEventRecord(p->ev_aux, sa));
-            CSRK_HIP(hipStreamWaitEvent(s, p->ev_aux, 0));
-        }
-        CSRK_TRY(flush_fix());      // the carries of the light stream and of the tiers, one launch
         if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
-                CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg));
+                CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 16, nullptr, nullptr, nullptr));
         for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
             // y[row] = sum over column blocks of the (block, row) partials, in block order
-            // (tier 1 with a hot-window stream: one more block, the stream's row sums)
-            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb + (q == 1 && p->t1h.on ? 1 : 0)));
+            const bool stream_form = q == 1 && p->t1s.on;      // (its carries are in the partials already)
+            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb, pn->nb > 64 ? 16 : 2,
+                             stream_form ? nullptr : pn->crp.as<int32_t>(), stream_form ? nullptr : pn->cidx.as<int32_t>(),
+                             stream_form ? nullptr : pn->carry_val.as<double>()));
         }
-        CSRK_TRY(flush_red());      // the ordered reduces of the tiers, one launch
+        CSRK_TRY(flush_epi());      // the light stream's carries and the ordered reduces of the tiers, one launch
         break;
     }
     case CSRK_SPMV_VECTOR: {
@@ -3987,16 +3853,17 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
                                 &p->heavy_row, &p->ci_hot, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
             add(*b);
         for (const Panel &t : p->tier)
-            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y}) add(*b);
+            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx})
+                add(*b);
         for (const AccPanel *ap : p->acc)
             for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
-        for (const LightStream *l : {&p->ls, &p->t1s, &p->t1h})
+        for (const LightStream *l : {&p->ls, &p->t1s})
             for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
-                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold})
+                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold, &l->round_start, &l->round_tile0, &l->wg_round0})
                 add(*b);
     }
-    // [26] tier-1 entries served by the hot-window stream, [27] tiles per staging round when the round is held in LDS (else 0)
-    const int64_t v[28] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    // [26] tiles per staging round when the round is held in LDS (else 0)
+    const int64_t v[27] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
@@ -4004,8 +3871,8 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
                            p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
-                           p->t1h.on ? p->t1h_nnz : 0, p->ls.round_start.p ? p->ls.stage_tiles : 0};
-    for (int i = 0; i < n && i < 28; i++) out[i] = v[i];
+                           p->ls.round_start.p ? p->ls.stage_tiles : 0};
+    for (int i = 0; i < n && i < 27; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

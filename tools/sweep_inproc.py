@@ -52,8 +52,8 @@ for cfg in sys.argv[1:] or ['']:
     ms = (time.perf_counter() - t0) / steps * 1e3
     nrec, k4 = C.c_int(0), (C.c_float * 4)()
     check(lib.csrk_spmv_profile_end4(h, C.byref(nrec), k4))
-    st = (C.c_int64 * 28)()
-    check(lib.csrk_spmv_plan_stats(h, st, 28))
+    st = (C.c_int64 * 27)()
+    check(lib.csrk_spmv_plan_stats(h, st, 27))
     same = None
     if ref is None:
         ref = y.clone()
@@ -62,6 +62,6 @@ for cfg in sys.argv[1:] or ['']:
         if not same:
             same = f'maxdiff {float((ref - y).abs().max()):.3e}'
     print(f'[{cfg or "defaults"}] {ms:.4f} ms/step  light {k4[0]:.4f} acc {k4[1]:.4f} t1 {k4[2]:.4f} stage {k4[3]:.4f} | '
-          f'pack {int(st[16])} cold {int(st[24])} t0 {int(st[10])} t1 {int(st[13])} t1h {int(st[26])} light {int(st[3])} | plan+first {plan_s*1e3:.0f} ms | same_bits {same}',
+          f'pack {int(st[16])} cold {int(st[24])} t0 {int(st[10])} t1 {int(st[13])} light {int(st[3])} round {int(st[26])} | plan+first {plan_s*1e3:.0f} ms | same_bits {same}',
           flush=True)
     check(lib.csrk_free(h))
