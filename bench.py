@@ -65,6 +65,9 @@ def parse():
                          '(each builds extra per-chunk plans); default: allgather, allgatherv, p2p-split')
     ap.add_argument('--calibrate-seconds', type=float, default=20.0,
                     help='N > 1: a candidate whose build + 3 untimed steps take longer than this is dropped')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the N > 1 code path (process group on RCCL, exchange candidates, completeness checks) whatever N is: '
+                         'with --gpus 1 it is the one-rank rehearsal of the multi-GPU run (tests/test_gpu_fullsize.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
@@ -72,7 +75,7 @@ def parse():
 
 
 def load_traffic(path, workload, kernel):
-    "per-launch HBM bytes of `kernel` from a committed PMC summary, or None"
+    "(per-launch HBM bytes of `kernel`, the file they come from) from a committed PMC summary, or (None, None)"
     cands = [path] if path else []
     pdir = os.path.join(ROOT, 'profiles')
     if os.path.isdir(pdir):
@@ -84,10 +87,10 @@ def load_traffic(path, workload, kernel):
                 d = json.load(f)
             key = kernel
             if d.get('workload') == workload and key in d.get('hbm_bytes_per_launch', {}):
-                return float(d['hbm_bytes_per_launch'][key])
+                return float(d['hbm_bytes_per_launch'][key]), os.path.relpath(p, ROOT)
         except (OSError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def _visible_gpus():
@@ -166,8 +169,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     check(lib.csrk_set_device(dev_index))
-    if world > 1:
+    distd = world > 1 or args.force_dist      # the row-partitioned path with its exchange step
+    if distd:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:           # (--force-dist without a launcher: one rank, any free port)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         import datetime
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -196,7 +205,7 @@ def main():
     check(lib.csrk_set_spmv_algo(h, algo_code))
 
     def barrier():
-        if world > 1:
+        if distd:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -253,9 +262,9 @@ def main():
 
     def make_op(name):
         "-> (operator, handles it owns)"
-        if world == 1 or name in ('allgather', 'allgatherv', 'allreduce'):
+        if not distd or name in ('allgather', 'allgatherv', 'allreduce'):
             return RowPartitionedSpMV(shard['bounds'], rank, world, local, dev,
-                                      mode=name if world > 1 else 'allgather'), []
+                                      mode=name if distd else 'allgather'), []
         if name == 'p2p-split':
             run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
             return SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
@@ -272,7 +281,7 @@ def main():
                                            exchange=exch), hs
 
     calibration = None
-    if world > 1 and args.collective == 'auto':
+    if distd and args.collective == 'auto':
         # measure, don't guess: the exchange is bound by the point-to-point links and by how well RCCL drives them,
         # which a 1-GPU box cannot show.  Every candidate runs 3 untimed steps (its chunk handles build their
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
@@ -340,7 +349,7 @@ def main():
         collective, op, op_handles = best
         del ref_sum
     else:
-        collective = args.collective if world > 1 else 'none'
+        collective = args.collective if distd else 'none'
         if collective == 'auto':
             collective = 'none'
         op, op_handles = make_op(collective)
@@ -356,7 +365,7 @@ def main():
             every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)      # (event pairs cost ~3 us each on the stream)
             check(lib.csrk_spmv_profile_every(hp, every))
             check(lib.csrk_spmv_profile_begin(hp, args.steps // every + 2))
-        op.timing = world > 1
+        op.timing = distd
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = op.step(x)
@@ -367,7 +376,7 @@ def main():
             check(lib.csrk_spmv_profile_end4(hp, C.byref(n_rec), k_ms2))
         compute_ms = None
         exchange_ok = None
-        if world == 1:
+        if not distd:
             break
         # every rank must hold the same complete y: the wrapping int64 sum of the bit patterns of a rank's own slice,
         # summed over ranks, equals that of the whole vector on every rank (order-independent, exact)
@@ -446,13 +455,15 @@ def main():
                         'light stream\'s order through LDS windows (overhead pass)', 'ms': k_ms2[3], 'entries': int(st[24]),
                         'algorithmic_bytes': 0, 'stream_bytes': (int(st[24]) + int(st[16])) * 14 + ncols * 8})
     traffic_all = {}
+    traffic_src = None
     for k in kernels:
         k['achieved_gbs'] = round(k['algorithmic_bytes'] / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
         k['stream_gbs'] = round(k['stream_bytes'] / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
         k['ms'] = round(k['ms'], 4)
-        tr = load_traffic(args.traffic_json, workload, k['kernel']) if world == 1 else None
+        tr, src = load_traffic(args.traffic_json, workload, k['kernel']) if world == 1 else (None, None)
         k['traffic'] = tr
         if tr:
+            traffic_src = src
             traffic_all[k['kernel']] = tr
             k['traffic_gbs'] = round(tr / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
             k['traffic_over_algorithmic'] = round(tr / k['algorithmic_bytes'], 3) if k['algorithmic_bytes'] else None
@@ -466,6 +477,10 @@ def main():
         'bound': 'hbm', 'kernel': dom['kernel'], 'role': dom['role'], 'achieved': dom['achieved_gbs'], 'peak': HBM_PEAK_GBS,
         'unit': 'GB/s', 'frac': round(dom['achieved_gbs'] / HBM_PEAK_GBS, 4),
         'traffic': dom['traffic'],
+        # where `traffic` comes from: HBM counters cannot be read inside this run; they are the per-launch means of separate
+        # rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh), committed under profiles/
+        'traffic_source': (traffic_src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)')
+                          if dom['traffic'] else None,
         'kernel_ms': dom['ms'], 'launches_timed': n_rec.value, 'algorithmic_bytes': dom['algorithmic_bytes'],
         # the same kernel priced by the bytes its private stream holds and by the counter traffic: neither can exceed
         # the copy rate (6.29 TB/s measured, MI355X_MICROARCH.md) by much; the algorithmic rate above can, when the
@@ -522,7 +537,17 @@ def main():
         out['multi_gpu'] = {'exchange': collective, 'fallback': fallback_note, 'y_complete_and_identical_on_every_rank': exchange_ok, 'candidates_ms_per_step': calibration,
                             'local_spmv_ms_max_over_ranks': round(compute_ms, 4),
                             'exchange_ms': round(ms_per_step - compute_ms, 4),
-                            'kernel_only_gflops': round(2.0 * nnz / (compute_ms * 1e-3) / 1e9, 1) if compute_ms > 0 else None}
+                            'kernel_only_gflops': round(2.0 * nnz / (compute_ms * 1e-3) / 1e9, 1) if compute_ms > 0 else None,
+                            # kernel-only and end-to-end rates side by side (the driver computes
+                            # the scaling efficiency itself from `value` at each N; these are the two numerators)
+                            'end_to_end_gflops': round(gflops, 1),
+                            'backend': dist.get_backend() if distd else None}
+        if world == 1:
+            # one-rank rehearsal: the exchanged y must be the plain product, bit for bit
+            y_plain = torch.empty_like(y)
+            local(x, y_plain[:n_loc])
+            torch.cuda.synchronize()
+            out['multi_gpu']['y_equals_plain_product_bitwise'] = bool(torch.equal(y.view(torch.int64), y_plain.view(torch.int64)))
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O       # the checker / baseline, never the thing measured above
@@ -590,7 +615,7 @@ def main():
     for hc in op_handles:
         check(lib.csrk_free(hc))
     check(lib.csrk_free(h))
-    if world > 1:
+    if distd:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     'csrk_create': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_create_device': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_free': (_int, [handle_t]),
+    'csrk_device_bytes': (_int, [handle_t, C.POINTER(_i64)]),
     'csrk_info': (_int, [handle_t, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64),
                          C.POINTER(_int), C.POINTER(_int)]),
     'csrk_export': (_int, [handle_t, _vp, _vp, _vp]),

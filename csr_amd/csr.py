@@ -11,6 +11,7 @@ Layout rules kept verbatim (csr/csr.py:79-100): rowptrs int32 when nnz <= INT32_
 int64; colinds int32; values any float dtype or None; all C-contiguous.
 """
 import logging
+import sys
 
 import numpy as np
 
@@ -48,27 +49,41 @@ class CSR:
         self.colinds = cis
         self._values = vs
 
+    # While a device copy of this matrix is cached (csr_amd/kernels/hip.py, handle cache) its three arrays are
+    # write-protected; every method here that changes them calls _edited() first.
+    __csrk_cacheable__ = True
+
+    def _edited(self):
+        "the arrays are about to change: drop cached device copies (restores the arrays' writeable flags)"
+        from . import kernels as _k
+        mods = list(_k.kernels.values())
+        hip = sys.modules.get(_k.__name__ + '.hip')       # (loaded but not yet looked up through the registry)
+        if hip is not None and hip not in mods:
+            mods.append(hip)
+        for kern in mods:
+            inv = getattr(kern, 'invalidate', None)
+            if inv is not None:
+                inv(self)
+
     # ---- construction ---------------------------------------------------------------------
     @classmethod
     def empty(cls, nrows, ncols, row_nnzs=None, values=True):
-        "csr/csr.py:102-136"
-        assert nrows >= 0 and ncols >= 0
-        if row_nnzs is None:
-            return cls(nrows, ncols, 0, np.zeros(nrows + 1, dtype=np.intc), np.zeros(0, dtype=np.intc),
-                       np.zeros(0))
-        assert len(row_nnzs) == nrows
-        nnz = int(np.sum(row_nnzs, dtype=np.int64))
-        rp_dtype = np.intc if nnz <= INTC.max else np.int64
-        rps = np.zeros(nrows + 1, dtype=rp_dtype)
-        np.cumsum(row_nnzs, dtype=rp_dtype, out=rps[1:])
-        cis = np.zeros(nnz, dtype=np.int32)
-        if values is True:
-            vs = np.zeros(nnz)
-        elif values:
-            vs = np.zeros(nnz, dtype=values)
-        else:
+        """
+        A matrix of the given shape with zeroed arrays: no entries, or (row_nnzs) room for that many per row;
+        `values`: True = float64, a dtype, or False = structure only.  (csr/csr.py:102-136 is the counterpart.)
+        """
+        if nrows < 0 or ncols < 0:
+            raise ValueError('negative shape')
+        counts = np.zeros(nrows, dtype=np.int64) if row_nnzs is None else np.asarray(row_nnzs, dtype=np.int64)
+        if counts.shape != (nrows,):
+            raise ValueError('row_nnzs must have one count per row')
+        rps = np.concatenate(([0], np.cumsum(counts)))
+        nnz = int(rps[-1])
+        if not values:
             vs = None
-        return cls(nrows, ncols, nnz, rps, cis, vs)
+        else:
+            vs = np.zeros(nnz, dtype=np.float64 if values is True else values)
+        return cls(nrows, ncols, nnz, rps, np.zeros(nnz, dtype=np.intc), vs)
 
     @classmethod
     def from_coo(cls, rows, cols, vals, shape=None):
@@ -94,27 +109,6 @@ class CSR:
         np.cumsum(np.bincount(rows, minlength=nrows), out=rps[1:])
         return cls(nrows, ncols, nnz, rps, cols[order], None if vals is None else np.asarray(vals)[order])
 
-    @classmethod
-    def from_scipy(cls, mat, copy=True):
-        "csr/csr.py:171-192"
-        import scipy.sparse as sps
-        if not sps.isspmatrix_csr(mat):
-            mat = mat.tocsr(copy=copy)
-        rp = np.require(mat.indptr, np.intc, 'C')
-        cs = np.require(mat.indices, np.intc, 'C')
-        vs = mat.data
-        if copy:
-            rp, cs, vs = rp.copy(), cs.copy(), vs.copy()
-        return cls(mat.shape[0], mat.shape[1], mat.nnz, rp, cs, vs)
-
-    def to_scipy(self):
-        "csr/csr.py:194-209"
-        import scipy.sparse as sps
-        values = self.values
-        if values is None:
-            values = np.full(self.nnz, 1.0)
-        return sps.csr_matrix((values, self.colinds, self.rowptrs), shape=(self.nrows, self.ncols))
-
     # ---- fields ---------------------------------------------------------------------------
     @property
     def values(self):
@@ -122,23 +116,14 @@ class CSR:
 
     @values.setter
     def values(self, vs):
-        "csr/csr.py:224-242"
+        "replace the value array (None = structure only); a longer array is cut to nnz (csr/csr.py:224-242)"
         if vs is not None:
-            if len(vs) < self.nnz:
+            vs = np.ascontiguousarray(vs)
+            if vs.shape[0] < self.nnz:
                 raise ValueError('value array too small')
-            elif len(vs) > self.nnz:
-                vs = vs[:self.nnz]
-            vs = np.require(vs, requirements='C')
+            vs = vs[:self.nnz]
+        self._edited()
         self._values = vs
-
-    def copy(self, include_values=True, *, copy_structure=True):
-        "csr/csr.py:298-321"
-        values = self.values
-        values = np.copy(values) if include_values and values is not None else None
-        rps, cis = self.rowptrs, self.colinds
-        if copy_structure:
-            rps, cis = np.copy(rps), np.copy(cis)
-        return CSR(self.nrows, self.ncols, self.nnz, rps, cis, values)
 
     # ---- rows -----------------------------------------------------------------------------
     def row_extent(self, row):
@@ -148,27 +133,6 @@ class CSR:
     def row_nnzs(self):
         "csr/csr.py:432-441.  Host diff like the reference; the device version is kernel.row_nnzs."
         return np.diff(self.rowptrs)
-
-    def row_cs(self, row):
-        sp, ep = self.row_extent(row)
-        return self.colinds[sp:ep]
-
-    def row_vs(self, row):
-        sp, ep = self.row_extent(row)
-        if self.values is None:
-            return np.full(ep - sp, 1.0)
-        return self.values[sp:ep]
-
-    def row(self, row):
-        "csr/csr.py:370-386 (single row only): dense copy of one row"
-        sp, ep = self.row_extent(row)
-        if self.values is None:
-            v = np.zeros(self.ncols, dtype=np.float32)
-            v[self.colinds[sp:ep]] = 1
-        else:
-            v = np.zeros(self.ncols, dtype=self.values.dtype)
-            v[self.colinds[sp:ep]] = self.values[sp:ep]
-        return v
 
     def subset_rows(self, begin, end):
         "csr/csr.py:331-346 -> csr/structure.py:70-81: views of colinds/values, rebased pointers"
@@ -220,7 +184,9 @@ class CSR:
         K, fn = self._ext('center_rows' if normalization == 'center' else 'unit_rows')
         with releasing(K.to_handle(self), K) as h:
             stat = fn(h)
-            self._values[...] = K.values_of(h)
+            vs = K.values_of(h)
+        self._edited()
+        self._values[...] = vs
         return stat
 
     def sort_rows(self):
@@ -229,6 +195,7 @@ class CSR:
         with releasing(K.to_handle(self), K) as h:
             K.order_columns(h)
             out = K.from_handle(h)
+        self._edited()
         self.colinds[...] = out.colinds
         if self._values is not None:
             self._values[...] = out.values
@@ -287,6 +254,7 @@ class CSR:
         if self.values is None:
             return
         keep = self.values != 0
+        self._edited()
         cum = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
         self.rowptrs = cum[self.rowptrs].astype(self.rowptrs.dtype)
         self.colinds = np.ascontiguousarray(self.colinds[keep])

@@ -130,6 +130,8 @@ Matrix *from_handle(csrk_handle_t h);          // nullptr (and error set) if inv
 inline csrk_handle_t to_handle(Matrix *m) { return reinterpret_cast<csrk_handle_t>(m); }
 void free_spmv_plan(SpmvPlan *p);
 void free_spmm_plan(SpmmPlan *p);
+int64_t spmv_plan_bytes(const SpmvPlan *p);     // device memory a plan holds
+int64_t spmm_plan_bytes(const SpmmPlan *p);
 // Drop the handle's SpMV / SpMM plans (they hold re-ordered COPIES of colinds and values, so every operation
 // that changes the matrix in place -- unit_rows, center_rows, order_columns -- must call this).  Waits for the
 // device first: a launch may still be reading the plan.  Caller holds m->mu.

@@ -321,7 +321,10 @@ int csrk_free(csrk_handle_t h)
     if (!m) return CSRK_ERR_INVALID;
     // launches on a caller's (possibly non-blocking) stream may still be reading the arrays and plans that
     // ~Matrix hands back to the caching allocator, whose next user runs in default-stream order
-    drain_user_streams(m);
+    {
+        std::lock_guard<std::mutex> lk(m->mu);      // an operation in flight on another thread finishes its launch group first
+        drain_user_streams(m);
+    }
     delete m;
     return CSRK_OK;
 }
@@ -335,6 +338,19 @@ int csrk_info(csrk_handle_t h, int32_t *nrows, int32_t *ncols, int64_t *nnz, int
     if (nnz) *nnz = m->nnz;
     if (ptr_is_64) *ptr_is_64 = m->ptr64;
     if (val_type) *val_type = m->val_type;
+    return CSRK_OK;
+}
+
+int csrk_device_bytes(csrk_handle_t h, int64_t *bytes)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(bytes, "bytes is NULL");
+    std::lock_guard<std::mutex> lk(m->mu);
+    int64_t b = (int64_t)((size_t)(m->nrows + 1) * m->ptr_bytes() + (size_t)m->nnz * 4 + (size_t)m->nnz * m->val_bytes());
+    if (m->spmv_plan) b += spmv_plan_bytes(m->spmv_plan);
+    if (m->spmm_plan) b += spmm_plan_bytes(m->spmm_plan);
+    *bytes = b;
     return CSRK_OK;
 }
 

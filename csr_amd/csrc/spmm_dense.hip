@@ -59,6 +59,13 @@ struct SpmmPlan {
 };
 
 void free_spmm_plan(SpmmPlan *p) { delete p; }
+int64_t spmm_plan_bytes(const SpmmPlan *p)
+{
+    int64_t b = 0;
+    for (const DevBuf *d : {&p->slice, &p->slice_first, &p->hpart, &p->part_off, &p->split_rows, &p->seg_off, &p->seg, &p->part})
+        b += (int64_t)d->bytes;
+    return b;
+}
 
 template <int VT>
 __device__ __forceinline__ double mm_val(const void *v, int64_t k)

@@ -211,6 +211,29 @@ struct KernelTimer {   // records an event pair around one launch when the plan 
 
 void free_spmv_plan(SpmvPlan *p) { delete p; }
 
+// device memory the plan holds (private streams, tables, scratch)
+int64_t spmv_plan_bytes(const SpmvPlan *p)
+{
+    int64_t plan_bytes = 0;
+    {
+        auto add = [&](const DevBuf &b) { plan_bytes += (int64_t)b.bytes; };
+        for (const DevBuf *b : {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut,
+                                &p->heavy_row, &p->ci_hot, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
+            add(*b);
+        for (const Panel &t : p->tier)
+            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx})
+                add(*b);
+        for (const AccPanel *ap : p->acc)
+            for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
+        for (const LightStream *l : {&p->ls, &p->t1s})
+            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
+                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold, &l->round_start, &l->round_tile0, &l->wg_round0})
+                add(*b);
+    }
+    return plan_bytes;
+}
+
+
 constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_IPT = 8;
 constexpr int MERGE_ITEMS = MERGE_THREADS * MERGE_IPT;   // 2048 path items per tile
@@ -3706,7 +3729,10 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
     CSRK_TRY(dy.alloc((size_t)m->nrows * 8));
     if (m->ncols) CSRK_HIP(hipMemcpy(dx32.p, x, (size_t)m->ncols * 4, hipMemcpyHostToDevice));
     if (m->val_type == CSRK_VAL_F32) {
-        // float32 x float32: the product is rounded to float32 (the reference's arithmetic), outside the planned kernels
+        // float32 x float32: the product is rounded to float32 (the reference's arithmetic), outside the planned kernels.
+        // Reads the handle's arrays directly: under the handle's lock like every other product (unit_rows, center_rows
+        // and order_columns rewrite them under it), held until the kernel has finished.
+        std::lock_guard<std::mutex> lk(m->mu);
         const unsigned g = (unsigned)ceil_div((int64_t)m->nrows * WAVE, 256);
         if (m->ptr64)
             spmv_f32x_kernel<int64_t><<<g, 256>>>((const int64_t *)m->d_rowptrs, m->d_colinds, (const float *)m->d_values,
@@ -3715,6 +3741,7 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
             spmv_f32x_kernel<int32_t><<<g, 256>>>((const int32_t *)m->d_rowptrs, m->d_colinds, (const float *)m->d_values,
                                                   dx32.as<float>(), m->nrows, dy.as<double>());
         CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipDeviceSynchronize());
     } else {
         // float64 (or absent) values: Numba widens x, the product is float64 -- the usual kernels on the widened vector
         CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
@@ -3845,23 +3872,7 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
         a_nb = ap->nb;
     }
     const bool af = !p->acc.empty();
-    // [25]: bytes of device memory the plan holds (private streams, tables, scratch)
-    int64_t plan_bytes = 0;
-    {
-        auto add = [&](const DevBuf &b) { plan_bytes += (int64_t)b.bytes; };
-        for (const DevBuf *b : {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut,
-                                &p->heavy_row, &p->ci_hot, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
-            add(*b);
-        for (const Panel &t : p->tier)
-            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx})
-                add(*b);
-        for (const AccPanel *ap : p->acc)
-            for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
-        for (const LightStream *l : {&p->ls, &p->t1s})
-            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
-                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold, &l->round_start, &l->round_tile0, &l->wg_round0})
-                add(*b);
-    }
+    const int64_t plan_bytes = spmv_plan_bytes(p);      // [25]
     // [26] tiles per staging round when the round is held in LDS (else 0)
     const int64_t v[27] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,

@@ -17,16 +17,27 @@ Handle cache.  The reference's callers make a handle per operation (CSR.mult_vec
 release_handle, csr/csr.py:580-583); for a matrix in HBM that is a PCIe copy of the whole matrix per product, and
 libcsrk's planned kernels (built on a handle's second product) are never reached.  docs/kernels.rst:69-80 lets a
 kernel copy in to_handle and obliges the caller to release explicitly, so `to_handle` here keeps the device copy of
-a released handle alive and hands it out again when the SAME CSR object comes back with the SAME arrays:
+a released handle alive and hands it out again when the SAME CSR object comes back with the SAME arrays -- but only
+where a stale copy cannot go unseen:
+  * by default only for CSR classes that declare `__csrk_cacheable__ = True` (csr_amd.CSR does): their own mutators
+    call `invalidate`, their arrays own their memory, and WHILE A DEVICE COPY IS CACHED THE THREE HOST ARRAYS ARE
+    WRITE-PROTECTED (ndarray.flags.writeable = False; restored when the copy is dropped) -- `A.values[i] = v` between
+    two products raises "assignment destination is read-only" instead of multiplying by the old matrix.  Call
+    `invalidate(A)` first (it drops the copy and restores the flags), then edit.  The reference's numba handle
+    aliases the host arrays (csr/kernels/numba/__init__.py:16-27), so there an edit is simply seen; here it is
+    either seen or refused, never missed.  (A view of an array taken BEFORE its first product keeps its own
+    writeable flag -- the one alias the guard cannot reach; the sampled fingerprint below is the second line.)
+  * CSRK_HANDLE_CACHE=1 extends the cache to every CSR class WITHOUT the write guard (fingerprint only: a single
+    element poked into a foreign class's arrays is not seen -- for callers who never edit in place);
+    CSRK_HANDLE_CACHE=0 turns it off: every to_handle copies, like the MKL kernel (csr/kernels/mkl/handle.py:61-70);
   * key: id(csr) + shape + nnz + the three arrays' data pointers and dtypes; the entry dies with the CSR object
-    (weakref.finalize), so a recycled id or address can never hit;
-  * a sampled fingerprint of the arrays (first / last 32 + 2048 strided elements each) is compared on every hit, which
-    catches the whole-array in-place transforms the reference's API performs (normalize_rows, fill_values,
-    sort_rows, _filter_zeros); a single element poked into `A.values` between two products is NOT seen -- call
-    `invalidate(A)` (or set CSRK_HANDLE_CACHE=0) when doing that;
-  * idle device copies are evicted least-recently-used beyond CSRK_HANDLE_CACHE_BYTES (default 16 GiB of matrix
-    bytes) and on a device out-of-memory error;
-  * the in-place protocol operations (order_columns, unit_rows, center_rows) detach their handle from the cache.
+    (weakref.finalize), so a recycled id or address can never hit; a sampled fingerprint of the arrays (first / last
+    32 + 2048 strided elements each) is compared on every hit;
+  * a cached copy is handed out only while IDLE: a second live handle on the same CSR gets a copy of its own, so the
+    in-place protocol operations (order_columns, unit_rows, center_rows), which also detach their handle from the
+    cache, never change a device copy another live handle is reading;
+  * idle device copies are evicted least-recently-used beyond CSRK_HANDLE_CACHE_BYTES (default 16 GiB; a copy
+    counts with its SpMV / SpMM plans) and whenever a library call runs out of device memory (retried once).
 """
 import ctypes as C
 import os
@@ -69,17 +80,22 @@ def _live(h):
 
 # ---- handle cache ------------------------------------------------------------------------------------------
 class _Entry:
-    __slots__ = ('H', 'refs', 'bytes', 'key', 'finger', 'tick', 'cached', 'fin')
+    __slots__ = ('H', 'refs', 'bytes', 'key', 'finger', 'tick', 'cached', 'fin', 'guard')
 
 
 _cache_lock = threading.RLock()
 _cache = {}                     # key -> _Entry (live or idle device copies that may be handed out again)
+_guards = {}                    # id(array) -> [array, entries guarding it]: host arrays write-protected while cached
 _tick = 0
 _SAMPLE = 2048
 
 
-def _cache_enabled():
-    return os.environ.get('CSRK_HANDLE_CACHE', '1') not in ('0', 'off', 'false')
+def _cache_mode():
+    "'off' | 'guarded' (classes that declare __csrk_cacheable__, write-protected arrays) | 'all' (fingerprint only)"
+    v = os.environ.get('CSRK_HANDLE_CACHE')
+    if v is None or v == '':
+        return 'guarded'
+    return 'off' if v in ('0', 'off', 'false') else 'all'
 
 
 def _cache_budget():
@@ -104,12 +120,41 @@ def _fingerprint(rps, cis, vs):
     return hash((_sample(rps), _sample(cis), _sample(vs)))
 
 
+def _protect(arrays):
+    "write-protect the host arrays of a cached copy (caller holds the lock); returns what to hand to _unprotect"
+    held = []
+    for a in arrays:
+        if a is None or not a.flags.writeable:
+            continue
+        g = _guards.get(id(a))
+        if g is None:
+            g = _guards[id(a)] = [a, 0]
+            a.flags.writeable = False
+        g[1] += 1
+        held.append(a)
+    return held
+
+
+def _unprotect(held):
+    for a in held:
+        g = _guards.get(id(a))
+        if g is None:
+            continue
+        g[1] -= 1
+        if g[1] <= 0:
+            del _guards[id(a)]
+            a.flags.writeable = True
+
+
 def _drop_entry(e):
     "remove from the index; free the device copy once nobody holds it (caller holds the lock)"
     if e.cached:
         e.cached = False
         if _cache.get(e.key) is e:
             del _cache[e.key]
+    if e.guard:
+        held, e.guard = e.guard, None
+        _unprotect(held)
     if e.refs == 0 and e.H:
         H, e.H = e.H, 0
         check(lib.csrk_free(H))
@@ -140,31 +185,39 @@ def flush_handle_cache():
 
 
 def invalidate(csr):
-    "forget the cached device copy of `csr` (after editing its arrays in place); the next to_handle copies afresh"
+    """
+    Forget the cached device copy of `csr` and make its arrays writable again: call BEFORE editing them in place
+    (csr_amd.CSR's own mutators do); the next to_handle copies afresh.
+    """
     with _cache_lock:
         for e in [e for e in _cache.values() if e.key[0] == id(csr)]:
             _drop_entry(e)
 
 
+def _call(fn, *args):
+    "a library call that may need device memory: on failure, give back what idle cached copies hold and retry once"
+    rc = fn(*args)
+    if rc == _lib.ERR_HIP:
+        with _cache_lock:
+            idle = any(e.refs == 0 for e in _cache.values())
+        if idle:
+            flush_handle_cache()
+            check(lib.csrk_trim_cache())
+            rc = fn(*args)
+    check(rc)
+
+
 def _create(csr, rps, cis, vs):
     out = handle_t(0)
-    args = (int(csr.nrows), int(csr.ncols), int(csr.nnz), ptr(rps), int(rps.dtype == np.dtype('i8')), ptr(cis), ptr(vs),
-            _VAL_CODES[None if vs is None else vs.dtype], C.byref(out))
-    try:
-        check(lib.csrk_create(*args))
-    except _lib.CsrkError:
-        if not any(e.refs == 0 for e in _cache.values()):
-            raise
-        flush_handle_cache()            # device memory may be held by idle cached copies: give it back and retry once
-        check(lib.csrk_trim_cache())
-        check(lib.csrk_create(*args))
+    _call(lib.csrk_create, int(csr.nrows), int(csr.ncols), int(csr.nnz), ptr(rps), int(rps.dtype == np.dtype('i8')), ptr(cis),
+          ptr(vs), _VAL_CODES[None if vs is None else vs.dtype], C.byref(out))
     return out.value
 
 
 def to_handle(csr):
     """
     csr/kernels/numba/__init__.py:16-27; csr/kernels/mkl/handle.py:61-70.  Copies the
-    matrix to HBM -- or hands out the cached copy made for this same CSR object and arrays (module docstring).
+    matrix to HBM -- or hands out the idle cached copy made for this same CSR object and arrays (module docstring).
     Accepts f4/f8/absent values and int32/int64 row pointers; other value
     dtypes are widened to f8 (the reference's results are f8 whatever the storage dtype).
     """
@@ -181,12 +234,19 @@ def to_handle(csr):
         if vs.dtype not in (np.dtype('f4'), np.dtype('f8')):
             vs = vs.astype(np.float64)
     nr, nc, nnz = int(csr.nrows), int(csr.ncols), int(csr.nnz)
+    mode = _cache_mode()
+    guarded = mode == 'guarded'
     # small matrices are cheaper to copy than to look up; arrays that had to be converted are temporaries whose
-    # addresses mean nothing on the next call
+    # addresses mean nothing on the next call; in guarded mode the class must vouch for its mutators and every array
+    # must own its memory (a view's base could be written behind the guard)
     def own(a, orig):
-        return (a is None and orig is None) or (isinstance(orig, np.ndarray) and a.ctypes.data == orig.ctypes.data)
-    cacheable = (_cache_enabled() and nnz >= 4096 and own(rps, csr.rowptrs) and own(cis, csr.colinds)
-                 and own(vs, csr.values))
+        if a is None and orig is None:
+            return True
+        if not (isinstance(orig, np.ndarray) and a.ctypes.data == orig.ctypes.data):
+            return False
+        return not guarded or orig.base is None
+    cacheable = (mode != 'off' and nnz >= 4096 and (not guarded or getattr(type(csr), '__csrk_cacheable__', False))
+                 and own(rps, csr.rowptrs) and own(cis, csr.colinds) and own(vs, csr.values))
     if cacheable:
         key = (id(csr), nr, nc, nnz, _arr_key(rps), _arr_key(cis), _arr_key(vs))
         finger = _fingerprint(rps, cis, vs)
@@ -195,6 +255,11 @@ def to_handle(csr):
             e = _cache.get(key)
             if e is not None and e.finger != finger:      # same arrays, different contents: edited in place
                 _drop_entry(e)
+                e = None
+            if e is not None and e.refs > 0:
+                # another live handle is using the cached copy (and may change it in place: order_columns,
+                # unit_rows, center_rows): this one gets a copy of its own, outside the cache
+                cacheable = False
                 e = None
             if e is not None:
                 e.refs += 1
@@ -211,7 +276,7 @@ def to_handle(csr):
             return h
         fin.atexit = False
         e = _Entry()
-        e.H, e.refs, e.key, e.finger, e.cached, e.fin = H, 1, key, finger, True, fin
+        e.H, e.refs, e.key, e.finger, e.cached, e.fin, e.guard = H, 1, key, finger, True, fin, None
         e.bytes = rps.nbytes + cis.nbytes + (0 if vs is None else vs.nbytes)
         with _cache_lock:
             old = _cache.get(key)
@@ -219,6 +284,8 @@ def to_handle(csr):
                 _drop_entry(old)
             e.tick = _tick
             _cache[key] = e
+            if guarded:
+                e.guard = _protect([csr.rowptrs, csr.colinds, csr.values])
         h._entry = e
     return h
 
@@ -232,6 +299,9 @@ def _detach(h):
                 e.cached = False
                 if _cache.get(e.key) is e:
                     del _cache[e.key]
+            if e.guard:
+                held, e.guard = e.guard, None
+                _unprotect(held)
 
 
 def _info(H):
@@ -277,6 +347,10 @@ def release_handle(h):
         e.refs -= 1
         if e.refs == 0 and not e.cached:
             _drop_entry(e)
+        elif e.cached:
+            nb = C.c_int64(0)                      # the copy stays: count it with the plans it has grown meanwhile
+            if lib.csrk_device_bytes(H, C.byref(nb)) == _lib.OK and nb.value > 0:
+                e.bytes = nb.value
     if e.cached:
         _evict_idle(_cache_budget())
 
@@ -284,7 +358,7 @@ def release_handle(h):
 def order_columns(h):
     "csr/kernels/numba/__init__.py:47-52: sort each row by column, in place on the handle"
     _detach(h)
-    check(lib.csrk_order_columns(_live(h)))
+    _call(lib.csrk_order_columns, _live(h))
 
 
 def mult_vec(h, v):
@@ -301,10 +375,10 @@ def mult_vec(h, v):
     y = np.empty(h.nrows, dtype=np.float64)
     if v.dtype == np.float32:
         x = np.ascontiguousarray(v)
-        check(lib.csrk_spmv_f32x(_live(h), ptr(x), ptr(y)))
+        _call(lib.csrk_spmv_f32x, _live(h), ptr(x), ptr(y))
         return y
     x = np.ascontiguousarray(v, dtype=np.float64)
-    check(lib.csrk_spmv(_live(h), ptr(x), ptr(y)))
+    _call(lib.csrk_spmv, _live(h), ptr(x), ptr(y))
     return y
 
 
@@ -312,7 +386,7 @@ def mult_ab(a_h, b_h):
     "csr/kernels/numba/multiply.py:13-38: C = A B as a NEW handle the caller must release"
     assert a_h.ncols == b_h.nrows
     out = handle_t(0)
-    check(lib.csrk_spgemm_ab(_live(a_h), _live(b_h), C.byref(out)))
+    _call(lib.csrk_spgemm_ab, _live(a_h), _live(b_h), C.byref(out))
     return _wrap(out.value)
 
 
@@ -320,7 +394,7 @@ def mult_abt(a_h, b_h):
     "csr/kernels/numba/multiply.py:41-57: C = A B^T as a NEW handle"
     assert a_h.ncols == b_h.ncols
     out = handle_t(0)
-    check(lib.csrk_spgemm_abt(_live(a_h), _live(b_h), C.byref(out)))
+    _call(lib.csrk_spgemm_abt, _live(a_h), _live(b_h), C.byref(out))
     return _wrap(out.value)
 
 
@@ -329,7 +403,7 @@ def mult_abt(a_h, b_h):
 def transpose(h, include_values=True):
     "csr/structure.py:240-247: transposed matrix as a NEW handle (bit-exact with the reference)"
     out = handle_t(0)
-    check(lib.csrk_transpose(_live(h), int(bool(include_values)), C.byref(out)))
+    _call(lib.csrk_transpose, _live(h), int(bool(include_values)), C.byref(out))
     return _wrap(out.value)
 
 
@@ -351,8 +425,8 @@ def from_coo(rows, cols, vals, shape):
         if vals.dtype not in (np.dtype('f4'), np.dtype('f8')):
             vals = vals.astype(np.float64)
     out = handle_t(0)
-    check(lib.csrk_from_coo(nrows, ncols, nnz, ptr(rows), ptr(cols), ptr(vals),
-                            _VAL_CODES[None if vals is None else vals.dtype], C.byref(out)))
+    _call(lib.csrk_from_coo, nrows, ncols, nnz, ptr(rows), ptr(cols), ptr(vals),
+          _VAL_CODES[None if vals is None else vals.dtype], C.byref(out))
     return _wrap(out.value)
 
 
@@ -377,7 +451,7 @@ def _row_stat(fn, h):
         raise ValueError('matrix has no values')
     _detach(h)                     # unit_rows / center_rows rewrite the device copy's values
     out = np.empty(h.nrows, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
-    check(fn(h.H, ptr(out)))
+    _call(fn, h.H, ptr(out))
     return out
 
 
@@ -395,14 +469,14 @@ def pick_rows(h, rows, include_values=True):
     "csr/csr.py:347-364 on the device: NEW handle with the given rows (in order, repeats allowed)"
     rows = np.ascontiguousarray(rows, dtype=np.int32)
     out = handle_t(0)
-    check(lib.csrk_pick_rows(_live(h), rows.ctypes.data_as(C.c_void_p), rows.size, int(bool(include_values)), C.byref(out)))
+    _call(lib.csrk_pick_rows, _live(h), rows.ctypes.data_as(C.c_void_p), rows.size, int(bool(include_values)), C.byref(out))
     return _wrap(out.value)
 
 
 def filter_zeros(h):
     "csr/_struct.py:61-76 on the device: NEW handle without exact-zero entries"
     out = handle_t(0)
-    check(lib.csrk_filter_zeros(_live(h), C.byref(out)))
+    _call(lib.csrk_filter_zeros, _live(h), C.byref(out))
     return _wrap(out.value)
 
 
@@ -426,7 +500,7 @@ def mult_dense(h, B):
         raise ValueError(f'panel has shape {B.shape}, expected ({h.ncols}, k)')
     k = B.shape[1]
     out = np.empty((h.nrows, k), dtype=np.float64)
-    check(lib.csrk_spmm_dense(_live(h), ptr(B), k, k, ptr(out), k))
+    _call(lib.csrk_spmm_dense, _live(h), ptr(B), k, k, ptr(out), k)
     return out
 
 

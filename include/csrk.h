@@ -99,6 +99,10 @@ CSRK_API int csrk_create_device(int32_t nrows, int32_t ncols, int64_t nnz,
 CSRK_API int csrk_free(csrk_handle_t h);
 CSRK_API int csrk_info(csrk_handle_t h, int32_t *nrows, int32_t *ncols, int64_t *nnz,
                        int *ptr_is_64, int *val_type);
+/* Device memory the handle holds right now: its three arrays plus whatever SpMV / SpMM plans it has built (private
+ * re-ordered streams, tables, scratch).  Builds nothing.  (The host side's handle cache budgets with it; the
+ * reference's handles are host objects and have no counterpart.) */
+CSRK_API int csrk_device_bytes(csrk_handle_t h, int64_t *bytes);
 /* Copy the matrix back to caller-allocated host arrays sized from csrk_info
  * (any of the three may be NULL to skip it). */
 CSRK_API int csrk_export(csrk_handle_t h, void *rowptrs, int32_t *colinds, void *values);

@@ -250,6 +250,42 @@ def test_bench_two_ranks_plumbing(collective):
         assert d['multi_gpu']['exchange'] == collective
 
 
+@pytest.mark.parametrize('collective', ['auto', 'allreduce', 'p2p'])
+def test_bench_one_rank_on_rccl(collective):
+    """
+    The N > 1 code path of bench.py under the REAL backend with ONE rank (`--gpus 1 --force-dist`): RCCL loads and builds
+    its communicator (init_process_group('nccl', device_id=...)), all_gather_into_tensor / all_gather / all_reduce /
+    batch_isend_irecv and the split-phase form's small all-gather run on device tensors, the calibration picks an
+    exchange, the completeness check passes, and the exchanged y equals the plain product bit for bit.  The parallel
+    form of csr/csr.py:584-590 (shard products concatenated) as far as one GPU can rehearse it; RCCL refuses two ranks
+    on one device, so the 2-rank plumbing test above runs on gloo.
+    """
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BENCH_TEST_SHARE_GPU',
+                                                            'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '3', '--warmup', '1',
+           '--scale', '0.05', '--no-cpu-baseline', '--collective', collective]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    mg = d['multi_gpu']
+    assert d['n_gpus'] == 1 and mg['backend'] == 'nccl'
+    assert mg['y_complete_and_identical_on_every_rank'] is True and mg['y_equals_plain_product_bitwise'] is True
+    assert mg['kernel_only_gflops'] > 0 and mg['end_to_end_gflops'] > 0
+    if collective == 'auto':
+        cands = mg['candidates_ms_per_step']
+        assert mg['exchange'] in cands
+        for name in ('allgather', 'allgatherv', 'p2p-split'):      # each ran on RCCL (a number, not an error string)
+            assert isinstance(cands[name], float), cands
+    else:
+        assert mg['exchange'] == collective
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     "`python bench.py --gpus 8` on a box with fewer GPUs: a clear message and a non-zero exit, before anything is launched"
     import os

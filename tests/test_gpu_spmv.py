@@ -479,8 +479,10 @@ def test_handle_cache_reaches_the_plan():
     """
     The reference's caller path (csr/csr.py:580-583: a handle per product) through csr_amd.CSR: the device copy made by
     the first product is handed out again to the later ones (same csrk handle), so they run on the plan the second
-    product builds; results stay identical to the oracle's and to each other, a whole-array in-place edit of the host
-    values is picked up, a single poked element after `invalidate`.
+    product builds; results stay identical to the oracle's and to each other.  An edit of the host arrays between two
+    products is never missed (the reference re-reads them on every product, csr/csr.py:580-583): while the device copy
+    is cached the arrays are write-protected, so ONE poked element raises; after `invalidate` the edit goes through and
+    the next product sees it.
     """
     from oracle import oracle as O
     from csr_amd import CSR, synth
@@ -505,11 +507,46 @@ def test_handle_cache_reaches_the_plan():
     for y in ys:
         check(y)
     assert np.array_equal(ys[2], ys[3])
-    A.values *= 0.5                                         # whole-array edit in place: the fingerprint changes
-    check(A.mult_vec(x))
-    A.values[777] = 3.0                                     # one element: not sampled, the caller says so
+    y_old = ys[3]
+    with pytest.raises(ValueError):                         # ONE element edited between two products: refused, never ignored
+        A.values[777] = 3.0
+    with pytest.raises(ValueError):
+        A.values *= 0.5
+    K.invalidate(A)                                         # announce the edit: the copy is dropped, the arrays writable again
+    A.values[777] = 3.0
+    y_new = A.mult_vec(x)
+    check(y_new)                                            # the NEW product (the oracle reads the edited array) ...
+    assert not np.array_equal(y_new, y_old)                 # ... not the old one
     K.invalidate(A)
+    A.values *= 0.5
     check(A.mult_vec(x))
+    A.values = A.values + 1.0                               # csr_amd.CSR's own setter invalidates by itself
+    check(A.mult_vec(x))
+    K.flush_handle_cache()
+    assert A.values.flags.writeable
+
+
+def test_live_handles_are_independent():
+    """
+    Two live handles on one CSR (csr/csr.py:543-567 makes them for A.multiply(A)): an in-place protocol operation on one
+    -- order_columns, csr/kernels/numba/__init__.py:47-52 -- must not change what the other reads.
+    """
+    from csr_amd import CSR
+    from csr_amd.kernels import hip as K
+    K.flush_handle_cache()
+    rng = np.random.default_rng(5)
+    n, per = 3000, 6
+    cols = np.concatenate([rng.permutation(n)[:per] for _ in range(n)]).astype(np.int32)      # unsorted rows
+    A = CSR(n, n, n * per, np.arange(0, n * per + 1, per, dtype=np.int32), cols, rng.uniform(-1, 1, n * per), _cast=False)
+    h1, h2 = K.to_handle(A), K.to_handle(A)
+    assert h1.H != h2.H
+    K.order_columns(h2)
+    a1, a2 = K.from_handle(h1), K.from_handle(h2)
+    assert np.array_equal(a1.colinds, A.colinds) and np.array_equal(a1.values, A.values)      # h1 untouched
+    assert not np.array_equal(a2.colinds, A.colinds)
+    assert all(np.all(np.diff(a2.colinds[i * per:(i + 1) * per]) > 0) for i in range(0, n, 97))
+    K.release_handle(h1)
+    K.release_handle(h2)
     K.flush_handle_cache()
 
 

@@ -14,7 +14,7 @@ class FakeLib:
     "counts csrk_create / csrk_free; handles are 1, 2, 3, ..."
 
     def __init__(self):
-        self.created, self.freed, self.live, self.fail_next = 0, [], set(), 0
+        self.created, self.freed, self.live, self.fail_next, self.bytes_of = 0, [], set(), 0, {}
 
     def csrk_create(self, nr, nc, nnz, rp, p64, ci, vs, vt, out):
         if self.fail_next:
@@ -35,6 +35,10 @@ class FakeLib:
     def csrk_trim_cache(self):
         return 0
 
+    def csrk_device_bytes(self, H, out):
+        out._obj.value = self.bytes_of.get(getattr(H, 'value', H), 0)      # 0: keep the host-side estimate
+        return 0
+
     def csrk_last_error(self):
         return b'hipMalloc failed: out of memory'
 
@@ -49,7 +53,9 @@ def K(monkeypatch):
     hip.flush_handle_cache()
     hip._cache.clear()
     yield hip
+    hip.flush_handle_cache()
     hip._cache.clear()
+    assert not hip._guards                            # every write guard was lifted with its entry
 
 
 def _mat(n=6000, seed=0, vals=True):
@@ -67,10 +73,8 @@ def test_same_csr_reuses_the_device_copy(K):
     assert h1.H == 0 and K.lib.freed == []            # idle, still in HBM
     K.release_handle(h1)                              # idempotent (csr/kernels/mkl/handle.py:144-148)
     h2 = K.to_handle(A)
-    h3 = K.to_handle(A)                               # two live handles share the copy
-    assert K.lib.created == 1 and h2.H == h3.H == 1
+    assert K.lib.created == 1 and h2.H == 1           # the idle copy is handed out again
     K.release_handle(h2)
-    K.release_handle(h3)
     assert K.lib.freed == []
     B = _mat(seed=1)                                  # another matrix: its own copy
     hb = K.to_handle(B)
@@ -78,6 +82,22 @@ def test_same_csr_reuses_the_device_copy(K):
     K.release_handle(hb)
     K.flush_handle_cache()
     assert sorted(K.lib.freed) == [1, 2] and not K.lib.live
+
+
+def test_two_live_handles_never_share_a_device_copy(K, monkeypatch):
+    "an in-place protocol operation on one handle must not change what another live handle reads (every to_handle of the reference yields an independent object)"
+    A = _mat()
+    h1 = K.to_handle(A)
+    h2 = K.to_handle(A)                               # the cached copy is in use: this one is private
+    assert K.lib.created == 2 and h1.H != h2.H
+    monkeypatch.setattr(K.lib, 'csrk_order_columns', lambda H: 0, raising=False)
+    K.order_columns(h2)                               # h1's copy is untouched
+    K.release_handle(h2)
+    assert K.lib.freed == [h2.H or 2]                 # the private copy is freed on release
+    K.release_handle(h1)
+    h3 = K.to_handle(A)
+    assert h3.H == 1 and K.lib.created == 2           # idle again: reused
+    K.release_handle(h3)
 
 
 def test_entry_dies_with_the_csr_object(K):
@@ -98,22 +118,61 @@ def test_entry_dies_with_the_csr_object(K):
     assert not K.lib.live
 
 
-def test_in_place_edits_are_seen(K):
+def test_in_place_edits_are_refused_or_seen_never_missed(K):
+    "csr/csr.py:580-583: the reference re-reads the arrays on every product; here an edit of a cached matrix raises until invalidate()"
     A = _mat()
     K.release_handle(K.to_handle(A))
-    A.values[:] *= 2.0                                # a whole-array transform (normalize_rows, fill_values ...)
+    for arr in (A.values, A.colinds, A.rowptrs):
+        assert not arr.flags.writeable                # write-protected while the device copy is cached
+    with pytest.raises(ValueError):
+        A.values[4001] = 7.0                          # ONE element: refused, not silently ignored
+    with pytest.raises(ValueError):
+        A.values[:] *= 2.0
+    K.invalidate(A)                                   # the caller announces the edit ...
+    assert A.values.flags.writeable and A.colinds.flags.writeable and K.lib.freed == [1]
+    A.values[4001] = 7.0                              # ... and makes it
     h = K.to_handle(A)
-    assert K.lib.created == 2 and K.lib.freed == [1]  # fingerprint mismatch: fresh copy, stale one freed
+    assert K.lib.created == 2                         # fresh copy
     K.release_handle(h)
-    A.values[4001] = 7.0                              # a single poke is not sampled ...
-    K.invalidate(A)                                   # ... so the caller says so
+    A.values = A.values * 2.0                         # csr_amd.CSR's own mutators invalidate by themselves
+    assert K.lib.freed == [1, 2] and A.values.flags.writeable
     h = K.to_handle(A)
-    assert K.lib.created == 3 and K.lib.freed == [1, 2]
+    assert K.lib.created == 3
     K.release_handle(h)
+    K.invalidate(A)
     A.colinds = A.colinds.copy()                      # new arrays on the same object: different key
     h = K.to_handle(A)
     assert K.lib.created == 4
     K.release_handle(h)
+
+
+def test_foreign_csr_classes_are_cached_only_on_request(K, monkeypatch):
+    "a class that does not declare __csrk_cacheable__ (the reference's own CSR) gets a fresh copy per handle unless CSRK_HANDLE_CACHE=1"
+    class Foreign:
+        pass
+    A = _mat()
+    F = Foreign()
+    F.nrows, F.ncols, F.nnz, F.rowptrs, F.colinds, F.values = A.nrows, A.ncols, A.nnz, A.rowptrs, A.colinds, A.values
+    for _ in range(2):
+        K.release_handle(K.to_handle(F))
+    assert K.lib.created == 2 and K.lib.freed == [1, 2] and F.values.flags.writeable
+    monkeypatch.setenv('CSRK_HANDLE_CACHE', '1')      # fingerprint-validated, no write guard: the caller's responsibility
+    for _ in range(2):
+        K.release_handle(K.to_handle(F))
+    assert K.lib.created == 3 and F.values.flags.writeable
+    F.values[:] *= 2.0                                # a whole-array edit changes the sampled fingerprint
+    K.release_handle(K.to_handle(F))
+    assert K.lib.created == 4
+
+
+def test_views_are_not_cached(K):
+    "an array that does not own its memory can be written through its base behind the guard"
+    from csr_amd import CSR
+    A = _mat()
+    S = A.subset_rows(0, 5000)                        # colinds / values are views of A's
+    for _ in range(2):
+        K.release_handle(K.to_handle(S))
+    assert K.lib.created == 2 and A.values.flags.writeable
 
 
 def test_in_place_protocol_operations_detach(K, monkeypatch):
@@ -121,6 +180,7 @@ def test_in_place_protocol_operations_detach(K, monkeypatch):
     h = K.to_handle(A)
     monkeypatch.setattr(K.lib, 'csrk_order_columns', lambda H: 0, raising=False)
     K.order_columns(h)                                # the device copy no longer equals A
+    assert A.values.flags.writeable                   # ... and no longer guards A's arrays
     h2 = K.to_handle(A)
     assert h2.H != h.H and K.lib.created == 2
     K.release_handle(h)
