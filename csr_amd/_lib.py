@@ -83,6 +83,8 @@ SIGNATURES = {
     'csrk_row_nnzs': (_int, [handle_t, _vp]),
     'csrk_row_extent': (_int, [handle_t, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     'csrk_unit_rows': (_int, [handle_t, _vp]),
+    'csrk_unit_rows_device': (_int, [handle_t, _vp]),
+    'csrk_center_rows_device': (_int, [handle_t, _vp]),
     'csrk_center_rows': (_int, [handle_t, _vp]),
     'csrk_order_columns': (_int, [handle_t]),
     'csrk_filter_zeros': (_int, [handle_t, C.POINTER(handle_t)]),

@@ -125,6 +125,15 @@ class CSR:
         self._edited()
         self._values = vs
 
+    def copy(self, include_values=True, *, copy_structure=True):
+        """
+        A matrix of its own with the same entries: fresh arrays (copy_structure=False shares rowptrs / colinds
+        instead), without values if include_values is false.  (Counterpart: csr/csr.py:298-321.)
+        """
+        rps, cis = (self.rowptrs.copy(), self.colinds.copy()) if copy_structure else (self.rowptrs, self.colinds)
+        vs = self._values.copy() if include_values and self._values is not None else None
+        return type(self)(self.nrows, self.ncols, self.nnz, rps, cis, vs, _cast=False)
+
     # ---- rows -----------------------------------------------------------------------------
     def row_extent(self, row):
         "csr/csr.py:406-417 -> csr/_rows.py:9-13 (host field read, as in the reference)"

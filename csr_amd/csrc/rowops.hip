@@ -3,13 +3,22 @@
 //   order_columns             csr/kernels/numba/__init__.py:47-52 -> csr/structure.py:156-169
 //   filter_zeros              csr/_struct.py:61-76
 //
-// unit_rows / center_rows: one wavefront per row (rows are independent); lanes stride the
-// row coalesced, reductions are __shfl_down trees accumulated in float64 whatever the
-// storage dtype (so float32 results are within one rounding of exact, inside the
-// reference tests' rel 1e-6), and the element updates are done in the storage dtype with
-// the same two roundings as the reference (`v *= prenorm`, then `v /= inorm`).
-// HBM traffic: values read 3x (max, norm, scale; the 2nd/3rd hit L2 for rows <= 4 MiB) and
-// written once; row pointers once; norms once.
+// unit_rows / center_rows (round 3): every value is read ONCE where its row fits a register tile and twice where it does not,
+// written once; reductions are accumulated in float64 whatever the storage dtype (float32 results are within one rounding
+// of exact, inside the reference tests' rel 1e-6) and the element updates are done in the storage dtype with the same two
+// roundings as the reference (`v *= prenorm`, then `v /= inorm`).  Three row classes, one pass over the row pointers:
+//   A  rows of <= 8 entries      one LANE per row: the row's values sit in 8 registers between load, reduction and store
+//                                (a power-law matrix: 9.4 of the headline matrix's 10 million rows);
+//   B  rows of 9 .. 512 entries  8 lanes per row (up to 64 entries) or one WAVEFRONT per row, 8 values per lane in
+//                                registers, coalesced segments;
+//   C  longer rows               cut into CHUNKS of 4096 entries, one 512-thread workgroup per chunk: (C1) per-chunk
+//                                partials with the chunk in registers -- its maximum, and the sum of squares under the
+//                                chunk's OWN power-of-two prescale (a power-of-two factor moves through the float64 sum
+//                                unchanged, so the row's sum is the chunks' sums rescaled) --, (C2) one thread per long
+//                                row joins its chunks' partials in chunk order, (C3) the chunks are scaled.  A 10^6-entry
+//                                row is then 245 workgroups instead of one (one workgroup per long row: 1.9 ms of the
+//                                former 4.0 ms of kernels on the headline matrix, bound by its longest row on one CU).
+// HBM traffic: values 1 read + 1 write (A, B), 2 reads + 1 write (C); row pointers once; norms once.
 #include "common.h"
 
 namespace csrk {
@@ -34,6 +43,125 @@ __device__ __forceinline__ double wmax_nan(double v, bool nan)
     return __any(nan) ? __builtin_nan("") : v;   // np.max propagates NaN (transform.py:52)
 }
 
+template <class T> struct FInfo;
+template <> struct FInfo<double> { static constexpr int maxexp = 1024, minexp = -1022; };
+template <> struct FInfo<float> { static constexpr int maxexp = 128, minexp = -126; };
+
+constexpr int RS_A = 8;             // class A: one lane per row
+constexpr int RS_K = 8;             // values per lane in classes B and C
+constexpr int RS_B8 = 8 * RS_K;     // class B, 8 lanes per row (64)
+constexpr int RS_B = WAVE * RS_K;   // class B, one wavefront per row (512)
+#ifndef CSRK_RS_THREADS
+#define CSRK_RS_THREADS 512      // (class C1 alone on the headline matrix: 1024 threads 0.357 ms, 512 0.270, 256 0.278)
+#endif
+constexpr int RS_THREADS = CSRK_RS_THREADS;
+constexpr int RS_CHUNK = RS_THREADS * RS_K;      // class C: entries per chunk (8192)
+
+// (m, e) = frexp(vmax); pnexp = clamp(-e, minexp, maxexp - 1); prenorm = 2^pnexp (transform.py:55-58); a NaN or infinite
+// maximum leaves the exponent at 0
+template <class T>
+__device__ __forceinline__ int prenorm_exp(double vmax)
+{
+    int ve = 0;
+    if (vmax == vmax && !isinf(vmax)) (void)frexp(vmax, &ve);
+    int pnexp = -ve;
+    pnexp = pnexp > FInfo<T>::maxexp - 1 ? FInfo<T>::maxexp - 1 : pnexp;
+    pnexp = pnexp < FInfo<T>::minexp ? FInfo<T>::minexp : pnexp;
+    return pnexp;
+}
+
+// The B (8 lanes / a wavefront per row) and C lists are built without atomics: a counting pass writes, per wavefront of
+// 64 consecutive rows, how many of them fall in each class; one exclusive scan over [class][wavefront] turns the counts
+// into list positions; the class A kernel -- one lane per row -- then drops its longer rows at their positions (rows
+// ascend inside every list: deterministic).  (Appending with atomics serialised on the three counters: 2.0 ms of the
+// kernel's 2.0 ms on the headline matrix with an atomic per row, 3.0 ms with one per wavefront and list.)
+__device__ __forceinline__ int row_class(int64_t len)      // 0: class A (or no row), 1: B8, 2: B, 3: C
+{
+    return len <= RS_A ? 0 : (len <= RS_B8 ? 1 : (len <= RS_B ? 2 : 3));
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void row_class_count_kernel(const P *__restrict__ rp, int32_t nrows, int64_t n_waves,
+                                                             int32_t *__restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = r < nrows ? row_class((int64_t)rp[r + 1] - (int64_t)rp[r]) : 0;
+    const int64_t w = r / WAVE;
+    if (w >= n_waves) return;
+#pragma unroll
+    for (int c = 1; c <= 3; c++) {
+        const unsigned long long mk = __ballot(cls == c);
+        if ((threadIdx.x & (WAVE - 1)) == 0) cnt[(int64_t)(c - 1) * n_waves + w] = __popcll(mk);
+    }
+}
+
+// Class A and the lists: one lane per row.  pos = the exclusive scan of the counts ([class][wavefront], then the total).
+template <class P, class T, bool UNIT>
+__global__ __launch_bounds__(256) void row_stat_a_kernel(const P *__restrict__ rp, T *__restrict__ vs, T *__restrict__ out,
+                                                        int32_t nrows, int64_t n_waves, const int32_t *__restrict__ pos,
+                                                        int32_t *__restrict__ list_b8, int32_t *__restrict__ list_b,
+                                                        int32_t *__restrict__ list_c)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = r < nrows;
+    const int64_t sp = ok ? (int64_t)rp[r] : 0, ep = ok ? (int64_t)rp[r + 1] : 0;
+    const int64_t len = ep - sp;
+    {
+        const int cls = ok ? row_class(len) : 0;
+        const int lane = threadIdx.x & (WAVE - 1);
+        const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
+        const int64_t w = r / WAVE;
+#pragma unroll
+        for (int c = 1; c <= 3; c++) {
+            const unsigned long long mk = __ballot(cls == c);
+            if (cls == c) {
+                int32_t *list = c == 1 ? list_b8 : (c == 2 ? list_b : list_c);
+                list[pos[(int64_t)(c - 1) * n_waves + w] - pos[(int64_t)(c - 1) * n_waves] + __popcll(mk & below)] = (int32_t)r;
+            }
+        }
+    }
+    if (!ok || len > RS_A) return;
+    if (len == 0) {                       // empty row: norm / mean 0 (transform.py:36-38, :19-21)
+        out[r] = (T)0;
+        return;
+    }
+    T v[RS_A];
+#pragma unroll
+    for (int j = 0; j < RS_A; j++) v[j] = j < len ? vs[sp + j] : (T)0;
+    if (UNIT) {
+        double vmax = 0.0;
+        bool nan = false;
+#pragma unroll
+        for (int j = 0; j < RS_A; j++) {
+            const double a = fabs((double)v[j]);
+            nan |= a != a;
+            vmax = a > vmax ? a : vmax;
+        }
+        if (nan) vmax = __builtin_nan("");        // np.max propagates NaN (transform.py:52)
+        const T prenorm = (T)ldexp(1.0, prenorm_exp<T>(vmax));
+        double ss = 0.0;
+#pragma unroll
+        for (int j = 0; j < RS_A; j++) {
+            v[j] = v[j] * prenorm;            // :59
+            ss += (double)v[j] * (double)v[j];
+        }
+        const T inorm = (T)sqrt(ss);          // :62
+        out[r] = inorm / prenorm;             // :63
+#pragma unroll
+        for (int j = 0; j < RS_A; j++)
+            if (j < len) vs[sp + j] = v[j] / inorm;      // :64
+    } else {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < RS_A; j++) s += (double)v[j];
+        const T m = (T)(s / (double)len);
+        out[r] = m;
+#pragma unroll
+        for (int j = 0; j < RS_A; j++)
+            if (j < len) vs[sp + j] = v[j] - m;
+    }
+}
+
 // reductions over aligned groups of LPR lanes (LPR a power of two <= 64); every lane gets the result
 template <int LPR>
 __device__ __forceinline__ double gsum(double v)
@@ -55,104 +183,81 @@ __device__ __forceinline__ double gmax_nan(double v, bool nan)
     return f ? __builtin_nan("") : v;   // np.max propagates NaN (transform.py:52)
 }
 
-constexpr int ROW_LONG = 8192;     // rows longer than this get a whole workgroup
-
-template <class T> struct FInfo;
-template <> struct FInfo<double> { static constexpr int maxexp = 1024, minexp = -1022; };
-template <> struct FInfo<float> { static constexpr int maxexp = 128, minexp = -126; };
-
-// LPR lanes per row: a whole wavefront (64) for ordinary rows, 8 when the average row has < 16 entries (a
-// power-law matrix with millions of 1-entry rows kept 63 of 64 lanes idle: 6 ms for the headline matrix)
-template <class P, class T, int LPR>
-__global__ __launch_bounds__(256) void unit_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
-                                                       T *__restrict__ norms, int32_t nrows,
-                                                       int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long,
-                                                       const int32_t *__restrict__ row_list, int32_t med_min,
-                                                       int32_t *__restrict__ med_rows, int32_t *__restrict__ n_med)
-{
-    // row_list (optional): the rows to process; med_min > 0: rows with more entries than that (and <= ROW_LONG)
-    // are left to a second, wavefront-per-row launch over med_rows
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
-    const int lane = threadIdx.x & (LPR - 1);
-    if (q >= nrows) return;
-    const int64_t r = row_list ? row_list[q] : q;
-    const int64_t sp = rp[r], ep = rp[r + 1];
-    if (ep - sp > ROW_LONG) {             // left to the workgroup-per-row kernel
-        if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
-        return;
-    }
-    if (med_min > 0 && ep - sp > med_min) {
-        if (lane == 0) med_rows[atomicAdd(n_med, 1)] = (int32_t)r;
-        return;
-    }
-    if (sp == ep) {                       // empty row: norm 0 (transform.py:36-38)
-        if (lane == 0) norms[r] = (T)0;
-        return;
-    }
-    double vmax = 0.0;
-    bool nan = false;
-    for (int64_t k = sp + lane; k < ep; k += LPR) {
-        double a = fabs((double)vs[k]);
-        nan |= a != a;
-        vmax = a > vmax ? a : vmax;
-    }
-    vmax = gmax_nan<LPR>(vmax, nan);
-    // (m, e) = frexp(vmax); pnexp = clamp(-e, minexp, maxexp - 1); prenorm = 2^pnexp (:55-58)
-    int ve = 0;
-    if (vmax == vmax && !isinf(vmax)) (void)frexp(vmax, &ve);
-    int pnexp = -ve;
-    pnexp = pnexp > FInfo<T>::maxexp - 1 ? FInfo<T>::maxexp - 1 : pnexp;
-    pnexp = pnexp < FInfo<T>::minexp ? FInfo<T>::minexp : pnexp;
-    const T prenorm = (T)ldexp(1.0, pnexp);
-    double ss = 0.0;
-    for (int64_t k = sp + lane; k < ep; k += LPR) {
-        T v = vs[k] * prenorm;            // :59
-        ss += (double)v * (double)v;
-    }
-    const T inorm = (T)sqrt(gsum<LPR>(ss));    // :62
-    if (lane == 0) norms[r] = inorm / prenorm;   // :63
-    for (int64_t k = sp + lane; k < ep; k += LPR) {
-        T v = vs[k] * prenorm;
-        vs[k] = v / inorm;                // :64
-    }
-}
-
-template <class P, class T, int LPR>
-__global__ __launch_bounds__(256) void center_rows_kernel(const P *__restrict__ rp, T *__restrict__ vs,
-                                                         T *__restrict__ means, int32_t nrows,
-                                                         int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long,
-                                                         const int32_t *__restrict__ row_list, int32_t med_min,
-                                                         int32_t *__restrict__ med_rows, int32_t *__restrict__ n_med)
+// Class B: LPR lanes per listed row (8 for 9 .. 64 entries, 64 for 65 .. 512), the row in registers
+template <class P, class T, bool UNIT, int LPR>
+__global__ __launch_bounds__(256) void row_stat_b_kernel(const P *__restrict__ rp, T *__restrict__ vs, T *__restrict__ out,
+                                                        const int32_t *__restrict__ list_b, int32_t n_b)
 {
     const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
     const int lane = threadIdx.x & (LPR - 1);
-    if (q >= nrows) return;
-    const int64_t r = row_list ? row_list[q] : q;
-    const int64_t sp = rp[r], ep = rp[r + 1];
-    if (ep - sp > ROW_LONG) {
-        if (lane == 0) long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
-        return;
+    if (q >= n_b) return;      // (LPR-lane groups leave together: the group shuffles below stay inside a group)
+    const int32_t r = list_b[q];
+    const int64_t sp = rp[r];
+    const int len = (int)((int64_t)rp[r + 1] - sp);
+    T v[RS_K];
+#pragma unroll
+    for (int j = 0; j < RS_K; j++) v[j] = j * LPR + lane < len ? vs[sp + j * LPR + lane] : (T)0;
+    if (UNIT) {
+        double vmax = 0.0;
+        bool nan = false;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++) {
+            const double a = fabs((double)v[j]);
+            nan |= a != a;
+            vmax = a > vmax ? a : vmax;
+        }
+        vmax = gmax_nan<LPR>(vmax, nan);
+        const T prenorm = (T)ldexp(1.0, prenorm_exp<T>(vmax));
+        double ss = 0.0;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++) {
+            v[j] = v[j] * prenorm;
+            ss += (double)v[j] * (double)v[j];
+        }
+        const T inorm = (T)sqrt(gsum<LPR>(ss));
+        if (lane == 0) out[r] = inorm / prenorm;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++)
+            if (j * LPR + lane < len) vs[sp + j * LPR + lane] = v[j] / inorm;
+    } else {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++) s += (double)v[j];
+        const T m = (T)(gsum<LPR>(s) / (double)len);
+        if (lane == 0) out[r] = m;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++)
+            if (j * LPR + lane < len) vs[sp + j * LPR + lane] = v[j] - m;
     }
-    if (med_min > 0 && ep - sp > med_min) {
-        if (lane == 0) med_rows[atomicAdd(n_med, 1)] = (int32_t)r;
-        return;
-    }
-    if (sp == ep) {
-        if (lane == 0) means[r] = (T)0;
-        return;
-    }
-    double s = 0.0;
-    for (int64_t k = sp + lane; k < ep; k += LPR) s += (double)vs[k];
-    const T m = (T)(gsum<LPR>(s) / (double)(ep - sp));
-    if (lane == 0) means[r] = m;
-    for (int64_t k = sp + lane; k < ep; k += LPR) vs[k] = vs[k] - m;
 }
 
-// Rows longer than ROW_LONG entries: one 1024-thread workgroup per row (a single wavefront would need
-// ~10^4 serial iterations for the 10^6-entry rows of a power-law matrix).  Block-wide reductions =
-// wavefront shuffles + one LDS stage, in a fixed order: deterministic.
-constexpr int ROW_LONG_THREADS = 1024;
+// Class C.  Chunk c of the listed long rows: entries [chunk_k0[c], chunk_k0[c] + chunk_len[c]) (one row's); long row i
+// owns chunks row_chunk0[i] .. row_chunk0[i + 1].
+template <class P>
+__global__ void row_chunk_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ list_c, int32_t n_c,
+                                       int32_t *__restrict__ cnt)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_c) cnt[i] = (int32_t)(((int64_t)rp[list_c[i] + 1] - (int64_t)rp[list_c[i]] + RS_CHUNK - 1) / RS_CHUNK);
+}
 
+template <class P>
+__global__ void row_chunk_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ list_c, int32_t n_c,
+                                      const int32_t *__restrict__ row_chunk0, int64_t *__restrict__ chunk_k0,
+                                      int32_t *__restrict__ chunk_len, int32_t *__restrict__ chunk_row)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_c) return;
+    const int64_t sp = rp[list_c[i]], ep = rp[list_c[i] + 1];
+    int32_t c = row_chunk0[i];
+    for (int64_t k = sp; k < ep; k += RS_CHUNK, c++) {
+        chunk_k0[c] = k;
+        chunk_len[c] = (int32_t)(ep - k < RS_CHUNK ? ep - k : RS_CHUNK);
+        chunk_row[c] = i;
+    }
+}
+
+// workgroup-wide reductions: wavefront shuffles + one LDS stage, in a fixed order (deterministic)
 __device__ __forceinline__ double block_sum(double v, double *s_red)
 {
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -162,129 +267,226 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     if (lane == 0) s_red[w] = v;
     __syncthreads();
     double t = 0.0;
-    for (int k = 0; k < ROW_LONG_THREADS / WAVE; k++) t += s_red[k];
+    for (int k = 0; k < RS_THREADS / WAVE; k++) t += s_red[k];
     return t;
 }
 
-template <class P, class T, bool UNIT>
-__global__ __launch_bounds__(ROW_LONG_THREADS) void row_stat_long_kernel(const P *__restrict__ rp, T *__restrict__ vs,
-                                                                        T *__restrict__ out,
-                                                                        const int32_t *__restrict__ long_rows)
+// C1: per-chunk partials.  UNIT: part_a = the chunk's maximum (NaN if it holds one), part_b = sum of squares of the
+// chunk's values under the chunk's own prescale 2^part_e; CENTER: part_a = the chunk's sum.
+template <class T, bool UNIT>
+__global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(const T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
+                                                                const int32_t *__restrict__ chunk_len,
+                                                                double *__restrict__ part_a, double *__restrict__ part_b,
+                                                                int32_t *__restrict__ part_e, const int32_t *__restrict__ n_chunks)
 {
-    __shared__ double s_red[ROW_LONG_THREADS / WAVE];
+    __shared__ double s_red[RS_THREADS / WAVE];
     __shared__ int s_nan;
-    const int32_t r = long_rows[blockIdx.x];
-    const int64_t sp = rp[r], ep = rp[r + 1];
+    if ((int32_t)blockIdx.x >= *n_chunks) return;      // (the grid is an upper bound of the chunk count)
+    const int64_t k0 = chunk_k0[blockIdx.x];
+    const int len = chunk_len[blockIdx.x];
     const int tid = threadIdx.x;
+    double v[RS_K];
+#pragma unroll
+    for (int j = 0; j < RS_K; j++) v[j] = j * RS_THREADS + tid < len ? (double)vs[k0 + j * RS_THREADS + tid] : 0.0;
     if (!UNIT) {
         double s = 0.0;
-        for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) s += (double)vs[k];
-        const T m = (T)(block_sum(s, s_red) / (double)(ep - sp));
-        if (tid == 0) out[r] = m;
-        for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) vs[k] = vs[k] - m;
+#pragma unroll
+        for (int j = 0; j < RS_K; j++) s += v[j];
+        s = block_sum(s, s_red);
+        if (tid == 0) part_a[blockIdx.x] = s;
         return;
     }
     if (tid == 0) s_nan = 0;
     __syncthreads();
     double vmax = 0.0;
     bool nan = false;
-    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
-        double a = fabs((double)vs[k]);
+#pragma unroll
+    for (int j = 0; j < RS_K; j++) {
+        const double a = fabs(v[j]);
         nan |= a != a;
         vmax = a > vmax ? a : vmax;
     }
     if (nan) s_nan = 1;
-    // block maximum through the same LDS stage (max is order independent)
-    {
+    {      // the workgroup's maximum through the same LDS stage (max is order independent)
         const int lane = tid & (WAVE - 1), w = tid / WAVE;
 #pragma unroll
         for (int off = WAVE / 2; off > 0; off >>= 1) {
-            double o = __shfl_down(vmax, off, WAVE);
+            const double o = __shfl_down(vmax, off, WAVE);
             vmax = o > vmax ? o : vmax;
         }
         __syncthreads();
         if (lane == 0) s_red[w] = vmax;
         __syncthreads();
         vmax = 0.0;
-        for (int k = 0; k < ROW_LONG_THREADS / WAVE; k++) vmax = s_red[k] > vmax ? s_red[k] : vmax;
+        for (int k = 0; k < RS_THREADS / WAVE; k++) vmax = s_red[k] > vmax ? s_red[k] : vmax;
         if (s_nan) vmax = __builtin_nan("");
     }
-    int ve = 0;
-    if (vmax == vmax && !isinf(vmax)) (void)frexp(vmax, &ve);
-    int pnexp = -ve;
-    pnexp = pnexp > FInfo<T>::maxexp - 1 ? FInfo<T>::maxexp - 1 : pnexp;
-    pnexp = pnexp < FInfo<T>::minexp ? FInfo<T>::minexp : pnexp;
-    const T prenorm = (T)ldexp(1.0, pnexp);
+    const int pe = prenorm_exp<T>(vmax);
+    const double pre = ldexp(1.0, pe);
     double ss = 0.0;
-    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
-        T v = vs[k] * prenorm;
-        ss += (double)v * (double)v;
+#pragma unroll
+    for (int j = 0; j < RS_K; j++) {
+        const double u = (double)(T)((T)v[j] * (T)pre);      // the reference's `v *= prenorm` in the storage dtype (:59)
+        ss += u * u;
     }
-    const T inorm = (T)sqrt(block_sum(ss, s_red));
-    if (tid == 0) out[r] = inorm / prenorm;
-    for (int64_t k = sp + tid; k < ep; k += ROW_LONG_THREADS) {
-        T v = vs[k] * prenorm;
-        vs[k] = v / inorm;
+    ss = block_sum(ss, s_red);
+    if (tid == 0) {
+        part_a[blockIdx.x] = vmax;
+        part_b[blockIdx.x] = ss;
+        part_e[blockIdx.x] = pe;
     }
 }
 
+// C2: one wavefront per long row: join the chunks' partials (lane l takes chunks l, l + 64, ... in order, the lanes are
+// joined by a fixed shuffle tree: deterministic).  UNIT: scale_a = prenorm, scale_b = inorm, out = inorm / prenorm;
+// CENTER: scale_a = out = the mean.
+template <class P, class T, bool UNIT>
+__global__ __launch_bounds__(256) void row_stat_c2_kernel(const P *__restrict__ rp, const int32_t *__restrict__ list_c, int32_t n_c,
+                                                         const int32_t *__restrict__ row_chunk0, const double *__restrict__ part_a,
+                                                         const double *__restrict__ part_b, const int32_t *__restrict__ part_e,
+                                                         T *__restrict__ scale_a, T *__restrict__ scale_b, T *__restrict__ out)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (i >= n_c) return;
+    const int32_t r = list_c[i];
+    const int32_t c0 = row_chunk0[i], c1 = row_chunk0[i + 1];
+    if (!UNIT) {
+        double s = 0.0;
+        for (int32_t c = c0 + lane; c < c1; c += WAVE) s += part_a[c];
+        const T m = (T)(wsum(s) / (double)((int64_t)rp[r + 1] - (int64_t)rp[r]));
+        if (lane == 0) {
+            scale_a[i] = m;
+            out[r] = m;
+        }
+        return;
+    }
+    double vmax = 0.0;
+    bool nan = false;
+    for (int32_t c = c0 + lane; c < c1; c += WAVE) {
+        const double a = part_a[c];
+        nan |= a != a;
+        vmax = a > vmax ? a : vmax;
+    }
+    vmax = wmax_nan(vmax, nan);
+    const int pe = prenorm_exp<T>(vmax);
+    double ss = 0.0;
+    for (int32_t c = c0 + lane; c < c1; c += WAVE) ss += ldexp(part_b[c], 2 * (pe - part_e[c]));      // exact rescaling of each chunk's sum
+    const T prenorm = (T)ldexp(1.0, pe);
+    const T inorm = (T)sqrt(wsum(ss));
+    if (lane == 0) {
+        scale_a[i] = prenorm;
+        scale_b[i] = inorm;
+        out[r] = inorm / prenorm;
+    }
+}
+
+// C3: apply
+template <class T, bool UNIT>
+__global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
+                                                                const int32_t *__restrict__ chunk_len,
+                                                                const int32_t *__restrict__ chunk_row,
+                                                                const T *__restrict__ scale_a, const T *__restrict__ scale_b,
+                                                                const int32_t *__restrict__ n_chunks)
+{
+    if ((int32_t)blockIdx.x >= *n_chunks) return;
+    const int64_t k0 = chunk_k0[blockIdx.x];
+    const int len = chunk_len[blockIdx.x];
+    const int32_t i = chunk_row[blockIdx.x];
+    const T a = scale_a[i], b = UNIT ? scale_b[i] : (T)0;
+#pragma unroll
+    for (int j = 0; j < RS_K; j++) {
+        const int k = j * RS_THREADS + (int)threadIdx.x;
+        if (k < len) {
+            const T v = vs[k0 + k];
+            vs[k0 + k] = UNIT ? (T)(v * a) / b : v - a;      // :59 then :64 / :24
+        }
+    }
+}
+
+// out_dev (optional): the norms / means stay on the device there (values dtype); out_host (optional): copied out
 template <bool UNIT>
-static int row_stat(Matrix *m, void *out_host)
+static int row_stat(Matrix *m, void *out_host, void *out_dev)
 {
     CSRK_REQUIRE(m->val_type != CSRK_VAL_NONE, "matrix has no values");
-    CSRK_REQUIRE(out_host || m->nrows == 0, "output is NULL");
+    CSRK_REQUIRE(out_host || out_dev || m->nrows == 0, "output is NULL");
     if (m->nrows == 0) return CSRK_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     invalidate_plans(m);          // the values change in place; the plans hold copies of them
-    DevBuf d, longs, nl;
-    CSRK_TRY(d.alloc((size_t)m->nrows * m->val_bytes()));
-    const int64_t max_long = m->nnz / ROW_LONG + 1;           // at most this many rows can be that long
-    CSRK_TRY(longs.alloc((size_t)max_long * 4));
-    CSRK_TRY(nl.alloc(4));
-    CSRK_HIP(hipMemset(nl.p, 0, 4));
-    // Mostly short rows (power-law matrices: half the rows of the headline matrix have <= 1 entry): 8 lanes per
-    // row for rows of <= 64 entries, the others collected and given a wavefront each in a second launch.
-    const bool short_rows = m->nnz / (int64_t)m->nrows < 64;
-    constexpr int MED_MIN = 64;
-    DevBuf meds, nm;
-    if (short_rows) {
-        CSRK_TRY(meds.alloc((size_t)(m->nnz / MED_MIN + 1) * 4));
-        CSRK_TRY(nm.alloc(4));
-        CSRK_HIP(hipMemset(nm.p, 0, 4));
+    DevBuf d, list_b8, list_b, list_c, counts;
+    const int64_t n_waves = ceil_div((int64_t)m->nrows, WAVE);
+    void *out = out_dev;
+    if (!out) {
+        CSRK_TRY(d.alloc((size_t)m->nrows * m->val_bytes()));
+        out = d.p;
     }
-    unsigned grid = (unsigned)ceil_div((int64_t)m->nrows * (short_rows ? 8 : WAVE), 256);
-#define ROW_ARGS(T, LIST, N, MEDMIN)                                                                      \
-    (const P_ *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), N, longs.as<int32_t>(), nl.as<int32_t>(), LIST, MEDMIN,    \
-        meds.as<int32_t>(), nm.as<int32_t>()
-#define GO(P, T)                                                                                          \
-    do {                                                                                                  \
-        typedef P P_;                                                                                     \
-        if (UNIT && short_rows)                                                                           \
-            unit_rows_kernel<P, T, 8><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, MED_MIN));      \
-        else if (UNIT)                                                                                    \
-            unit_rows_kernel<P, T, WAVE><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, 0));         \
-        else if (short_rows)                                                                              \
-            center_rows_kernel<P, T, 8><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, MED_MIN));    \
-        else                                                                                              \
-            center_rows_kernel<P, T, WAVE><<<grid, 256>>>(ROW_ARGS(T, (const int32_t *)nullptr, m->nrows, 0));       \
-        CSRK_LAUNCH_CHECK();                                                                              \
-        if (short_rows) {                                                                                 \
-            int32_t n_med = 0;                                                                            \
-            CSRK_HIP(hipMemcpy(&n_med, nm.p, 4, hipMemcpyDeviceToHost));                                  \
-            if (n_med > 0) {                                                                              \
-                const unsigned gm = (unsigned)ceil_div((int64_t)n_med * WAVE, 256);                       \
-                if (UNIT)                                                                                 \
-                    unit_rows_kernel<P, T, WAVE><<<gm, 256>>>(ROW_ARGS(T, meds.as<int32_t>(), n_med, 0)); \
-                else                                                                                      \
-                    center_rows_kernel<P, T, WAVE><<<gm, 256>>>(ROW_ARGS(T, meds.as<int32_t>(), n_med, 0));           \
-            }                                                                                             \
-        }                                                                                                 \
-        CSRK_LAUNCH_CHECK();                                                                              \
-        int32_t n_long = 0;                                                                               \
-        CSRK_HIP(hipMemcpy(&n_long, nl.p, 4, hipMemcpyDeviceToHost));                                     \
-        if (n_long > 0)                                                                                   \
-            row_stat_long_kernel<P, T, UNIT><<<(unsigned)n_long, ROW_LONG_THREADS>>>(                     \
-                (const P *)m->d_rowptrs, (T *)m->d_values, d.as<T>(), longs.as<int32_t>());               \
+    // at most nnz / 9 rows reach class B, nnz / 513 class C
+    CSRK_TRY(list_b8.alloc((size_t)(m->nnz / (RS_A + 1) + 1) * 4));
+    CSRK_TRY(list_b.alloc((size_t)(m->nnz / (RS_B8 + 1) + 1) * 4));
+    CSRK_TRY(list_c.alloc((size_t)(m->nnz / (RS_B + 1) + 1) * 4));
+    CSRK_TRY(counts.alloc((size_t)(3 * n_waves + 1) * 4));
+    const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
+#define GO(P, T)                                                                                                       \
+    do {                                                                                                               \
+        row_class_count_kernel<P><<<ga, 256>>>((const P *)m->d_rowptrs, m->nrows, n_waves, counts.as<int32_t>());       \
+        CSRK_LAUNCH_CHECK();                                                                                           \
+        CSRK_TRY(exclusive_scan_i32(counts.as<int32_t>(), counts.as<int32_t>(), 3 * n_waves, nullptr));                \
+        row_stat_a_kernel<P, T, UNIT><<<ga, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, m->nrows,       \
+                                                   n_waves, counts.as<int32_t>(), list_b8.as<int32_t>(),               \
+                                                   list_b.as<int32_t>(), list_c.as<int32_t>());                        \
+        CSRK_LAUNCH_CHECK();                                                                                           \
+        int32_t n_bc[4] = {0, 0, 0, 0};      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */         \
+        for (int c = 0; c < 4; c++)                                                                                    \
+            CSRK_HIP(hipMemcpyAsync(&n_bc[c], counts.as<int32_t>() + c * n_waves, 4, hipMemcpyDeviceToHost, nullptr)); \
+        CSRK_HIP(hipStreamSynchronize(nullptr));                                                                       \
+        const int32_t n_b8 = n_bc[1] - n_bc[0], n_b = n_bc[2] - n_bc[1], n_c = n_bc[3] - n_bc[2];                      \
+        if (n_b8 > 0) {                                                                                                \
+            row_stat_b_kernel<P, T, UNIT, 8><<<(unsigned)ceil_div((int64_t)n_b8 * 8, 256), 256>>>(                     \
+                (const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, list_b8.as<int32_t>(), n_b8);                      \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+        }                                                                                                              \
+        if (n_b > 0) {                                                                                                 \
+            row_stat_b_kernel<P, T, UNIT, WAVE><<<(unsigned)ceil_div((int64_t)n_b * WAVE, 256), 256>>>(                \
+                (const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, list_b.as<int32_t>(), n_b);                        \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+        }                                                                                                              \
+        if (n_c > 0) {                                                                                                 \
+            DevBuf rc0, ck0, clen, crow, pa, pb, pe, sa, sb;                                                           \
+            CSRK_TRY(rc0.alloc((size_t)(n_c + 2) * 4));                                                                \
+            const unsigned gc = (unsigned)ceil_div(n_c, 256);                                                          \
+            row_chunk_count_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>()); \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            CSRK_TRY(exclusive_scan_i32(rc0.as<int32_t>(), rc0.as<int32_t>(), n_c, nullptr));                          \
+            /* at most one partial chunk per long row beyond the full ones: no host round trip for the exact count */ \
+            const int64_t n_chunks = (int64_t)n_c + m->nnz / RS_CHUNK;                                                 \
+            CSRK_TRY(ck0.alloc((size_t)n_chunks * 8));                                                                 \
+            CSRK_TRY(clen.alloc((size_t)n_chunks * 4));                                                                \
+            CSRK_TRY(crow.alloc((size_t)n_chunks * 4));                                                                \
+            CSRK_TRY(pa.alloc((size_t)n_chunks * 8));                                                                  \
+            CSRK_TRY(pb.alloc((size_t)n_chunks * 8));                                                                  \
+            CSRK_TRY(pe.alloc((size_t)n_chunks * 4));                                                                  \
+            CSRK_TRY(sa.alloc((size_t)n_c * sizeof(T)));                                                               \
+            CSRK_TRY(sb.alloc((size_t)n_c * sizeof(T)));                                                               \
+            row_chunk_fill_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>(), \
+                                                  ck0.as<int64_t>(), clen.as<int32_t>(), crow.as<int32_t>());           \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            row_stat_c1_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((const T *)m->d_values, ck0.as<int64_t>(),  \
+                                                                            clen.as<int32_t>(), pa.as<double>(),        \
+                                                                            pb.as<double>(), pe.as<int32_t>(),          \
+                                                                            rc0.as<int32_t>() + n_c);                   \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            row_stat_c2_kernel<P, T, UNIT><<<(unsigned)ceil_div((int64_t)n_c * WAVE, 256), 256>>>(                     \
+                                                        (const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c,             \
+                                                        rc0.as<int32_t>(), pa.as<double>(), pb.as<double>(),            \
+                                                        pe.as<int32_t>(), sa.as<T>(), sb.as<T>(), (T *)out);            \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            row_stat_c3_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((T *)m->d_values, ck0.as<int64_t>(),        \
+                                                                            clen.as<int32_t>(), crow.as<int32_t>(),     \
+                                                                            sa.as<T>(), sb.as<T>(),                     \
+                                                                            rc0.as<int32_t>() + n_c);                   \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            CSRK_HIP(hipDeviceSynchronize());      /* the chunk tables are released here */                            \
+        }                                                                                                              \
     } while (0)
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, double); else GO(int64_t, float);
@@ -292,9 +494,8 @@ static int row_stat(Matrix *m, void *out_host)
         if (m->val_type == CSRK_VAL_F64) GO(int32_t, double); else GO(int32_t, float);
     }
 #undef GO
-#undef ROW_ARGS
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipMemcpy(out_host, d.p, (size_t)m->nrows * m->val_bytes(), hipMemcpyDeviceToHost));
+    CSRK_HIP(hipDeviceSynchronize());
+    if (out_host) CSRK_HIP(hipMemcpy(out_host, out, (size_t)m->nrows * m->val_bytes(), hipMemcpyDeviceToHost));
     return CSRK_OK;
 }
 
@@ -498,14 +699,28 @@ int csrk_unit_rows(csrk_handle_t h, void *norms)
 {
     Matrix *m = from_handle(h);
     if (!m) return CSRK_ERR_INVALID;
-    return row_stat<true>(m, norms);
+    return row_stat<true>(m, norms, nullptr);
 }
 
 int csrk_center_rows(csrk_handle_t h, void *means)
 {
     Matrix *m = from_handle(h);
     if (!m) return CSRK_ERR_INVALID;
-    return row_stat<false>(m, means);
+    return row_stat<false>(m, means, nullptr);
+}
+
+int csrk_unit_rows_device(csrk_handle_t h, void *d_norms)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    return row_stat<true>(m, nullptr, d_norms);
+}
+
+int csrk_center_rows_device(csrk_handle_t h, void *d_means)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    return row_stat<false>(m, nullptr, d_means);
 }
 
 int csrk_pick_rows(csrk_handle_t h, const int32_t *rows, int64_t n_rows, int with_values, csrk_handle_t *out)

@@ -209,6 +209,10 @@ CSRK_API int csrk_row_extent(csrk_handle_t h, int32_t row, int64_t *start, int64
  * norms / means in the VALUES' dtype (float32 or float64), host memory.  Requires values. */
 CSRK_API int csrk_unit_rows(csrk_handle_t h, void *norms);
 CSRK_API int csrk_center_rows(csrk_handle_t h, void *means);
+/* The same with the norms / means left in DEVICE memory (nrows entries of the values' dtype): the caller copies them out
+ * when and how it likes (a pinned buffer, another stream) -- 80 MB for 10^7 rows is 3 ms of pageable copy otherwise. */
+CSRK_API int csrk_unit_rows_device(csrk_handle_t h, void *d_norms);
+CSRK_API int csrk_center_rows_device(csrk_handle_t h, void *d_means);
 
 /* ---- order_columns (IN PLACE) -------------------------------------------------------------
  * csr/kernels/numba/__init__.py:47-52 -> csr/structure.py:156-169; lk_mkl_sporder.

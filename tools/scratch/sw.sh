@@ -1,4 +1,1 @@
-export SWEEP_STEPS=200
-timeout -k 10 300 python tools/sweep_inproc.py "" > gpurun_out/sweep_g.log 2>&1
-for v in w16 w12 w12b; do CSRK_LIBRARY=csr_amd/libcsrk_$v.so timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | sed "s/^/[$v] /" >> gpurun_out/sweep_g.log; done
-cat gpurun_out/sweep_g.log
+for v in rs256 rs512; do echo "== $v"; CSRK_LIBRARY=$PWD/csr_amd/libcsrk_$v.so tools/kstats_rowops.sh ks_$v 2>&1 | grep -v "^E2026\|^W2026" | grep "headline\|c1_kernel\|c3_kernel"; done
