@@ -1,6 +1,7 @@
 # scratch: local SpMV time of ONE rank's row range for world = 1, 2, 4, 8 (what the N-GPU bench computes per rank
 # before the exchange); usage: PYTHONPATH=. python tools/probe_rank.py
-import ctypes as C, torch
+import ctypes as C, torch, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from csr_amd import synth
 from csr_amd._lib import lib, check, handle_t
 dev = 'cuda'
