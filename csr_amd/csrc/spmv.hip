@@ -2635,7 +2635,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
 #define CSRK_STAGE_TILES 8
 #endif
 constexpr int LS_STAGE_TILES = CSRK_STAGE_TILES;     // tiles per staging round
-constexpr int LS_STAGE_WMAX = 9984;                   // columns per block at most: a 78-KiB window of x in LDS, two per CU
+constexpr int LS_STAGE_WMAX = 9984;                   // columns per block at most: a 78-KiB window of x in LDS, two per CU (one per CU with 156 KiB: 58 vs 46 us; three: 49)
 constexpr int LS_STAGE_THREADS = 1024, LS_STAGE_IPT = 8;
 
 __device__ __forceinline__ bool ls_is_cold(uint32_t ix) { return !(ix & LS_HOT_BIT) && (ix & LS_COL_MASK) != LS_PAD; }

@@ -127,6 +127,24 @@ def test_spmm_config3_full_size():
             _spmv(habs, xc.abs().contiguous(), yb)
             torch.cuda.synchronize()
             assert float(((Cm[:, c] - y).abs() / (yb + 1e-300)).max()) <= 1e-12
+        # ... and against the pinned oracle itself (the reference's mult_ab(A, CSR(B)) recurrence, multiply.py:110-122) on
+        # the rows holding the first 2e6 entries plus the 3 longest rows: every panel entry to 1e-12 of sum |a||b|
+        from oracle import oracle as O
+        rp_h = m['rowptrs'].cpu().numpy()
+        r_s = int(np.searchsorted(rp_h, 2_000_000))
+        e_s = int(rp_h[r_s])
+        B_h = B.cpu().numpy()
+        ci_h, vs_h = m['colinds'][:e_s].cpu().numpy(), m['values'][:e_s].cpu().numpy()
+        C_o = O.spmm_dense(r_s, rp_h[:r_s + 1], ci_h, vs_h, B_h)
+        C_b = O.spmm_dense(r_s, rp_h[:r_s + 1], ci_h, np.abs(vs_h), np.abs(B_h))
+        assert np.all(np.abs(Cm[:r_s].cpu().numpy() - C_o) <= 1e-12 * C_b + 1e-300)
+        for r in np.argsort(np.diff(rp_h))[-3:]:
+            a, b = int(rp_h[r]), int(rp_h[r + 1])
+            ci_r, vs_r = m['colinds'][a:b].cpu().numpy(), m['values'][a:b].cpu().numpy()
+            srp = np.array([0, b - a], dtype=np.int32)
+            c_o = O.spmm_dense(1, srp, ci_r, vs_r, B_h)[0]
+            c_b = O.spmm_dense(1, srp, ci_r, np.abs(vs_r), np.abs(B_h))[0]
+            assert np.all(np.abs(Cm[int(r)].cpu().numpy() - c_o) <= 1e-12 * c_b + 1e-300)
     finally:
         check(lib.csrk_free(h))
         check(lib.csrk_free(habs))

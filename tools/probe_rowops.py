@@ -18,5 +18,8 @@ def run(name, nr, nc, nnz, **kw):
         alg = 2 * nnz * 8 + nr * 12
         print(f'{name:12s} {op:12s} wall ms {min(ts):8.3f}  (algorithmic {alg/1e9:.2f} GB: values read + written, row pointers, norms -> {alg/min(ts)/1e6:.0f} GB/s = {alg/min(ts)/1e6/8000:.3f} of 8 TB/s; norms stay on the device)', flush=True)
     check(lib.csrk_free(h))
-run('cfg5 ML25M', 162_541, 59_047, 25_000_095, alpha=0.9, max_degree=7000)
-run('headline', 10_000_000, 10_000_000, 200_000_000)
+shape = os.environ.get('ROWOPS_SHAPE', 'both')
+if shape in ('ml', 'both'):
+    run('cfg5 ML25M', 162_541, 59_047, 25_000_095, alpha=0.9, max_degree=7000)
+if shape in ('headline', 'both'):
+    run('headline', 10_000_000, 10_000_000, 200_000_000)
