@@ -2950,12 +2950,15 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         int nt0 = LS_RND_MAXTILES / NW * NW;
         if (const char *e = getenv("CSRK_LS_RND_TILES")) nt0 = atoi(e) >= NW ? atoi(e) / NW * NW : nt0;
         rnd = false;
-        for (int nt = nt0; nt >= NW; nt -= NW) {
+        for (int nt = nt0; nt >= NW;) {
             CSRK_TRY(count_pass(nt, true, &max_round));
             if (max_round <= LS_RND_CAP) {
                 rnd = true;
                 break;
             }
+            // the fullest round scales with the round's size: jump to the size that would just fit, then step down
+            int next = (int)((double)nt * LS_RND_CAP / (double)max_round) / NW * NW;
+            nt = next < nt - NW ? next : nt - NW;
         }
     }
     if (!rnd) CSRK_TRY(count_pass(LS_STAGE_TILES, false, &max_round));
