@@ -489,7 +489,8 @@ def test_handle_cache_reaches_the_plan():
     from csr_amd.kernels import hip as K
     K.flush_handle_cache()
     w = synth.powerlaw_csr(40000, 600000, 1500000, device='cpu')
-    A = CSR(40000, 600000, 1500000, w['rowptrs'].numpy(), w['colinds'].numpy(), w['values'].numpy().copy())
+    # (arrays that own their memory: views -- torch-backed ones included -- are never cached under the write guard)
+    A = CSR(40000, 600000, 1500000, w['rowptrs'].numpy().copy(), w['colinds'].numpy().copy(), w['values'].numpy().copy())
     x = synth.dense_vector(600000).numpy()
 
     def check(y):
@@ -507,6 +508,7 @@ def test_handle_cache_reaches_the_plan():
     for y in ys:
         check(y)
     assert np.array_equal(ys[2], ys[3])
+    assert any(k[0] == id(A) for k in K._cache) and not A.values.flags.writeable      # cached, and guarded
     y_old = ys[3]
     with pytest.raises(ValueError):                         # ONE element edited between two products: refused, never ignored
         A.values[777] = 3.0
