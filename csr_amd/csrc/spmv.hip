@@ -114,6 +114,9 @@ struct LightStream {
     int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
     unsigned grid = 0;
     DevBuf vals, idx, rowids, tile_base, carry_idx, carry_row, carry_val;
+    // dense rows (build_light_stream): EVERY row of the view has a run -- a row without entries holds one padding entry --
+    // so run k is row k: no row-id table (`rowids` stays empty), no gaps to clear
+    bool dense = false;
     // cold staging (build_cold_stage): the x values of the stream's unpacked columns, copied per call into the
     // order the stream reads them
     int64_t n_cold = 0;
@@ -1503,6 +1506,15 @@ __global__ void ls_rowflag_kernel(const P *__restrict__ rpv, int32_t nrows, int3
     if (r <= nrows) flag[r] = (r < nrows && rpv[r + 1] > rpv[r]) ? 1 : 0;
 }
 
+// dense rows: rpd[r] = rpv[r] + (empty rows before r) -- every empty row of the view gets one slot; nz = exclusive scan of
+// the non-empty flags (so r - nz[r] = empty rows before r)
+template <class P>
+__global__ void ls_dense_ptr_kernel(const P *__restrict__ rpv, const int32_t *__restrict__ nz, int32_t nrows, P *__restrict__ rpd)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= nrows) rpd[r] = (P)((int64_t)rpv[r] + (r - (int64_t)nz[r]));
+}
+
 template <class P>
 __global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
                                  int32_t *__restrict__ rowids)
@@ -1535,8 +1547,10 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
                                                      const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                                      LsSegs sg, int64_t n_slots, const int32_t *__restrict__ phys_tile,
                                                      const int32_t *__restrict__ slot_map, double *__restrict__ svals,
-                                                     uint32_t *__restrict__ sidx)
+                                                     uint32_t *__restrict__ sidx, const P *__restrict__ rp_len)
 {
+    // rp_len (dense rows): the view's own row pointers; rpv then gives every row at least one slot, and a row that is
+    // empty in rp_len becomes one padding entry that opens (and is) its run
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     const int64_t lt = slot / ACC_TILE;
@@ -1549,12 +1563,16 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
     if (L < sg.ent0[q + 1]) {
         const int32_t r = ls_row_of(rpv, nrows, L);
         const int64_t first = (int64_t)rpv[r];
-        const int64_t a = (int64_t)src[r] + (L - first);
-        v = ValLoad<VT>::at(vs, a);
-        const int32_t c = ci[a];
-        const int32_t sl = slot_map ? slot_map[c] : -1;         // slot of a packed column
-        ix = sl >= 0 ? (LS_HOT_BIT | (uint32_t)sl) : (uint32_t)c;
-        if (L == first) ix |= LS_START_BIT;
+        if (rp_len && rp_len[r + 1] == rp_len[r]) {
+            ix = LS_PAD | LS_START_BIT;
+        } else {
+            const int64_t a = (int64_t)src[r] + (L - first);
+            v = ValLoad<VT>::at(vs, a);
+            const int32_t c = ci[a];
+            const int32_t sl = slot_map ? slot_map[c] : -1;         // slot of a packed column
+            ix = sl >= 0 ? (LS_HOT_BIT | (uint32_t)sl) : (uint32_t)c;
+            if (L == first) ix |= LS_START_BIT;
+        }
     }
     svals[t * ACC_TILE + acc_val_slot(el)] = v;
     sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
@@ -1608,8 +1626,9 @@ __device__ unsigned long long g_ls_stamps[4096 * LS_NSTAMP];
 // offset there.  The copy pass can then use rounds of 64 tiles (its store transactions are per (round, column block)
 // bucket: 0.049 ms against 0.065 at 8 tiles) without the stream side paying for it in L1 lines (0.257 ms at 64 tiles when
 // the round's range is read by gathers).  Two workgroup barriers per round.
+// DENSE: run k is row k (LightStream::dense): row ids are not loaded and there are no gaps between runs to clear.
 constexpr int LS_PLAIN = 0, LS_XGT = 1, LS_RND = 2;
-template <int MODE>
+template <int MODE, bool DENSE = false>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
@@ -1733,7 +1752,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             for (int j = 0; j < ACC_K; j++) {
                 const uint32_t c = e[j] & LS_COL_MASK;
                 const bool hot = (e[j] & LS_HOT_BIT) != 0;
-                inl[j] = e[j] != LS_PAD && (!hot || (int32_t)c < n_lds);      // (a padding slot multiplies 0 * 0)
+                inl[j] = c != LS_PAD && (!hot || (int32_t)c < n_lds);      // (a padding slot multiplies 0 * 0)
                 gv[j] = 0.0;
                 if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
             }
@@ -1747,7 +1766,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 inl[j] = hot && (int32_t)c < n_lds;
                 gv[j] = 0.0;
                 const double *g = hot ? xh + c : x + c;
-                if (!inl[j] && e[j] != LS_PAD) gv[j] = *g;          // padding slots gather nothing and multiply 0 * 0
+                if (!inl[j] && c != LS_PAD) gv[j] = *g;          // padding slots gather nothing and multiply 0 * 0
             }
         }
         // row ids of the tile's first run slots (slot k <-> run tb - 1 + k): requested now, used at the end
@@ -1755,7 +1774,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
         for (int i = 0; i < LS_RID; i++) {
             const int run = tb - 1 + lane + i * WAVE;
-            rid[i] = rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)];
+            const int runc = run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run);
+            rid[i] = DENSE ? runc : rowids[runc];
         }
         asm volatile("" ::: "memory");      // (compiler-level: keep the two groups of loads in this order)
         {
@@ -1794,7 +1814,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 const uint32_t c = e[j] & LS_COL_MASK;
                 const bool hot = (e[j] & LS_HOT_BIT) != 0;
                 const bool lds_hot = hot && (int32_t)c < n_lds;
-                const bool cold = !hot && e[j] != LS_PAD;
+                const bool cold = !hot && c != LS_PAD;
                 inl[j] = lds_hot || cold;                       // served from LDS: the hot slots or the staged range
                 const double *src = cold ? s_out + c : s_hot + (lds_hot ? c : 0);
                 lv[j] = *src;
@@ -1803,7 +1823,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) {
                 const uint32_t c = e[j] & LS_COL_MASK;
-                const bool cold = !(e[j] & LS_HOT_BIT) && e[j] != LS_PAD;
+                const bool cold = !(e[j] & LS_HOT_BIT) && c != LS_PAD;
                 const double *src = cold ? s_rnd + c : s_hot + (inl[j] ? c : 0);
                 lv[j] = *src;
             }
@@ -1899,10 +1919,13 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                     carry_row[ct] = opens ? -1 : r;              // r = rowids[tb - 1] (clamped when tb == 0: then it opens)
                 } else {
                     y[r] = val;
-                    g0 = run > 0 ? (int64_t)r_prev + 1 : 0;
-                    g1 = r;
+                    if (!DENSE) {
+                        g0 = run > 0 ? (int64_t)r_prev + 1 : 0;
+                        g1 = r;
+                    }
                 }
             }
+            if (DENSE) return;
             const int64_t gap = g1 - g0;
             if (gap > 0 && gap <= 4) {
                 for (int64_t q = g0; q < g1; q++) y[q] = 0.0;
@@ -1922,9 +1945,10 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll 1
         for (int k0 = LS_RID * WAVE; k0 <= total; k0 += WAVE) {
             const int run = tb - 1 + k0 + lane;
-            out_batch(k0, rowids[run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run)]);
+            const int runc = run < 0 ? 0 : (run > n_runs - 1 ? n_runs - 1 : run);
+            out_batch(k0, DENSE ? runc : rowids[runc]);
         }
-        if (total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
+        if (!DENSE && total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
             for (int64_t q = (int64_t)rowids[n_runs - 1] + 1 + lane; q < nrows; q += WAVE) y[q] = 0.0;
         }
         LS_STAMP(4)
@@ -2557,9 +2581,12 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
 template <class P, int VT>
 static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, int32_t nrows_view, const int32_t *ci,
                         const void *vs, const LsSegs &sg, int64_t n_tiles, const std::vector<int32_t> *phys, int32_t n_out,
-                        const int32_t *slot_map, hipStream_t s)
+                        const int32_t *slot_map, hipStream_t s, const P *rp_len = nullptr)
 {
+    // rp_len (dense rows): rpv gives every row of the view at least one slot; a row that is empty in rp_len is one padding
+    // entry.  Run k is then row k, and no row-id table is built.
     ls->on = false;
+    ls->dense = rp_len != nullptr;
     DevBuf ridx, dphys;
     CSRK_TRY(ridx.alloc((size_t)(nrows_view + 2) * 4));
     const unsigned gr = (unsigned)ceil_div((int64_t)nrows_view + 1, 256);
@@ -2570,9 +2597,11 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + nrows_view, 4, hipMemcpyDeviceToHost, s));
     CSRK_HIP(hipStreamSynchronize(s));
     if (n_runs < 1) return CSRK_OK;
-    CSRK_TRY(ls->rowids.alloc((size_t)n_runs * 4));
-    ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
+    if (!ls->dense) {
+        CSRK_TRY(ls->rowids.alloc((size_t)n_runs * 4));
+        ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+    }
     const int32_t *d_phys = nullptr;
     if (phys) {
         CSRK_TRY(dphys.alloc((size_t)n_tiles * 4));
@@ -2583,7 +2612,8 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
     ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>());
+        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(),
+        rp_len);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
     ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
@@ -2600,6 +2630,12 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(160 * 1024)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
     const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
@@ -3057,13 +3093,43 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
     if ((size_t)n_tiles * ACC_TILE * 12 + ((size_t)m->nrows + n_tiles) * 8 + (64u << 20) > mfree && !(env && env[0] == '1'))
         return CSRK_OK;
+    // Dense rows: when few rows of the view are empty (rows without entries, rows cut out for the tiers: 7 % on the
+    // headline matrix) each of them gets ONE padding entry, so every row has a run, run k IS row k, and the stream kernel
+    // neither loads row ids (4 loads per tile: 12 of its 170 us) nor clears gaps.  rpd = the view's pointers with empty
+    // rows widened to one slot.  Not when the padding would add more than an eighth to the stream, nor past P's range.
+    DevBuf rpd_buf;
+    const P *rp_dense = nullptr;
+    int64_t n_view_d = n_view, n_tiles_d = n_tiles;
+    {
+        const char *de = getenv("CSRK_LS_DENSE");
+        DevBuf nz;
+        CSRK_TRY(nz.alloc((size_t)(m->nrows + 2) * 4));
+        ls_rowflag_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, m->nrows, nz.as<int32_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_TRY(exclusive_scan_i32(nz.as<int32_t>(), nz.as<int32_t>(), m->nrows, s));
+        int32_t n_nonempty = 0;
+        CSRK_HIP(hipMemcpyAsync(&n_nonempty, nz.as<int32_t>() + m->nrows, 4, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        const int64_t n_pad = (int64_t)m->nrows - n_nonempty;
+        const bool fits = sizeof(P) == 8 || n_view + n_pad <= (int64_t)INT32_MAX;
+        if (!(de && de[0] == '0') && fits && (n_pad * 8 <= n_view || (de && de[0] == '1'))) {
+            CSRK_TRY(rpd_buf.alloc((size_t)(m->nrows + 1) * sizeof(P)));
+            ls_dense_ptr_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, nz.as<int32_t>(), m->nrows,
+                                                                                                rpd_buf.as<P>());
+            CSRK_LAUNCH_CHECK();
+            rp_dense = rpd_buf.as<P>();
+            n_view_d = n_view + n_pad;
+            n_tiles_d = ceil_div(n_view_d, ACC_TILE);
+        }
+        CSRK_HIP(hipStreamSynchronize(s));      // nz is released here
+    }
     LsSegs sg;
     sg.n = 1;
-    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles * ACC_TILE, sg.ent0[k] = n_view;
+    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles_d * ACC_TILE, sg.ent0[k] = n_view_d;
     sg.slot0[0] = 0;
     sg.ent0[0] = 0;
-    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles, nullptr, m->nrows,
-                                  slot_map, s)));
+    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rp_dense ? rp_dense : rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles_d,
+                                  nullptr, m->nrows, slot_map, s, rp_dense ? rpv : (const P *)nullptr)));
     if (p->ls.on && p->n_hot) {
         CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
         // (round-in-LDS form: the round's staged values take the place of the hot window's tail)
@@ -3468,17 +3534,21 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),      \
         (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
         p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>()
-                if (p->ls.n_cold && p->ls.round_start.p) {
-                    constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-                    spmv_lstream_kernel<LS_RND><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(LS_ARGS, p->ls.round_start.as<int32_t>(),
-                                                                                          p->ls.round_tile0.as<int32_t>(),
-                                                                                          p->ls.wg_round0.as<int32_t>());
-                } else if (p->ls.n_cold && p->ls.tile_cold.p)
-                    spmv_lstream_kernel<LS_XGT><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), (const int32_t *)nullptr,
-                                                                                          (const int32_t *)nullptr);
-                else
-                    spmv_lstream_kernel<LS_PLAIN><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                                                                                            (const int32_t *)nullptr);
+                constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
+                const int32_t *nil = nullptr;
+#define LS_GO(D)                                                                                                       \
+    do {                                                                                                               \
+        if (p->ls.n_cold && p->ls.round_start.p)                                                                       \
+            spmv_lstream_kernel<LS_RND, D><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                                    \
+                LS_ARGS, p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(), p->ls.wg_round0.as<int32_t>()); \
+        else if (p->ls.n_cold && p->ls.tile_cold.p)                                                                    \
+            spmv_lstream_kernel<LS_XGT, D><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), nil, nil); \
+        else                                                                                                           \
+            spmv_lstream_kernel<LS_PLAIN, D><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, nil, nil, nil);           \
+    } while (0)
+                if (p->ls.dense) LS_GO(true);
+                else LS_GO(false);
+#undef LS_GO
 #undef LS_ARGS
                 kl.stop();
                 CSRK_LAUNCH_CHECK();
