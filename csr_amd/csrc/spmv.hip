@@ -1058,7 +1058,7 @@ __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t 
 constexpr int ACC_CB = 4096;
 constexpr int ACC_K = 8;                      // consecutive entries per lane
 constexpr int ACC_TILE = WAVE * ACC_K;        // 512
-constexpr int ACC_MAXROWS = 15360;            // heavy rows per group: 120 KiB of accumulators + 32 KiB window + heads <= 160 KiB
+constexpr int ACC_MAXROWS = 15936;            // heavy rows per group: 124.5 KiB of accumulators + 32 KiB window + 3 KiB of head slots <= 160 KiB
 constexpr int ACC_FLOOR = 128;                // tier 0 is never extended to rows shorter than this (512 before the 10-B stream: a rank of an 8-way split ran 0.129 ms, 0.119 with 128)
 constexpr int ACC_SEG_TILES = 256;            // head slots per segment
 constexpr int ACC_THREADS = 1024;
