@@ -1677,7 +1677,9 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             const int k = 2 * (q * LS_THREADS + (int)threadIdx.x);
-            rv[q] = *(const F64x2 *)(x + r0 + (k < rn ? k : 0));
+            // (non-temporal, like the y stores below: read / written once per product -- kept out of the caches they leave
+            // x there for the next product's copy pass: 48 -> 42 us, the step 0.547 -> 0.538 ms)
+            rv[q] = __builtin_nontemporal_load((const F64x2 *)(x + r0 + (k < rn ? k : 0)));
         }
     };
     if (RND && R_begin < R_end) round_request(R_begin);
@@ -1918,7 +1920,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                     carry_val[ct] = val;
                     carry_row[ct] = opens ? -1 : r;              // r = rowids[tb - 1] (clamped when tb == 0: then it opens)
                 } else {
-                    y[r] = val;
+                    __builtin_nontemporal_store(val, y + r);
                     if (!DENSE) {
                         g0 = run > 0 ? (int64_t)r_prev + 1 : 0;
                         g1 = r;
