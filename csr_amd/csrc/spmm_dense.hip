@@ -143,8 +143,9 @@ __device__ __forceinline__ void mm_store4(double *__restrict__ dst, int32_t c, i
     if (c >= k) return;
     if (FULL4) {
         mm_f64x2 t0 = {acc[0], acc[1]}, t1 = {acc[2], acc[3]};
-        *(MMF64x2 *)(dst + c) = t0;
-        *(MMF64x2 *)(dst + c + 2) = t1;
+        // (non-temporal: panel rows are written once; kept out of L2 they leave more of it to the B rows: 2.61 -> 2.57 ms)
+        __builtin_nontemporal_store(t0, (MMF64x2 *)(dst + c));
+        __builtin_nontemporal_store(t1, (MMF64x2 *)(dst + c + 2));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++)

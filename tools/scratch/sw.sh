@@ -1,3 +1,5 @@
-export SWEEP_STEPS=200
-for v in rndnt ynt bothnt; do CSRK_LIBRARY=csr_amd/libcsrk_$v.so timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults | sed "s/^/[$v] /"; done
-timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults
+for lib in csr_amd/libcsrk.so csr_amd/libcsrk_nt2.so; do
+  echo "== $lib"
+  CSRK_LIBRARY=$PWD/$lib python tools/bench_configs.py spmm 2>&1 | grep -o '"ms": [0-9.]*' | head -1
+  CSRK_LIBRARY=$PWD/$lib ROWOPS_SHAPE=headline python tools/probe_rowops.py 2>&1 | grep headline | cut -c1-60
+done
