@@ -1615,6 +1615,19 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                     esc_min = -1;                // beyond the sort's budget: the round-1 heavy-row paths take these rows
                     continue;
                 }
+                // ... and into device memory?  The product matrix, its two transposes and the sort's scratch are ~52 B per
+                // product at the peak; when that is not there even after the pool has given its cached blocks back, the same paths take over
+                // instead of failing the whole product on an allocation half-way through.
+                size_t mfree = 0, mtotal = 0;
+                CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+                if ((size_t)esc_products * 52 + (64u << 20) > mfree) {
+                    (void)csrk_trim_cache();
+                    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+                    if ((size_t)esc_products * 52 + (64u << 20) > mfree) {
+                        esc_min = -1;
+                        continue;
+                    }
+                }
             }
             break;
         }
@@ -1655,9 +1668,12 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             Matrix *pm = nullptr, *pt = nullptr;
             CSRK_TRY(new_matrix(n_esc, b->ncols, esc_products, 0, CSRK_VAL_F64, &pm));
             sg_esc_rowptr<<<(unsigned)ceil_div(n_esc + 1, 256), 256>>>(esc_off.as<int64_t>(), n_esc, (int32_t *)pm->d_rowptrs);
+            int erc = hipGetLastError() == hipSuccess ? CSRK_OK : CSRK_ERR_HIP;
             sg_esc_expand<FAST><<<(unsigned)n_esc, 256>>>(av, bv, list_e.as<int32_t>(), esc_off.as<int64_t>(), pm->d_colinds,
                                                           (double *)pm->d_values);
-            int erc = transpose_matrix(pm, 1, &pt, nullptr);
+            if (erc == CSRK_OK && hipGetLastError() != hipSuccess) erc = CSRK_ERR_HIP;
+            if (erc != CSRK_OK) set_error("expand-sort-compress: kernel launch failed");
+            if (erc == CSRK_OK) erc = transpose_matrix(pm, 1, &pt, nullptr);
             delete pm;
             if (erc == CSRK_OK) erc = transpose_matrix(pt, 1, &esc_ps, nullptr);
             delete pt;

@@ -92,7 +92,8 @@ struct Panel {
 
 // one segment of an accumulator-form workgroup's tile range (see "long rows, accumulator form")
 struct AccSeg {
-    int64_t tile0;    // first tile of the segment
+    int64_t tile0;    // first tile of the segment (logical: block-major order)
+    int64_t ptile0;   // ... and where it is stored; the segment's tile t is stored at ptile0 + t * n_wg
     int32_t ntiles;   // <= ACC_SEG_TILES, all in one column block
     int32_t blk;
 };
@@ -1146,6 +1147,25 @@ __global__ __launch_bounds__(256) void acc_gap_kernel(int64_t *__restrict__ cnt,
     }
 }
 
+// Where logical tile t is stored.  Workgroup w owns the logical tiles [wg_t0[w], wg_t0[w + 1]); its k-th tile is stored
+// at k * n_wg + w, i.e. the workgroups' streams are interleaved tile by tile: the persistent workgroups advance at
+// about the same pace, so at any moment they read one contiguous ~1 MB window of the array, spread over all HBM
+// channels.  (Contiguous per-workgroup ranges put 256 concurrent streams at a fixed stride: when that stride
+// resonates with the channel interleave the kernel loses up to 38 % -- 0.129 -> 0.177 ms measured on a 2-way partition's
+// shard at 580 tiles per workgroup, 0.218 -> 0.224 on the headline matrix; any other workgroup count restored the rate.)
+__device__ __forceinline__ int64_t acc_phys_tile(int64_t t, const int64_t *__restrict__ wg_t0, int32_t n_wg)
+{
+    int32_t lo = 0, hi = n_wg - 1;      // the workgroup with wg_t0[w] <= t < wg_t0[w + 1]
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo + 1) >> 1);
+        if (wg_t0[mid] <= t)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return (t - wg_t0[lo]) * n_wg + lo;
+}
+
 // one thread per (block, heavy row) pair: copies the pair's entries into the tiled stream (after the padding
 // entries that bridge a long step)
 template <class P, int VT>
@@ -1153,7 +1173,8 @@ __global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restr
                                 const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks, int32_t cb,
                                 const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
                                 const int32_t *__restrict__ pstart, const int32_t *__restrict__ gap,
-                                double *__restrict__ pvals, uint16_t *__restrict__ pidx, int32_t *__restrict__ tile_row0)
+                                double *__restrict__ pvals, uint16_t *__restrict__ pidx, int32_t *__restrict__ tile_row0,
+                                const int64_t *__restrict__ wg_t0, int32_t n_wg)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_heavy * n_blocks) return;
@@ -1166,19 +1187,22 @@ __global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restr
     const int32_t r = heavy_row[c];
     const int64_t lo = (int64_t)rp[r] + pstart[i];
     int64_t L = blk_tile0[b] * ACC_TILE + (off[i] - off[(int64_t)b * n_heavy]);      // logical position
+    int64_t t_of = -1, pt = 0;                                 // the logical tile last looked up and where it is stored
     for (int32_t k = 1; k <= npad; k++, L++) {                 // padding entry k stands on heavy row c - g + 7k
         const int64_t t = L / ACC_TILE;
         const int el = (int)(L % ACC_TILE);
-        pvals[t * ACC_TILE + acc_val_slot(el)] = 0.0;
-        pidx[L] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
+        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
+        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
+        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
         if (el == 0) tile_row0[t] = c - g + ACC_MAXSTEP * k;
     }
     int32_t step = g - ACC_MAXSTEP * npad;                     // first entry: from the previous row (or padding) to c
     for (int64_t k = lo; k < lo + n; k++, L++) {
         const int64_t t = L / ACC_TILE;
         const int el = (int)(L % ACC_TILE);
-        pvals[t * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
-        pidx[L] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? (uint32_t)step : 0u) << ACC_ROW_SHIFT));
+        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
+        pvals[pt * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
+        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? (uint32_t)step : 0u) << ACC_ROW_SHIFT));
         if (el == 0) tile_row0[t] = c;
         step = 0;
     }
@@ -1188,17 +1212,17 @@ __global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restr
 // block's last heavy row) -- a padding entry adds 0.0 * 0.0 to an accumulator
 __global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
                                                      const int64_t *__restrict__ blk_tile0, double *__restrict__ pvals,
-                                                     uint16_t *__restrict__ pidx)
+                                                     uint16_t *__restrict__ pidx, const int64_t *__restrict__ wg_t0, int32_t n_wg)
 {
     const int32_t b = blockIdx.x;
     if (b >= n_blocks) return;
     const int64_t cnt = off[(int64_t)(b + 1) * n_heavy] - off[(int64_t)b * n_heavy];
     const int64_t L0 = blk_tile0[b] * ACC_TILE + cnt, L1 = blk_tile0[b + 1] * ACC_TILE;
-    for (int64_t L = L0 + threadIdx.x; L < L1; L += blockDim.x) {
-        const int64_t t = L / ACC_TILE;
+    for (int64_t L = L0 + threadIdx.x; L < L1; L += blockDim.x) {      // (the tail of the block's last tile: one tile)
+        const int64_t pt = acc_phys_tile(L / ACC_TILE, wg_t0, n_wg);
         const int el = (int)(L % ACC_TILE);
-        pvals[t * ACC_TILE + acc_val_slot(el)] = 0.0;
-        pidx[L] = (uint16_t)ACC_CB;
+        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
+        pidx[pt * ACC_TILE + el] = (uint16_t)ACC_CB;
     }
 }
 
@@ -1252,9 +1276,10 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
         u32x4_t ix, ixn;                  // eight 16-bit index words per lane
         int32_t tr0 = 0, tr0n = 0;        // heavy-row index of the tile's first entry
         int t = wv;
+        const int64_t pstep = (int64_t)gridDim.x;      // the workgroups' tiles are interleaved (acc_phys_tile)
         if (t < nt) {
-            const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.tile0 + t) * ACC_TILE);
-            const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.tile0 + t) * ACC_TILE);
+            const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.ptile0 + t * pstep) * ACC_TILE);
+            const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.ptile0 + t * pstep) * ACC_TILE);
 #pragma unroll
             for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
             ix = __builtin_nontemporal_load(ip + lane);
@@ -1263,8 +1288,8 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
         for (; t < nt; t += NW) {
             const bool more = t + NW < nt;
             if (more) {      // next tile's loads are in flight while this one is reduced
-                const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.tile0 + t + NW) * ACC_TILE);
-                const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.tile0 + t + NW) * ACC_TILE);
+                const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.ptile0 + (t + NW) * pstep) * ACC_TILE);
+                const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.ptile0 + (t + NW) * pstep) * ACC_TILE);
 #pragma unroll
                 for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
                 ixn = __builtin_nontemporal_load(ip + lane);
@@ -2251,36 +2276,47 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div(be[b + 1] - be[b], ACC_TILE);
     const int64_t n_tiles = t0[nb];
     CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
-    CSRK_TRY(ap->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
-    CSRK_TRY(ap->idx.alloc((size_t)n_tiles * ACC_TILE * 2));
-    CSRK_TRY(ap->tile_row0.alloc((size_t)n_tiles * 4));
-    acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
-        rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
-        pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
-                                               ap->idx.as<uint16_t>());
-    CSRK_LAUNCH_CHECK();
-
-    // persistent workgroups: one per CU, equal shares of the tiles, cut into one-block segments
+    // persistent workgroups: one per CU, equal shares of the tiles (stored interleaved: acc_phys_tile), cut into one-block
+    // segments
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
     int64_t n_wg = cus > 0 ? cus : 256;
     if (const char *e = getenv("CSRK_ACC_WGS")) n_wg = atoll(e) > 0 ? atoll(e) : n_wg;
     if (n_wg > n_tiles) n_wg = n_tiles;
+    if (n_wg < 1) n_wg = 1;
+    std::vector<int64_t> wg_t0((size_t)n_wg + 1);
+    int64_t share_max = 0;
+    for (int64_t w = 0; w <= n_wg; w++) wg_t0[(size_t)w] = n_tiles * w / n_wg;
+    for (int64_t w = 0; w < n_wg; w++) share_max = std::max(share_max, wg_t0[(size_t)w + 1] - wg_t0[(size_t)w]);
+    const int64_t n_phys = share_max * n_wg;      // stored tiles (the last sweep has holes where a share is one tile shorter)
+    DevBuf d_wg_t0;
+    CSRK_TRY(d_wg_t0.alloc((size_t)(n_wg + 1) * 8));
+    CSRK_HIP(hipMemcpyAsync(d_wg_t0.p, wg_t0.data(), (size_t)(n_wg + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * 8));
+    CSRK_TRY(ap->idx.alloc((size_t)n_phys * ACC_TILE * 2));
+    CSRK_TRY(ap->tile_row0.alloc((size_t)(n_tiles ? n_tiles : 1) * 4));
+    acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
+        rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
+        pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(),
+        d_wg_t0.as<int64_t>(), (int32_t)n_wg);
+    CSRK_LAUNCH_CHECK();
+    acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
+                                               ap->idx.as<uint16_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg);
+    CSRK_LAUNCH_CHECK();
     std::vector<AccSeg> segs;
     std::vector<int32_t> wg_seg((size_t)n_wg + 1);
     int32_t b = 0;
     for (int64_t w = 0; w < n_wg; w++) {
         wg_seg[(size_t)w] = (int32_t)segs.size();
-        int64_t t = n_tiles * w / n_wg;
-        const int64_t t_end = n_tiles * (w + 1) / n_wg;
+        int64_t t = wg_t0[(size_t)w];
+        const int64_t t_end = wg_t0[(size_t)w + 1];
         while (t < t_end) {
             while (t0[b + 1] <= t) b++;
             int64_t e = t_end < t0[b + 1] ? t_end : t0[b + 1];
             if (e - t > ACC_SEG_TILES) e = t + ACC_SEG_TILES;
             AccSeg sg;
             sg.tile0 = t;
+            sg.ptile0 = (t - wg_t0[(size_t)w]) * n_wg + w;
             sg.ntiles = (int32_t)(e - t);
             sg.blk = b;
             segs.push_back(sg);

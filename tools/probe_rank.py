@@ -25,5 +25,5 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         torch.cuda.synchronize(); nr = C.c_int(0); km = (C.c_float * 4)(); check(lib.csrk_spmv_profile_end4(h, C.byref(nr), km))
         print('   kernels ms: light %.4f  tier0 %.4f  tier1 %.4f  stage %.4f' % tuple(km), flush=True)
         st = (C.c_int64 * 25)(); check(lib.csrk_spmv_plan_stats(h, st, 25))
-        print(f'world {world} rank {rank}: rows {nl} nnz {int(ci.numel())}: {e0.elapsed_time(e1) / 30:.4f} ms  (tier0 rows {st[9]} entries {st[10]}, tier1 entries {st[13]}, light {st[3]}, pack {st[16]}, staged {st[24]})', flush=True)
+        print(f'world {world} rank {rank}: rows {nl} nnz {int(ci.numel())}: {e0.elapsed_time(e1) / 30:.4f} ms  (tier0 rows {st[9]} entries {st[10]} slots {st[4]*512}, tier1 entries {st[13]}, light {st[3]}, pack {st[16]}, staged {st[24]})', flush=True)
         check(lib.csrk_free(h)); del sh, rp, ci, vs, y
