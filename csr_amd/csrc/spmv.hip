@@ -1400,8 +1400,9 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
 //   reduce: y[row_list[h]] = sum over w < n_wg of partial[w][h], in order, then the row's listed carries (crp/cidx: the
 //           tiles of the pair kernel whose last row end falls in a pair of long row h), in tile order.  A workgroup takes
 //           1024 / (64 G) sets of 64 rows; the G wavefronts of a set each sum a contiguous range of w, joined in order
-//           through LDS.  G = 16 for tier 0 (256 partials per row), 2 for tier 1 (38): 240 + 135 + 78 workgroups on the
-//           headline matrix, all resident at once (two per CU) -- 588 of them (G = 4) ran as two rounds: 21.9 us.
+//           through LDS.  G = 4 for tier 0 (256 partials per row: 64 per wavefront), 2 for tier 1 (38 blocks).  Measured
+//           on the headline matrix (tier 0 / tier 1): 16 / 2 -> 21.1 us, 8 / 2 -> 19.1, 4 / 2 -> 17.4, 2 / 2 -> 23.7,
+//           1 / 2 -> 38.2, 4 / 4 -> 18.5, 16 / 4 (588 workgroups: two rounds) -> 21.9.
 struct EpiJob {
     int32_t kind, blocks;      // 0 = fix, 1 = reduce
     // fix
@@ -3623,7 +3624,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         }
         if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
-                CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 16, nullptr, nullptr, nullptr));
+                CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 4, nullptr, nullptr, nullptr));
         for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
             Panel *pn = &p->tier[q];
             if (!pn->on || (q == 0 && !p->acc.empty())) continue;
