@@ -1,1 +1,3 @@
-for cfg in "CSRK_EXP_G0=2" "CSRK_EXP_G0=1" "CSRK_EXP_G0=4 CSRK_EXP_G1=4" "CSRK_EXP_G0=2 CSRK_EXP_G1=4" "CSRK_EXP_G0=4 CSRK_EXP_G1=8" "CSRK_EXP_G0=2 CSRK_EXP_G1=8"; do echo "== $cfg"; tools/kstats.sh ks_tmp "$cfg" 2>&1 | grep "epilogue" | cut -c62-100; done
+export SWEEP_STEPS=200
+for v in sa sb sc sd; do CSRK_LIBRARY=csr_amd/libcsrk_$v.so timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults | sed "s/^/[$v] /" | cut -c1-110; done
+timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults | cut -c1-110
