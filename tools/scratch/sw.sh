@@ -1,3 +1,2 @@
-export SWEEP_STEPS=200
-for v in sa sb sc sd; do CSRK_LIBRARY=csr_amd/libcsrk_$v.so timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults | sed "s/^/[$v] /" | cut -c1-110; done
-timeout -k 10 300 python tools/sweep_inproc.py "" 2>&1 | grep defaults | cut -c1-110
+timeout -k 10 300 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "unit or center" 2>&1 | tail -5 && \
+ROWOPS_SHAPE=both bash tools/kstats_rowops.sh ks_cf3 2>&1 | grep -v "^E2026\|^W2026" | tail -24
