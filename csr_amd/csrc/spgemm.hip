@@ -155,9 +155,17 @@ constexpr int SG_WAVE_CAP = 128;  // rows with at most this many products take t
 // whose rows have up to 7000 entries.)  Eight lanes per row (most rows of a sparse product have a handful of entries: a wavefront per row took 159 us for 10^6
 // rows); rows of more than SG_COUNT_LONG entries are listed for sg_count_products_long, a wavefront each.
 constexpr int SG_COUNT_LONG = 64;
+// The long rows are appended to SG_LONG_LISTS lists, workgroup b to list b % SG_LONG_LISTS (a counter per list, a cache line
+// apart): appends to ONE counter are served one after the other, ~10 ns each -- 10^4 long rows of a 10^6-row power-law matrix
+// cost 100 us of a 2.9-ms product.  List k holds at most long_cap rows (the rows of the workgroups that append to it).
+constexpr int SG_LONG_LISTS = 64, SG_LONG_STRIDE = 32;      // (counters SG_LONG_STRIDE int32 apart)
+// Rows of more than SG_COUNT_VLONG entries go to one more list (number SG_LONG_LISTS, at long_list + SG_LONG_LISTS * long_cap) and
+// are counted by ALL wavefronts together, 256 entries at a time (a wavefront per row: the longest row of a power-law matrix
+// alone was 0.10 ms).
+constexpr int SG_COUNT_VLONG = 4096;
 template <bool FAST>
 __global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, int64_t *__restrict__ ub,
-                                                         int32_t *__restrict__ long_list, int32_t *__restrict__ n_long)
+                                                         int32_t *__restrict__ long_list, int32_t long_cap, int32_t *__restrict__ n_long)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;
     const int l = threadIdx.x & 7;
@@ -174,28 +182,70 @@ __global__ __launch_bounds__(256) void sg_count_products(MatView a, MatView b, i
     }
     for (int off = 4; off; off >>= 1) tot += __shfl_down(tot, off, 8);
     if (i < a.nrows && l == 0) {
-        if (is_long) long_list[atomicAdd(n_long, 1)] = (int32_t)i;
-        else ub[i] = tot;
+        const bool vlong = rp_at<FAST>(a, i + 1) - rp_at<FAST>(a, i) > SG_COUNT_VLONG;
+        const int k = vlong ? SG_LONG_LISTS : blockIdx.x % SG_LONG_LISTS;
+        if (is_long) long_list[(int64_t)k * long_cap + atomicAdd(&n_long[k * SG_LONG_STRIDE], 1)] = (int32_t)i;
+        ub[i] = is_long ? 0 : tot;
     }
 }
 
+// a wavefront per long row, four requests per lane in flight (one at a time: 0.10 ms for rows of a few thousand entries)
 template <bool FAST>
 __global__ __launch_bounds__(256) void sg_count_products_long(MatView a, MatView b, int64_t *__restrict__ ub,
-                                                              const int32_t *__restrict__ long_list,
+                                                              const int32_t *__restrict__ long_list, int32_t long_cap,
                                                               const int32_t *__restrict__ n_long)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int32_t n = n_long[0];
-    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE; q < n; q += (int64_t)gridDim.x * blockDim.x / WAVE) {
-        const int32_t i = long_list[q];
+    const int64_t n_waves = (int64_t)gridDim.x * blockDim.x / WAVE;
+    const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    // the lists laid end to end: s_off[k] = rows in the lists before k (one load of the counters instead of one per list and wavefront)
+    __shared__ int32_t s_off[SG_LONG_LISTS + 1];
+    if (threadIdx.x < WAVE) {
+        const int32_t n = n_long[threadIdx.x * SG_LONG_STRIDE];
+        const int32_t ex = wave_exscan_i32(n, lane);
+        s_off[threadIdx.x] = ex;
+        if (threadIdx.x == WAVE - 1) s_off[SG_LONG_LISTS] = ex + n;
+    }
+    __syncthreads();
+    const int32_t n_all = s_off[SG_LONG_LISTS];
+    for (int64_t q = w0; q < n_all; q += n_waves) {
+        int k = 0;
+        for (int step = SG_LONG_LISTS / 2; step; step >>= 1)      // the list that holds position q
+            if (s_off[k + step] <= q) k += step;
+        const int32_t i = long_list[(int64_t)k * long_cap + (q - s_off[k])];
         const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
         int64_t tot = 0;
-        for (int64_t jj = s + lane; jj < e; jj += WAVE) {
-            const int32_t j = a.ci[jj];
-            tot += rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j);
+        for (int64_t j0 = s + lane; j0 < e; j0 += 4 * WAVE) {
+            int64_t len[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t jj = j0 + t * WAVE;
+                const int32_t j = a.ci[jj < e ? jj : e - 1];
+                len[t] = jj < e ? rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j) : 0;
+            }
+            tot += (len[0] + len[1]) + (len[2] + len[3]);
         }
         for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
         if (lane == 0) ub[i] = tot;
+    }
+    // the very long rows: every wavefront takes slices of 256 entries (integer adds: any order gives the same count)
+    const int32_t n_vl = n_long[SG_LONG_LISTS * SG_LONG_STRIDE];
+    for (int32_t q = 0; q < n_vl; q++) {
+        const int32_t i = long_list[(int64_t)SG_LONG_LISTS * long_cap + q];
+        const int64_t s = rp_at<FAST>(a, i), e = rp_at<FAST>(a, i + 1);
+        int64_t tot = 0;
+        for (int64_t j0 = s + w0 * (4 * WAVE) + lane; j0 < e; j0 += n_waves * (4 * WAVE)) {
+            int64_t len[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int64_t jj = j0 + t * WAVE;
+                const int32_t j = a.ci[jj < e ? jj : e - 1];
+                len[t] = jj < e ? rp_at<FAST>(b, j + 1) - rp_at<FAST>(b, j) : 0;
+            }
+            tot += (len[0] + len[1]) + (len[2] + len[3]);
+        }
+        for (int off = WAVE / 2; off; off >>= 1) tot += __shfl_down(tot, off, WAVE);
+        if (lane == 0 && tot) atomicAdd((unsigned long long *)&ub[i], (unsigned long long)tot);
     }
 }
 
@@ -833,8 +883,9 @@ __global__ void sg_sorted_check(const int32_t *__restrict__ rp, const int32_t *_
 //                     is on (esc_min >= 0);
 //   3 the round-1 heavy-row paths (counters[0]): the other rows with more than SG_CAP products.
 // Two launches: strip rows with long A rows first (pass 0), so the longest chains start first.
+constexpr int SG_LIST_THREADS = 1024;
 template <bool FAST>
-__global__ void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t nrows, int32_t s_dense, int strips_ok,
+__global__ __launch_bounds__(SG_LIST_THREADS) void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t nrows, int32_t s_dense, int strips_ok,
                              int64_t esc_min, int pass, unsigned char *__restrict__ route, int32_t *__restrict__ list_large,
                              int32_t *__restrict__ list_strip, int32_t *__restrict__ ebase, int32_t *__restrict__ list_esc,
                              int32_t *__restrict__ counters)
@@ -851,22 +902,37 @@ __global__ void sg_list_rows(MatView a, const int64_t *__restrict__ ub, int32_t 
     else if (pass != 0 || u <= 0) to = 0;
     else if (esc_min >= 0 && u > esc_min && !(dense && u > SG_CAP)) to = 2;
     else if (u > SG_CAP) to = 3;
-    // one atomic per wavefront and list (10^5 rows appending one by one to the same counter took 59 us)
+    // one atomic per WORKGROUP and list: atomics on one address are served one after the other (~10 ns each) -- 10^5 rows
+    // appending one by one took 59 us, 10^6 rows with one atomic per wavefront 176 us of a 2.9-ms product
     if (to == 1) {           // (few rows, and each needs its own A-entry base)
         const int32_t q = atomicAdd(&counters[1], 1);
         list_strip[q] = (int32_t)i;
         ebase[q] = atomicAdd(&counters[2], (int32_t)J);
         route[i] = 1;
     }
+    __shared__ int32_t s_cnt[2][SG_LIST_THREADS / WAVE], s_base[2];
+    const int w = threadIdx.x / WAVE;
+    unsigned long long mk[2];
 #pragma unroll
     for (int t = 2; t <= 3; t++) {
-        const unsigned long long m = __ballot(to == t);
-        if (m == 0) continue;                                   // uniform
-        int32_t base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&counters[t == 2 ? 3 : 0], (int32_t)__popcll(m));
-        base = __shfl(base, __builtin_ctzll(m), WAVE);
+        mk[t - 2] = __ballot(to == t);
+        if (lane == 0) s_cnt[t - 2][w] = (int32_t)__popcll(mk[t - 2]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int32_t tot = 0;
+        for (int k = 0; k < SG_LIST_THREADS / WAVE; k++) {
+            const int32_t c = s_cnt[threadIdx.x][k];
+            s_cnt[threadIdx.x][k] = tot;          // exclusive prefix over the workgroup's wavefronts
+            tot += c;
+        }
+        s_base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x == 0 ? 3 : 0], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 2; t <= 3; t++) {
         if (to == t) {
-            (t == 2 ? list_esc : list_large)[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+            (t == 2 ? list_esc : list_large)[s_base[t - 2] + s_cnt[t - 2][w] + __popcll(mk[t - 2] & ((1ull << lane) - 1ull))] = (int32_t)i;
             route[i] = (unsigned char)t;
         }
     }
@@ -1556,13 +1622,18 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
     if (nr > 0) {
         unsigned g = (unsigned)ceil_div(nr, 256);
         // (list_s / counters are scratch here: the list of long rows and its length)
+        const int64_t count_blocks = ceil_div((int64_t)nr * 8, 256);
+        const int32_t long_cap = (int32_t)(ceil_div(count_blocks, (int64_t)SG_LONG_LISTS) * 32);      // 32 rows per workgroup
+        DevBuf long_cnt;
+        CSRK_TRY(long_cnt.alloc((size_t)(SG_LONG_LISTS + 1) * SG_LONG_STRIDE * 4));
         CSRK_TRY(counters.alloc(16));
-        CSRK_TRY(list_s.alloc((size_t)(nr + 1) * 4));
-        CSRK_HIP(hipMemset(counters.p, 0, 16));
-        sg_count_products<FAST><<<(unsigned)ceil_div((int64_t)nr * 8, 256), 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(),
-                                                                                 counters.as<int32_t>());
+        // (the lists of long rows, then the list of very long rows: at most nnz / SG_COUNT_VLONG of them)
+        CSRK_TRY(list_s.alloc((size_t)std::max<int64_t>((int64_t)nr + 1, (int64_t)SG_LONG_LISTS * long_cap + a->nnz / SG_COUNT_VLONG + 1) * 4));
+        CSRK_HIP(hipMemsetAsync(long_cnt.p, 0, (size_t)(SG_LONG_LISTS + 1) * SG_LONG_STRIDE * 4, nullptr));
+        sg_count_products<FAST><<<(unsigned)count_blocks, 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(), long_cap,
+                                                                long_cnt.as<int32_t>());
         CSRK_LAUNCH_CHECK();
-        sg_count_products_long<FAST><<<256, 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(), counters.as<int32_t>());
+        sg_count_products_long<FAST><<<1024, 256>>>(av, bv, ub.as<int64_t>(), list_s.as<int32_t>(), long_cap, long_cnt.as<int32_t>());
         CSRK_LAUNCH_CHECK();
         CSRK_TRY(ebase.alloc((size_t)(nr + 1) * 4));
         const char *strips_env = getenv("CSRK_SPGEMM_STRIPS");      // 0: workgroup paths only (A/B measurements)
@@ -1593,7 +1664,7 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             CSRK_HIP(hipMemset(counters.p, 0, 16));
             CSRK_HIP(hipMemset(route.p, 0, (size_t)nr + 1));
             for (int pass = 0; pass < (strips > 0 ? 2 : 1); pass++) {
-                sg_list_rows<FAST><<<g, 256>>>(av, ub.as<int64_t>(), nr, s_dense, strips > 0 ? 1 : 0, esc_min, pass,
+                sg_list_rows<FAST><<<(unsigned)ceil_div(nr, SG_LIST_THREADS), SG_LIST_THREADS>>>(av, ub.as<int64_t>(), nr, s_dense, strips > 0 ? 1 : 0, esc_min, pass,
                                                route.as<unsigned char>(), list.as<int32_t>(), list_s.as<int32_t>(),
                                                ebase.as<int32_t>(), list_e.as<int32_t>(), counters.as<int32_t>());
                 CSRK_LAUNCH_CHECK();
