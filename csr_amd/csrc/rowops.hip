@@ -273,9 +273,14 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
 
 // C1: per-chunk partials.  UNIT: part_a = the chunk's maximum (NaN if it holds one), part_b = sum of squares of the
 // chunk's values under the chunk's own prescale 2^part_e; CENTER: part_a = the chunk's sum.
+// A row of ONE chunk (513 .. 4096 entries) is finished here, from the registers: read once, written once (a quarter of the
+// headline matrix's class-C entries, nearly all of a MovieLens-shaped matrix's).
 template <class T, bool UNIT>
-__global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(const T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
+__global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
                                                                 const int32_t *__restrict__ chunk_len,
+                                                                const int32_t *__restrict__ chunk_row,
+                                                                const int32_t *__restrict__ row_chunk0,
+                                                                const int32_t *__restrict__ list_c, T *__restrict__ out,
                                                                 double *__restrict__ part_a, double *__restrict__ part_b,
                                                                 int32_t *__restrict__ part_e, const int32_t *__restrict__ n_chunks)
 {
@@ -284,6 +289,8 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(const T *__rest
     if ((int32_t)blockIdx.x >= *n_chunks) return;      // (the grid is an upper bound of the chunk count)
     const int64_t k0 = chunk_k0[blockIdx.x];
     const int len = chunk_len[blockIdx.x];
+    const int32_t row_i = chunk_row[blockIdx.x];
+    const bool single = row_chunk0[row_i + 1] - row_chunk0[row_i] == 1;
     const int tid = threadIdx.x;
     double v[RS_K];
 #pragma unroll
@@ -293,6 +300,14 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(const T *__rest
 #pragma unroll
         for (int j = 0; j < RS_K; j++) s += v[j];
         s = block_sum(s, s_red);
+        if (single) {
+            const T m = (T)(s / (double)len);
+#pragma unroll
+            for (int j = 0; j < RS_K; j++)
+                if (j * RS_THREADS + tid < len) vs[k0 + j * RS_THREADS + tid] = (T)v[j] - m;      // :24
+            if (tid == 0) out[list_c[row_i]] = m;
+            return;
+        }
         if (tid == 0) part_a[blockIdx.x] = s;
         return;
     }
@@ -330,6 +345,14 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c1_kernel(const T *__rest
         ss += u * u;
     }
     ss = block_sum(ss, s_red);
+    if (single) {
+        const T prenorm = (T)pre, inorm = (T)sqrt(ss);      // :58, :62
+#pragma unroll
+        for (int j = 0; j < RS_K; j++)
+            if (j * RS_THREADS + tid < len) vs[k0 + j * RS_THREADS + tid] = (T)((T)v[j] * prenorm) / inorm;      // :59, :64
+        if (tid == 0) out[list_c[row_i]] = inorm / prenorm;      // :63
+        return;
+    }
     if (tid == 0) {
         part_a[blockIdx.x] = vmax;
         part_b[blockIdx.x] = ss;
@@ -351,6 +374,7 @@ __global__ __launch_bounds__(256) void row_stat_c2_kernel(const P *__restrict__ 
     if (i >= n_c) return;
     const int32_t r = list_c[i];
     const int32_t c0 = row_chunk0[i], c1 = row_chunk0[i + 1];
+    if (c1 - c0 == 1) return;      // (finished by C1)
     if (!UNIT) {
         double s = 0.0;
         for (int32_t c = c0 + lane; c < c1; c += WAVE) s += part_a[c];
@@ -386,6 +410,7 @@ template <class T, bool UNIT>
 __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
                                                                 const int32_t *__restrict__ chunk_len,
                                                                 const int32_t *__restrict__ chunk_row,
+                                                                const int32_t *__restrict__ row_chunk0,
                                                                 const T *__restrict__ scale_a, const T *__restrict__ scale_b,
                                                                 const int32_t *__restrict__ n_chunks)
 {
@@ -393,6 +418,7 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
     const int64_t k0 = chunk_k0[blockIdx.x];
     const int len = chunk_len[blockIdx.x];
     const int32_t i = chunk_row[blockIdx.x];
+    if (row_chunk0[i + 1] - row_chunk0[i] == 1) return;      // (finished by C1)
     const T a = scale_a[i], b = UNIT ? scale_b[i] : (T)0;
 #pragma unroll
     for (int j = 0; j < RS_K; j++) {
@@ -402,6 +428,27 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
             vs[k0 + k] = UNIT ? (T)(v * a) / b : v - a;      // :59 then :64 / :24
         }
     }
+}
+
+// a non-blocking stream and an event per device, made on first use (small copies that should not queue behind a kernel)
+struct SideStream {
+    hipStream_t st;
+    hipEvent_t ev;
+};
+static int side_stream(SideStream *out)
+{
+    static std::mutex mu;
+    static SideStream per_dev[64] = {};
+    int dev = 0;
+    CSRK_HIP(hipGetDevice(&dev));
+    CSRK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!per_dev[dev].st) {
+        CSRK_HIP(hipStreamCreateWithFlags(&per_dev[dev].st, hipStreamNonBlocking));
+        CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev, hipEventDisableTiming));
+    }
+    *out = per_dev[dev];
+    return CSRK_OK;
 }
 
 // out_dev (optional): the norms / means stay on the device there (values dtype); out_host (optional): copied out
@@ -426,19 +473,25 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     CSRK_TRY(list_c.alloc((size_t)(m->nnz / (RS_B + 1) + 1) * 4));
     CSRK_TRY(counts.alloc((size_t)(3 * n_waves + 1) * 4));
     const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
+    SideStream side;
+    CSRK_TRY(side_stream(&side));
 #define GO(P, T)                                                                                                       \
     do {                                                                                                               \
         row_class_count_kernel<P><<<ga, 256>>>((const P *)m->d_rowptrs, m->nrows, n_waves, counts.as<int32_t>());       \
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_TRY(exclusive_scan_i32(counts.as<int32_t>(), counts.as<int32_t>(), 3 * n_waves, nullptr));                \
+        /* the list lengths come back on a side stream WHILE the class A kernel runs (behind it on the same stream the   \
+           card sat idle for the host's round trip: ~25 us of a 1.2-ms call) */                                        \
+        CSRK_HIP(hipEventRecord(side.ev, nullptr));                                                                    \
+        CSRK_HIP(hipStreamWaitEvent(side.st, side.ev, 0));                                                             \
+        int32_t n_bc[4] = {0, 0, 0, 0};      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */         \
+        for (int c = 0; c < 4; c++)                                                                                    \
+            CSRK_HIP(hipMemcpyAsync(&n_bc[c], counts.as<int32_t>() + c * n_waves, 4, hipMemcpyDeviceToHost, side.st)); \
         row_stat_a_kernel<P, T, UNIT><<<ga, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, m->nrows,       \
                                                    n_waves, counts.as<int32_t>(), list_b8.as<int32_t>(),               \
                                                    list_b.as<int32_t>(), list_c.as<int32_t>());                        \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        int32_t n_bc[4] = {0, 0, 0, 0};      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */         \
-        for (int c = 0; c < 4; c++)                                                                                    \
-            CSRK_HIP(hipMemcpyAsync(&n_bc[c], counts.as<int32_t>() + c * n_waves, 4, hipMemcpyDeviceToHost, nullptr)); \
-        CSRK_HIP(hipStreamSynchronize(nullptr));                                                                       \
+        CSRK_HIP(hipStreamSynchronize(side.st));                                                                       \
         const int32_t n_b8 = n_bc[1] - n_bc[0], n_b = n_bc[2] - n_bc[1], n_c = n_bc[3] - n_bc[2];                      \
         if (n_b8 > 0) {                                                                                                \
             row_stat_b_kernel<P, T, UNIT, 8><<<(unsigned)ceil_div((int64_t)n_b8 * 8, 256), 256>>>(                     \
@@ -470,8 +523,10 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
             row_chunk_fill_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>(), \
                                                   ck0.as<int64_t>(), clen.as<int32_t>(), crow.as<int32_t>());           \
             CSRK_LAUNCH_CHECK();                                                                                       \
-            row_stat_c1_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((const T *)m->d_values, ck0.as<int64_t>(),  \
-                                                                            clen.as<int32_t>(), pa.as<double>(),        \
+            row_stat_c1_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((T *)m->d_values, ck0.as<int64_t>(),        \
+                                                                            clen.as<int32_t>(), crow.as<int32_t>(),     \
+                                                                            rc0.as<int32_t>(), list_c.as<int32_t>(),    \
+                                                                            (T *)out, pa.as<double>(),                  \
                                                                             pb.as<double>(), pe.as<int32_t>(),          \
                                                                             rc0.as<int32_t>() + n_c);                   \
             CSRK_LAUNCH_CHECK();                                                                                       \
@@ -482,7 +537,7 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
             CSRK_LAUNCH_CHECK();                                                                                       \
             row_stat_c3_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((T *)m->d_values, ck0.as<int64_t>(),        \
                                                                             clen.as<int32_t>(), crow.as<int32_t>(),     \
-                                                                            sa.as<T>(), sb.as<T>(),                     \
+                                                                            rc0.as<int32_t>(), sa.as<T>(), sb.as<T>(),  \
                                                                             rc0.as<int32_t>() + n_c);                   \
             CSRK_LAUNCH_CHECK();                                                                                       \
             CSRK_HIP(hipDeviceSynchronize());      /* the chunk tables are released here */                            \
