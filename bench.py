@@ -357,12 +357,28 @@ def main():
     fallback_note = None
     while True:
         hp = op_handles[0] if op_handles else h
+        # Kernel event pairs cost ~3 us apiece on the stream (~25 us for a product with four timed kernels).  During the
+        # warm-up every kernel is timed on every step; the timed region then brackets only the kernel that was the
+        # slowest there (the roofline's dominant kernel), on every 10th step of a long run.
+        events = not os.environ.get('BENCH_NO_KERNEL_EVENTS')
+        k_warm, n_warm = None, 0
+        if events and args.warmup > 0:
+            check(lib.csrk_spmv_profile_channels(hp, 0xf))
+            check(lib.csrk_spmv_profile_every(hp, 1))
+            check(lib.csrk_spmv_profile_begin(hp, args.warmup + 2))
         for _ in range(args.warmup):
             op.step(x)
         barrier()
-        # kernel event pairs on every 10th step of a long run (recorded on every step they cost ~25 us per SpMV)
-        if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-            every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)      # (event pairs cost ~3 us each on the stream)
+        chan_mask = 0xf
+        if events and args.warmup > 0:
+            n_w, k_w = C.c_int(0), (C.c_float * 4)(0.0, 0.0, 0.0, 0.0)
+            check(lib.csrk_spmv_profile_end4(hp, C.byref(n_w), k_w))
+            k_warm, n_warm = [float(v) for v in k_w], n_w.value
+            if n_warm > 0 and max(k_warm) > 0:
+                chan_mask = 1 << max(range(4), key=lambda c: k_warm[c])
+        if events:
+            every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)
+            check(lib.csrk_spmv_profile_channels(hp, chan_mask))
             check(lib.csrk_spmv_profile_every(hp, every))
             check(lib.csrk_spmv_profile_begin(hp, args.steps // every + 2))
         op.timing = distd
@@ -371,9 +387,13 @@ def main():
             y = op.step(x)
         barrier()
         elapsed = time.perf_counter() - t0
-        n_rec, k_ms2 = C.c_int(0), (C.c_float * 4)(0.0, 0.0, 0.0, 0.0)
-        if not os.environ.get('BENCH_NO_KERNEL_EVENTS'):
-            check(lib.csrk_spmv_profile_end4(hp, C.byref(n_rec), k_ms2))
+        n_rec, k_live = C.c_int(0), (C.c_float * 4)(0.0, 0.0, 0.0, 0.0)
+        if events:
+            check(lib.csrk_spmv_profile_end4(hp, C.byref(n_rec), k_live))
+            check(lib.csrk_spmv_profile_channels(hp, 0xf))
+        # per kernel: the timed region's mean where it was bracketed there, else the warm-up's
+        k_ms2 = [float(k_live[c]) if (chan_mask >> c) & 1 and k_live[c] > 0 else (k_warm[c] if k_warm else 0.0) for c in range(4)]
+        k_src = ['timed region' if (chan_mask >> c) & 1 and k_live[c] > 0 else ('warm-up' if k_warm else None) for c in range(4)]
         compute_ms = None
         exchange_ok = None
         if not distd:
@@ -433,7 +453,7 @@ def main():
     # sums; the others 12 B per entry) -- the algorithmic rate of a kernel whose stream is narrower than the CSR arrays
     # can exceed the copy rate, its stream rate cannot.
     whole_bytes = nnz_loc * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8
-    kernels = [dict(light, ms=k_ms2[0], entries=nnz_path,
+    kernels = [dict(light, ms=k_ms2[0], events=k_src[0], entries=nnz_path,
                     algorithmic_bytes=nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8,
                     stream_bytes=nnz_path * 12 + int(st[22]) * 4 + n_loc * 8 + int(st[24]) * 8)]
     if int(st[10]):
@@ -441,18 +461,18 @@ def main():
             if int(st[18]) else {'kernel': 'spmv_panel_kernel<tier0>', 'role': 'tier 0, (block, row) pair form: x window in LDS'}
         t0_stream = (int(st[4]) * 512 * 10 + int(st[4]) * 4 + ncols * 8 + 256 * int(st[9]) * 8) if int(st[18]) \
             else int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8
-        kernels.append(dict(t0, ms=k_ms2[1], entries=int(st[10]),
+        kernels.append(dict(t0, ms=k_ms2[1], events=k_src[1], entries=int(st[10]),
                             algorithmic_bytes=int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8, stream_bytes=t0_stream))
     if int(st[13]):
         kernels.append({'kernel': 'spmv_panel_kernel<tier1>', 'role': 'tier 1 (mid rows): (block, row) pairs, x window in L2',
-                        'ms': k_ms2[2], 'entries': int(st[13]),
+                        'ms': k_ms2[2], 'events': k_src[2], 'entries': int(st[13]),
                         'algorithmic_bytes': int(st[13]) * 12 + int(st[12]) * 12 + ncols * 8,
                         'stream_bytes': int(st[13]) * 12 + int(st[12]) * 12 + ncols * 8})
     if int(st[24]):
         # the cold-staging pass: no algorithmic bytes of its own (it re-orders x for the light stream); listed so that
         # the kernels add up to the SpMV, never the dominant one unless it really is the slowest
         kernels.append({'kernel': 'ls_stage_kernel', 'role': 'cold staging: x of the unpacked and packed columns copied into the '
-                        'light stream\'s order through LDS windows (overhead pass)', 'ms': k_ms2[3], 'entries': int(st[24]),
+                        'light stream\'s order through LDS windows (overhead pass)', 'ms': k_ms2[3], 'events': k_src[3], 'entries': int(st[24]),
                         'algorithmic_bytes': 0, 'stream_bytes': (int(st[24]) + int(st[16])) * 14 + ncols * 8})
     traffic_all = {}
     traffic_src = None
@@ -481,7 +501,9 @@ def main():
         # rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh), committed under profiles/
         'traffic_source': (traffic_src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)')
                           if dom['traffic'] else None,
-        'kernel_ms': dom['ms'], 'launches_timed': n_rec.value, 'algorithmic_bytes': dom['algorithmic_bytes'],
+        # HIP events on the launch stream: the dominant kernel inside the timed region; the other kernels during the warm-up steps
+        'kernel_ms': dom['ms'], 'kernel_ms_events': dom.get('events'), 'launches_timed': n_rec.value if dom.get('events') == 'timed region' else n_warm,
+        'algorithmic_bytes': dom['algorithmic_bytes'],
         # the same kernel priced by the bytes its private stream holds and by the counter traffic: neither can exceed
         # the copy rate (6.29 TB/s measured, MI355X_MICROARCH.md) by much; the algorithmic rate above can, when the
         # stream is narrower than the CSR arrays it replaces

@@ -72,6 +72,7 @@ SIGNATURES = {
     'csrk_spmv_plan_stats': (_int, [handle_t, C.POINTER(_i64), _int]),
     'csrk_spmv_profile_begin': (_int, [handle_t, _int]),
     'csrk_spmv_profile_every': (_int, [handle_t, _int]),
+    'csrk_spmv_profile_channels': (_int, [handle_t, _int]),
     'csrk_spmv_profile_end': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
     'csrk_spmv_profile_end4': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
     'csrk_spgemm_ab': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),

@@ -186,6 +186,7 @@ struct SpmvPlan {
     bool profiling = false;
     int prof_every = 1;           // profile every n-th launch group only (an event pair costs ~3 us on the stream)
     int prof_calls = 0;
+    int prof_mask = 0xf;          // channels that get event pairs (csrk_spmv_profile_channels)
     bool prof_this = false;       // the launch group in progress is being timed
     ~SpmvPlan()
     {
@@ -200,7 +201,7 @@ struct KernelTimer {   // records an event pair around one launch when the plan 
     int slot = -1;
     KernelTimer(SpmvPlan *p_, hipStream_t s_, int chan = 0) : p(p_), s(s_)
     {
-        if (p->profiling && p->prof_this && p->ev_used + 2 <= (int)p->ev.size()) {
+        if (p->profiling && p->prof_this && ((p->prof_mask >> chan) & 1) && p->ev_used + 2 <= (int)p->ev.size()) {
             slot = p->ev_used;
             p->ev_used += 2;
             p->ev_chan[slot / 2] = chan;
@@ -3932,6 +3933,18 @@ int csrk_spmv_profile_every(csrk_handle_t h, int every_n)
     return CSRK_OK;
 }
 
+int csrk_spmv_profile_channels(csrk_handle_t h, int mask)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(mask > 0 && mask <= 0xf, "mask must name at least one of the four channels");
+    SpmvPlan *p = nullptr;
+    CSRK_TRY(get_plan(m, nullptr, &p));
+    std::lock_guard<std::mutex> lk(m->mu);
+    p->prof_mask = mask;
+    return CSRK_OK;
+}
+
 int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean_ms)
 {
     Matrix *m = from_handle(h);
@@ -3951,7 +3964,8 @@ int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean_ms)
         tot[p->ev_chan[i]] += ms;
         cnt[p->ev_chan[i]]++;
     }
-    *n_records = cnt[0];
+    *n_records = 0;
+    for (int c = 0; c < 4; c++) *n_records = cnt[c] > *n_records ? cnt[c] : *n_records;      // (launch groups timed)
     for (int c = 0; c < 4; c++) mean_ms[c] = cnt[c] ? (float)(tot[c] / cnt[c]) : 0.f;
     p->ev_used = 0;
     return CSRK_OK;

@@ -158,6 +158,9 @@ CSRK_API int csrk_spmv_profile_begin(csrk_handle_t h, int max_records);
  * pairs sit on the launch stream between the kernels and cost ~3 us apiece -- 20 us per SpMV with three
  * timed kernels, 3 % of the headline step; call before csrk_spmv_profile_begin. */
 CSRK_API int csrk_spmv_profile_every(csrk_handle_t h, int every_n);
+/* Which of the four kernels get event pairs: bit c of `mask` = channel c of csrk_spmv_profile_end4 (default 0xf: all).
+ * A timed region that needs one kernel's duration pays for one event pair per timed call instead of four. */
+CSRK_API int csrk_spmv_profile_channels(csrk_handle_t h, int mask);
 CSRK_API int csrk_spmv_profile_end(csrk_handle_t h, int *n_records, float *mean_ms);
 /* The same with mean_ms[4]: [3] = the cold-staging pass that feeds the light stream (ls_stage_kernel; 0 if the plan
  * has none). */
