@@ -666,12 +666,17 @@ def test_from_coo_device(golden):
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_unit_center_long_rows_vs_oracle(dtype):
-    "rows longer than 8192 entries take the workgroup-per-row kernels; NaN row and zero row included"
+    "rows longer than 512 entries take the chunk kernels (one chunk: one pass; several: partials, join, scale); NaN, infinite and zero rows included"
     from oracle import oracle as O
     rng = np.random.default_rng(21)
     lens = rng.integers(0, 20, size=400)
     lens[[5, 77, 200, 399]] = [9000, 30000, 8193, 12000]
+    # rows of ONE 4096-entry chunk are finished by the first class-C kernel (513 .. 4096 entries), 4097 is two chunks
+    lens[[9, 150, 151, 300, 301]] = [513, 2500, 4096, 4097, 600]
     m = _rand(rng, 400, 3000, lens, dtype=dtype)
+    s300 = int(m.rowptrs[301])
+    m.values[s300:s300 + 600] = 0                       # an all-zero one-chunk row
+    m.values[int(m.rowptrs[150]) + 3] = np.inf          # an infinite value in a one-chunk row
     s200 = int(m.rowptrs[200])
     m.values[s200:s200 + 8193] = 0                      # an all-zero long row -> norm 0, NaN values
     m.values[int(m.rowptrs[399]) + 17] = np.nan         # NaN in a long row propagates
@@ -684,6 +689,7 @@ def test_unit_center_long_rows_vs_oracle(dtype):
     assert np.array_equal(np.isnan(u.values), np.isnan(ur))
     assert u.values == pytest.approx(ur, rel=rel, abs=1e-300, nan_ok=True)
     m.values[int(m.rowptrs[399]) + 17] = 0.5
+    m.values[int(m.rowptrs[150]) + 3] = 0.25
     c, cr = m.copy(), m.values.copy()
     means = c.normalize_rows('center')
     rm = O.center_rows(m.nrows, m.rowptrs, cr)
