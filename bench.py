@@ -69,6 +69,9 @@ def parse():
                     help='run the N > 1 code path (process group on RCCL, exchange candidates, completeness checks) whatever N is: '
                          'with --gpus 1 it is the one-rank rehearsal of the multi-GPU run (tests/test_gpu_fullsize.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='N = 1: skip the `secondary` block (SpMM configs[2], transpose + A B^T configs[4], unit_rows on the '
+                         'headline matrix: bench_secondary.py), which adds ~30 s after the SpMV has been timed')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
     return ap.parse_args()
@@ -632,11 +635,19 @@ def main():
             print(json.dumps(out))
             sys.exit('PARITY FAILURE: GPU result differs from the oracle')
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     for hc in op_handles:
         check(lib.csrk_free(hc))
     check(lib.csrk_free(h))
+    if world == 1 and not distd and not args.no_secondary and args.scale == 1.0:
+        # the other BASELINE configs, AFTER the SpMV has been timed and checked (nothing above depends on this):
+        # each entry carries ms, algorithmic bytes, frac of 8 TB/s, a parity flag and the oracle's time on a stated sample
+        import bench_secondary
+        del y
+        check(lib.csrk_trim_cache())
+        out['secondary'] = bench_secondary.run_all(dev, headline=(rp, ci, vs, nrows, ncols),
+                                                   log=lambda m: print(m, file=sys.stderr, flush=True))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if distd:
         dist.destroy_process_group()
 

@@ -1,0 +1,289 @@
+"""
+The other BASELINE.json configurations, measured the way bench.py measures the headline SpMV: through the libcsrk
+C ABI with inputs resident in HBM, each with its algorithmic bytes, the fraction of the 8 TB/s
+roofline, a parity flag against the CPU oracle, and the oracle timed on a stated sample as `cpu_baseline` (kind
+"port", 1 core).  bench.py puts the dicts these functions return into the `secondary` block of its JSON line
+(`--no-secondary` skips it); tools/bench_configs.py prints the same dicts one per line for profiles/rNN_configs.json.
+
+  spmm       configs[2]: dense-panel SpMM, A 2M x 2M nnz 5e7 (power-law) x B 2M x 64 f64 (csrk_spmm_dense_device;
+             reference: mult_ab with a fully populated B, csr/kernels/numba/multiply.py:13-38, 110-122)
+  transpose  configs[4]: csrk_transpose of the MovieLens-25M-shaped 162541 x 59047 matrix, nnz 25000095
+             (csr/structure.py:172-204), bit-exact against the oracle at full size
+  abt        configs[4]: mult_abt of ratings blocks A[2000] x B[20000]^T (csr/kernels/numba/multiply.py:41-57),
+             values compared bit for bit with the oracle (columns compared as sets per row: DESIGN.md section 3)
+  unit_rows  csrk_unit_rows_device on the headline matrix (csr/transform.py:29-66)
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from csr_amd import synth
+from csr_amd._lib import lib, check, handle_t
+
+HBM_PEAK_GBS = 8000.0
+ML_SHAPE = (162_541, 59_047, 25_000_095)
+
+
+def _mk(rp, ci, vs, nrows, ncols):
+    h = handle_t(0)
+    check(lib.csrk_create_device(nrows, ncols, int(ci.numel()), rp.data_ptr(), int(rp.dtype == torch.int64),
+                                 ci.data_ptr(), vs.data_ptr(), 2, C.byref(h)))
+    return h
+
+
+def _wall_ms(fn, reps, warm=2):
+    "mean and minimum wall time of fn() in ms, the device idle before and after each call"
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.mean(ts)), float(np.min(ts))
+
+
+def _events_ms(fn, reps, warm=2):
+    "mean ms per call of `reps` back-to-back calls between two events on the null stream (where libcsrk launches by default)"
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _roof(alg_bytes, ms):
+    gbs = alg_bytes / ms / 1e6
+    return {'algorithmic_bytes': int(alg_bytes), 'achieved_gbs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def ml_matrix(dev):
+    nr, nc, nnz = ML_SHAPE
+    m = synth.powerlaw_csr(nr, nc, nnz, device=dev, alpha=0.9, max_degree=7000)
+    m['values'] = (torch.floor((m['values'] + 1.0) * 5.0).clamp_(0, 9) + 1.0) * 0.5      # ratings 0.5 .. 5.0
+    return m
+
+
+def spmm(dev, reps=10, cpu_entries=2_000_000):
+    from oracle import oracle as O
+    n, nnz, k = 2_000_000, 50_000_000, 64
+    m = synth.powerlaw_csr(n, n, nnz, device=dev, max_degree=250_000)
+    h = _mk(m['rowptrs'], m['colinds'], m['values'], n, n)
+    B = synth.dense_vector(n * k, device=dev, stream=7).view(n, k)
+    Cm = torch.empty(n, k, dtype=torch.float64, device=dev)
+    ms = _events_ms(lambda: check(lib.csrk_spmm_dense_device(h, B.data_ptr(), k, k, Cm.data_ptr(), k, None)), reps)
+    alg = nnz * 12 + (n + 1) * 4 + 2 * n * k * 8
+    # property at full size: panel column 0 equals the SpMV with that column, to 1e-12 of sum |a x|
+    x0 = B[:, 0].contiguous()
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    check(lib.csrk_spmv_device(h, x0.data_ptr(), y.data_ptr(), None))
+    absv = m['values'].abs()
+    habs = _mk(m['rowptrs'], m['colinds'], absv, n, n)
+    bound = torch.empty(n, dtype=torch.float64, device=dev)
+    xa = x0.abs().contiguous()
+    check(lib.csrk_spmv_device(habs, xa.data_ptr(), bound.data_ptr(), None))
+    torch.cuda.synchronize()
+    col0 = float(((Cm[:, 0] - y).abs() / (bound + 1e-300)).max())
+    # oracle on the first rows holding ~cpu_entries entries: baseline + parity sample
+    rp_h = m['rowptrs'].cpu().numpy()
+    r_s = int(np.searchsorted(rp_h, cpu_entries))
+    e_s = int(rp_h[r_s])
+    ci_h, vs_h = m['colinds'][:e_s].cpu().numpy(), m['values'][:e_s].cpu().numpy()
+    B_h = B.cpu().numpy()
+    t0 = time.perf_counter()
+    C_h = O.spmm_dense(r_s, rp_h[:r_s + 1], ci_h, vs_h, B_h)
+    t_cpu = time.perf_counter() - t0
+    # |C - C_oracle| <= 1e-6 * sum_j |a_ij| max_c |B_jc| is implied by the max-norm check below on U(-1,1) data
+    samp = float(np.max(np.abs(C_h - Cm[:r_s].cpu().numpy())) / max(1e-300, float(np.max(np.abs(C_h)))))
+    check(lib.csrk_free(h))
+    check(lib.csrk_free(habs))
+    out = {'config': 'spmm_dense A 2000000x2000000 nnz 50000000 (power-law) x B 2000000x64 f64', 'entry': 'csrk_spmm_dense_device',
+           'ms': round(ms, 4), 'gflops': round(2.0 * nnz * k / ms / 1e6, 1), 'bound': 'hbm', **_roof(alg, ms),
+           'parity': {'col0_vs_spmv_max_err_over_sum_abs_terms': col0, 'sample_vs_oracle_max_rel_err': samp,
+                      'tolerance': 1e-6, 'ok': bool(col0 <= 1e-6 and samp <= 1e-6)},
+           'cpu_baseline': {'value': round(2.0 * e_s * k / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1, 'kind': 'port',
+                            'sample': f'the first {r_s} rows of A ({e_s} entries) x the same B, one pass of orc_spmm_dense ({t_cpu:.2f} s)'}}
+    return out
+
+
+def transpose(dev, m=None, reps=10):
+    from oracle import oracle as O
+    nr, nc, nnz = ML_SHAPE
+    m = m or ml_matrix(dev)
+    h = _mk(m['rowptrs'], m['colinds'], m['values'], nr, nc)
+
+    def tr():
+        t = handle_t(0)
+        check(lib.csrk_transpose(h, 1, C.byref(t)))
+        check(lib.csrk_free(t))              # what CSR.transpose does after from_handle
+    ms, ms_min = _wall_ms(tr, reps)
+    t = handle_t(0)
+    check(lib.csrk_transpose(h, 1, C.byref(t)))
+    rpt = np.empty(nc + 1, np.int32)
+    ci_t = np.empty(nnz, np.int32)
+    vs_t = np.empty(nnz)
+    check(lib.csrk_export(t, rpt.ctypes.data_as(C.c_void_p), ci_t.ctypes.data_as(C.c_void_p), vs_t.ctypes.data_as(C.c_void_p)))
+    rp_h, ci_h, vs_h = m['rowptrs'].cpu().numpy(), m['colinds'].cpu().numpy(), m['values'].cpu().numpy()
+    t0 = time.perf_counter()
+    _, _, orp, oci, ovs = O.transpose(nr, nc, rp_h, ci_h, vs_h)
+    t_cpu = time.perf_counter() - t0
+    exact = bool(np.array_equal(rpt, orp) and np.array_equal(ci_t, oci) and np.array_equal(vs_t.view(np.int64), ovs.view(np.int64)))
+    check(lib.csrk_free(t))
+    check(lib.csrk_free(h))
+    alg = 4 * nnz + 2 * (4 + 8) * nnz + (nr + nc + 2) * 4
+    return {'config': f'transpose MovieLens-25M shape {nr}x{nc} nnz {nnz} f64', 'entry': 'csrk_transpose',
+            'ms': round(ms, 4), 'ms_min': round(ms_min, 4), 'timing': 'wall per call (create + free of the result handle included)',
+            'bound': 'hbm', **_roof(alg, ms),
+            'parity': {'bit_exact_vs_oracle_full_size': exact, 'ok': exact},
+            'cpu_baseline': {'value': round(alg / t_cpu / 1e9, 3), 'unit': 'GB/s', 'ms': round(t_cpu * 1e3, 1), 'cores': 1, 'kind': 'port',
+                             'sample': 'the whole matrix, one pass of orc_transpose'}}
+
+
+def abt(dev, m=None, ra=2000, rb=20000, reps=3):
+    from oracle import oracle as O
+    nr, nc, nnz = ML_SHAPE
+    m = m or ml_matrix(dev)
+
+    def sub(r1):
+        rp = m['rowptrs'][:r1 + 1].contiguous()
+        return rp, int(rp[-1].item())
+    rpa, ea = sub(ra)
+    rpb, eb = sub(rb)
+    ha = _mk(rpa, m['colinds'][:ea], m['values'][:ea], ra, nc)
+    hb = _mk(rpb, m['colinds'][:eb], m['values'][:eb], rb, nc)
+
+    def run(keep=False):
+        c = handle_t(0)
+        check(lib.csrk_spgemm_abt(ha, hb, C.byref(c)))
+        if keep:
+            return c
+        check(lib.csrk_free(c))
+    ms, ms_min = _wall_ms(run, reps, warm=1)
+    c = run(keep=True)
+    nrc, ncc, nnzc = C.c_int32(), C.c_int32(), C.c_int64()
+    check(lib.csrk_info(c, C.byref(nrc), C.byref(ncc), C.byref(nnzc), None, None))
+    d_rp, d_ci, d_vs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(lib.csrk_device_ptrs(c, C.byref(d_rp), C.byref(d_ci), C.byref(d_vs)))
+
+    def dview(p, n, typestr, dt):
+        class _D:
+            pass
+        d = _D()
+        d.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (int(p.value), False), 'version': 2}
+        return torch.as_tensor(d, device=dev)
+    g_rp = dview(d_rp, ra + 1, '<i4', torch.int32)
+    g_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
+    g_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
+    cnt_a = torch.bincount(m['colinds'][:ea].long(), minlength=nc).to(torch.float64)
+    cnt_b = torch.bincount(m['colinds'][:eb].long(), minlength=nc).to(torch.float64)
+    products = int(float((cnt_a * cnt_b).sum()))
+    # the oracle on the same block: transpose + mult_ab = the reference's mult_abt; its rows hold the same columns
+    # in reverse-discovery order: sort (row, column) keys on the card and compare values bit for bit
+    ci_h, vs_h = m['colinds'][:eb].cpu().numpy(), m['values'][:eb].cpu().numpy()
+    t0 = time.perf_counter()
+    tnr, tnc, trp, tci, tvs = O.transpose(rb, nc, rpb.cpu().numpy(), ci_h, vs_h)
+    r = O.mult_ab((ra, nc, rpa.cpu().numpy(), ci_h[:ea], vs_h[:ea]), (tnr, tnc, trp, tci, tvs))
+    t_cpu = time.perf_counter() - t0
+    o_rp, o_ci, o_vs = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (r[2], r[3], r[4]))
+    ok = bool(o_ci.numel() == nnzc.value and torch.equal(o_rp.to(torch.int64), g_rp.to(torch.int64)))
+    if ok:
+        rows = torch.repeat_interleave(torch.arange(ra, device=dev), (o_rp[1:] - o_rp[:-1]).long())
+        key, perm = torch.sort(rows * int(rb) + o_ci.long())
+        ok = bool(torch.equal(key, rows * int(rb) + g_ci.long())
+                  and torch.equal(o_vs[perm].view(torch.int64), g_vs.view(torch.int64)))
+    abc = (ea + eb) * 12 + (ra + rb + 2) * 4 + nnzc.value * 12 + (ra + 1) * 4
+    check(lib.csrk_free(c))
+    check(lib.csrk_free(ha))
+    check(lib.csrk_free(hb))
+    return {'config': f'mult_abt ({ra} x {nc}) x ({rb} x {nc})^T, rows of the MovieLens-25M-shaped matrix', 'entry': 'csrk_spgemm_abt',
+            'ms': round(ms, 3), 'ms_min': round(ms_min, 3), 'timing': 'wall per call', 'intermediate_products': products,
+            'products_per_s': round(products / ms * 1e3, -6), 'gflops_2_per_product': round(2.0 * products / ms / 1e6, 1),
+            'product_nnz': int(nnzc.value), 'bound': 'data-dependent (no roofline stated: DESIGN.md section 6)',
+            'a_bt_c_bytes': int(abc), 'a_bt_c_gbs': round(abc / ms / 1e6, 1),
+            'parity': {'rowptrs_colsets_and_values_bit_exact_vs_oracle': ok, 'ok': ok},
+            'cpu_baseline': {'value': round(2.0 * products / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'ms': round(t_cpu * 1e3, 1), 'cores': 1,
+                             'kind': 'port', 'sample': 'the same block, one pass of orc_transpose + orc_mult_ab'}}
+
+
+def unit_rows(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, reps=5, cpu_entries=40_000_000):
+    "on the headline matrix (bench.py hands over its resident arrays; values are cloned: the operation is in place)"
+    from oracle import oracle as O
+    if rp is None:
+        nrows = ncols = 10_000_000
+        m = synth.powerlaw_csr(nrows, ncols, 200_000_000, device=dev)
+        rp, ci, vs = m['rowptrs'], m['colinds'], m['values']
+    nnz = int(ci.numel())
+    vals = vs.clone()
+    h = _mk(rp, ci, vals, nrows, ncols)
+    norms = torch.empty(nrows, dtype=torch.float64, device=dev)
+    ts = []
+    for i in range(reps + 1):
+        vals.copy_(vs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        check(lib.csrk_unit_rows_device(h, norms.data_ptr()))
+        torch.cuda.synchronize()
+        if i:
+            ts.append((time.perf_counter() - t0) * 1e3)
+    ms, ms_min = float(np.mean(ts)), float(np.min(ts))
+    alg = 2 * nnz * 8 + (nrows + 1) * rp.element_size() + nrows * 8
+    rp_h = rp.cpu().numpy()
+    r_s = int(np.searchsorted(rp_h, cpu_entries))
+    e_s = int(rp_h[r_s])
+    v_h = vs[:e_s].cpu().numpy().copy()
+    t0 = time.perf_counter()
+    n_h = O.unit_rows(r_s, rp_h[:r_s + 1], v_h)
+    t_cpu = time.perf_counter() - t0
+    g_n, g_v = norms[:r_s].cpu().numpy(), vals[:e_s].cpu().numpy()
+    with np.errstate(invalid='ignore', divide='ignore'):
+        en = float(np.nanmax(np.abs(g_n - n_h) / np.maximum(np.abs(n_h), 1e-300)))
+        ev = float(np.nanmax(np.abs(g_v - v_h)))          # unit rows: |v| <= 1, absolute = relative to the row norm
+    nan_same = bool(np.array_equal(np.isnan(g_v), np.isnan(v_h)))
+    check(lib.csrk_free(h))
+    alg_s = 2 * e_s * 8 + (r_s + 1) * 4 + r_s * 8
+    return {'config': f'unit_rows {nrows}x{ncols} nnz {nnz} f64 (the headline matrix), norms left in HBM', 'entry': 'csrk_unit_rows_device',
+            'ms': round(ms, 4), 'ms_min': round(ms_min, 4), 'timing': 'wall per call', 'bound': 'hbm', **_roof(alg, ms),
+            'parity': {'sample_norms_max_rel_err': en, 'sample_values_max_abs_err': ev, 'nan_pattern_identical': nan_same,
+                       'tolerance': 1e-6, 'ok': bool(en <= 1e-6 and ev <= 1e-6 and nan_same)},
+            'cpu_baseline': {'value': round(alg_s / t_cpu / 1e9, 3), 'unit': 'GB/s', 'cores': 1, 'kind': 'port',
+                             'sample': f'the first {r_s} rows ({e_s} entries), one pass of orc_unit_rows ({t_cpu:.2f} s)'}}
+
+
+def run_all(dev, headline=None, log=None):
+    """
+    -> {'spmm': ..., 'transpose': ..., 'abt': ..., 'unit_rows': ..., 'seconds': ...}; a part that raises is reported as
+    {'error': ...} (the headline line must still be printed).  `headline` = (rp, ci, vs, nrows, ncols) resident arrays.
+    """
+    out = {}
+    t_all = time.perf_counter()
+
+    def part(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:                # noqa: BLE001 -- reported, never hidden
+            out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        out[name]['seconds'] = round(time.perf_counter() - t0, 2)
+        if log:
+            log(f'[bench secondary] {name}: {out[name].get("ms", out[name].get("error"))} ms, {out[name]["seconds"]} s')
+    if headline is not None:
+        part('unit_rows', lambda: unit_rows(dev, *headline))
+    else:
+        part('unit_rows', lambda: unit_rows(dev))
+    part('spmm', lambda: spmm(dev))
+    ml = ml_matrix(dev)
+    part('transpose', lambda: transpose(dev, ml))
+    part('abt', lambda: abt(dev, ml))
+    del ml
+    check(lib.csrk_trim_cache())
+    out['seconds'] = round(time.perf_counter() - t_all, 2)
+    return out

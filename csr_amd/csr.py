@@ -53,8 +53,15 @@ class CSR:
     # write-protected; every method here that changes them calls _edited() first.
     __csrk_cacheable__ = True
 
+    _parent = None      # subset_rows: the matrix whose colinds / values this one views
+
     def _edited(self):
-        "the arrays are about to change: drop cached device copies (restores the arrays' writeable flags)"
+        """
+        The arrays are about to change: drop cached device copies (restores the arrays' writeable flags) -- of this
+        matrix and of every matrix it is a row range of (subset_rows hands out views: the edit reaches the parent).
+        """
+        if self._parent is not None:
+            self._parent._edited()
         from . import kernels as _k
         mods = list(_k.kernels.values())
         hip = sys.modules.get(_k.__name__ + '.hip')       # (loaded but not yet looked up through the registry)
@@ -109,6 +116,27 @@ class CSR:
         np.cumsum(np.bincount(rows, minlength=nrows), out=rps[1:])
         return cls(nrows, ncols, nnz, rps, cols[order], None if vals is None else np.asarray(vals)[order])
 
+    @classmethod
+    def from_scipy(cls, mat, copy=True):
+        """
+        csr/csr.py:171-192: any SciPy sparse matrix -> CSR (through .tocsr() when it is not CSR already).
+        copy=False shares SciPy's arrays where their dtypes allow.  Host only.
+        """
+        import scipy.sparse as sps
+        if not sps.isspmatrix_csr(mat):
+            mat, copy = mat.tocsr(), False           # the conversion already made fresh arrays
+        parts = []
+        for a, dt in ((mat.indptr, np.intc), (mat.indices, np.intc), (mat.data, None)):
+            b = np.require(a, dt, 'C')
+            parts.append(b.copy() if copy and np.shares_memory(a, b) else b)
+        return cls(mat.shape[0], mat.shape[1], mat.nnz, *parts)
+
+    def to_scipy(self):
+        "csr/csr.py:194-209: scipy.sparse.csr_matrix over the same arrays (a structure-only matrix gets 1.0 values)"
+        import scipy.sparse as sps
+        vs = np.ones(self.nnz) if self._values is None else self._values
+        return sps.csr_matrix((vs, self.colinds, self.rowptrs), shape=(self.nrows, self.ncols))
+
     # ---- fields ---------------------------------------------------------------------------
     @property
     def values(self):
@@ -143,14 +171,53 @@ class CSR:
         "csr/csr.py:432-441.  Host diff like the reference; the device version is kernel.row_nnzs."
         return np.diff(self.rowptrs)
 
+    def rowinds(self):
+        "csr/csr.py:366-371 -> csr/_rows.py:116-122: the row index of every stored entry (COO row array), intc"
+        return np.repeat(np.arange(self.nrows, dtype=np.intc), np.diff(self.rowptrs))
+
+    def row_cs(self, row):
+        "csr/csr.py:419-423: the column indices stored for `row` (a view)"
+        lo, hi = self.row_extent(row)
+        return self.colinds[lo:hi]
+
+    def row_vs(self, row):
+        "csr/csr.py:425-430: the values stored for `row` (a view); 1.0 per entry for a structure-only matrix"
+        lo, hi = self.row_extent(row)
+        return np.ones(hi - lo) if self._values is None else self._values[lo:hi]
+
+    def _dense_rows(self, row, dtype, ones):
+        row = np.asarray(row, dtype=np.int32)
+        out = np.zeros(row.shape + (self.ncols,), dtype=dtype)
+        for dst, r in zip(out.reshape(-1, self.ncols), row.reshape(-1)):
+            lo, hi = self.row_extent(r)
+            dst[self.colinds[lo:hi]] = 1 if ones else self._values[lo:hi]
+        return out
+
+    def row(self, row):
+        """
+        csr/csr.py:373-388 -> csr/_rows.py:70-82: one row (or, for an index array, one row per index) densified:
+        stored values, 0 elsewhere; a structure-only matrix gives float32 ones.  Host only.
+        """
+        if self._values is None:
+            return self._dense_rows(row, np.float32, True)
+        return self._dense_rows(row, self._values.dtype, False)
+
+    def row_mask(self, row):
+        "csr/csr.py:390-404: like row(), but True where the row stores an entry"
+        return self._dense_rows(row, np.bool_, True)
+
     def subset_rows(self, begin, end):
-        "csr/csr.py:331-346 -> csr/structure.py:70-81: views of colinds/values, rebased pointers"
-        st = self.rowptrs[begin]
-        ed = self.rowptrs[end]
-        rps = self.rowptrs[begin:(end + 1)] - st
-        cis = self.colinds[st:ed]
-        vs = self.values[st:ed] if self.values is not None else None
-        return CSR(end - begin, self.ncols, ed - st, rps, cis, vs)
+        """
+        csr/csr.py:331-346 -> csr/structure.py:70-81: views of colinds/values, rebased pointers.  The views write
+        through to this matrix, as in the reference: a cached device copy of this matrix is dropped first (views taken
+        under the write guard would stay read-only for good), and the sub-matrix's own mutators drop it again.
+        """
+        self._edited()
+        lo, hi = int(self.rowptrs[begin]), int(self.rowptrs[end])
+        sub = CSR(end - begin, self.ncols, hi - lo, self.rowptrs[begin:end + 1] - lo, self.colinds[lo:hi],
+                  None if self._values is None else self._values[lo:hi])
+        sub._parent = self
+        return sub
 
     def pick_rows(self, rows, *, include_values=True):
         """
@@ -233,27 +300,25 @@ class CSR:
             crepr._filter_zeros()
             return crepr
 
-        if self.nnz <= K.max_nnz:
-            with releasing(K.to_handle(other), K) as b_h:
-                return mul(self, b_h)
-        shards = self._shard_rows(K.max_nnz)
         with releasing(K.to_handle(other), K) as b_h:
-            sparts = [mul(s, b_h) for s in shards]
-        return CSR._assemble_shards(sparts)
+            # one handle of B serves every row block of A; a single block is returned as it is
+            blocks = [mul(blk, b_h) for blk in self._row_blocks(K.max_nnz)]
+        return blocks[0] if len(blocks) == 1 else CSR._assemble_shards(blocks)
 
     def mult_vec(self, v):
-        "csr/csr.py:569-590"
+        "csr/csr.py:569-590: y = A v; above K.max_nnz the row blocks' products are concatenated in row order"
         v = np.asarray(v)
         assert v.shape == (self.ncols,)
         K = get_kernel()
-        if self.nnz <= K.max_nnz:
-            with releasing(K.to_handle(self), K) as h:
-                return K.mult_vec(h, v)
-        svs = []
-        for s in self._shard_rows(K.max_nnz):
-            with releasing(K.to_handle(s), K) as h:
-                svs.append(K.mult_vec(h, v))
-        return np.concatenate(svs)
+        ys = []
+        for blk in self._row_blocks(K.max_nnz):
+            with releasing(K.to_handle(blk), K) as h:
+                ys.append(K.mult_vec(h, v))
+        return ys[0] if len(ys) == 1 else np.concatenate(ys)
+
+    def _row_blocks(self, limit):
+        "the matrix itself when it fits the kernel's max_nnz, else its _shard_rows blocks"
+        return [self] if self.nnz <= limit else self._shard_rows(limit)
 
     def _filter_zeros(self):
         """
@@ -271,38 +336,40 @@ class CSR:
         self.nnz = int(cum[-1])
 
     def _shard_rows(self, tgt_nnz):
-        "csr/csr.py:599-621"
+        """
+        csr/csr.py:599-621: consecutive row blocks of at most tgt_nnz entries each, cut greedily: a block ends at the
+        last row boundary that keeps it within the target; a single row larger than the target cannot be placed.
+        Pinned by tests/golden/shard.npz (the reference's own cuts).
+        """
         assert tgt_nnz > 0
-        rest = self
-        shards = []
-        while rest.nnz > tgt_nnz:
-            split = int(np.searchsorted(rest.rowptrs, tgt_nnz))
-            if rest.rowptrs[split] > tgt_nnz:
-                if split <= 1:
+        ptr = self.rowptrs.astype(np.int64)
+        cuts = [0]
+        while int(ptr[-1]) - int(ptr[cuts[-1]]) > tgt_nnz:
+            first = cuts[-1]
+            room = int(ptr[first]) + tgt_nnz
+            # first row boundary at or past the target; when it overshoots, the boundary before it ends the block --
+            # unless that is the block's own start: then its first row alone exceeds the target
+            nxt = first + int(np.searchsorted(ptr[first:], room))
+            if ptr[nxt] > room:
+                if nxt - first <= 1:
                     raise ValueError("row too large to fit in target matrix size")
-                split -= 1
-            _log.debug('splitting %s at %d (rp@s: %d)', rest, split, rest.rowptrs[split])
-            shards.append(rest.subset_rows(0, split))
-            rest = rest.subset_rows(split, rest.nrows)
-        shards.append(rest)
-        return shards
+                nxt -= 1
+            _log.debug('%s: row block [%d, %d) holds %d entries', self, first, nxt, int(ptr[nxt]) - int(ptr[first]))
+            cuts.append(nxt)
+        cuts.append(self.nrows)
+        return [self.subset_rows(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
 
     @classmethod
     def _assemble_shards(cls, shards):
-        "csr/csr.py:623-650"
-        nrows = sum(s.nrows for s in shards)
-        ncols = max(s.ncols for s in shards)
+        "csr/csr.py:623-650: stack row blocks (same ncols up to trailing width) back into one matrix, rows in order"
+        counts = np.concatenate([np.diff(s.rowptrs) for s in shards]) if shards else np.zeros(0, np.int64)
+        rps = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum(counts, out=rps[1:])
         nnz = sum(s.nnz for s in shards)
-        rps = np.zeros(nrows + 1, np.int64)
-        rs = 0
-        for s in shards:
-            off = rps[rs]
-            rps[rs:rs + s.nrows + 1] = s.rowptrs + off
-            rs += s.nrows
-        assert rps[nrows] == nnz, f'{rps[nrows]} != {nnz}'
+        assert rps[-1] == nnz, f'{rps[-1]} != {nnz}'
         cis = np.concatenate([s.colinds for s in shards])
-        vs = np.concatenate([s.values for s in shards]) if shards[0].values is not None else None
-        return cls(nrows, ncols, nnz, rps, cis, vs)
+        vs = None if shards[0].values is None else np.concatenate([s.values for s in shards])
+        return cls(len(counts), max(s.ncols for s in shards), nnz, rps, cis, vs)
 
     def __str__(self):
         return '<CSR {}x{} ({} nnz)>'.format(self.nrows, self.ncols, self.nnz)

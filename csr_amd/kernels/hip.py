@@ -23,7 +23,8 @@ where a stale copy cannot go unseen:
     call `invalidate`, their arrays own their memory, and WHILE A DEVICE COPY IS CACHED THE THREE HOST ARRAYS ARE
     WRITE-PROTECTED (ndarray.flags.writeable = False; restored when the copy is dropped) -- `A.values[i] = v` between
     two products raises "assignment destination is read-only" instead of multiplying by the old matrix.  Call
-    `invalidate(A)` first (it drops the copy and restores the flags), then edit.  The reference's numba handle
+    `invalidate(A)` first (it drops the copy and restores the flags), then edit.  (NumPy raises that error itself:
+    the message cannot name `invalidate`; INTEGRATION.md section 2a does.)  The reference's numba handle
     aliases the host arrays (csr/kernels/numba/__init__.py:16-27), so there an edit is simply seen; here it is
     either seen or refused, never missed.  (A view of an array taken BEFORE its first product keeps its own
     writeable flag -- the one alias the guard cannot reach; the sampled fingerprint below is the second line.)
@@ -124,13 +125,17 @@ def _protect(arrays):
     "write-protect the host arrays of a cached copy (caller holds the lock); returns what to hand to _unprotect"
     held = []
     for a in arrays:
-        if a is None or not a.flags.writeable:
+        if a is None:
             continue
         g = _guards.get(id(a))
-        if g is None:
-            g = _guards[id(a)] = [a, 0]
-            a.flags.writeable = False
-        g[1] += 1
+        if g is not None and g[0] is a:
+            g[1] += 1                    # already guarded for another cached copy that shares it (CSR.copy(copy_structure=False))
+            held.append(a)
+            continue
+        if not a.flags.writeable:        # read-only before we came: not ours to restore
+            continue
+        _guards[id(a)] = [a, 1]
+        a.flags.writeable = False
         held.append(a)
     return held
 
@@ -187,15 +192,24 @@ def flush_handle_cache():
 def invalidate(csr):
     """
     Forget the cached device copy of `csr` and make its arrays writable again: call BEFORE editing them in place
-    (csr_amd.CSR's own mutators do); the next to_handle copies afresh.
+    (csr_amd.CSR's own mutators do); the next to_handle copies afresh.  Cached copies of OTHER matrices that share one
+    of csr's arrays (CSR.copy(copy_structure=False)) are dropped with it: the edit would reach them too.
     """
+    mine = [a for a in (getattr(csr, 'rowptrs', None), getattr(csr, 'colinds', None), getattr(csr, 'values', None))
+            if a is not None]
     with _cache_lock:
-        for e in [e for e in _cache.values() if e.key[0] == id(csr)]:
-            _drop_entry(e)
+        for e in list(_cache.values()):
+            if e.key[0] == id(csr) or (e.guard and any(g is a for g in e.guard for a in mine)):
+                _drop_entry(e)
 
 
 def _call(fn, *args):
-    "a library call that may need device memory: on failure, give back what idle cached copies hold and retry once"
+    """
+    A library call that may need device memory: on failure, give back what idle cached copies hold and retry once.
+    Only for calls that leave their operands untouched when they fail (products, transposes, copies): the in-place
+    operations (order_columns, unit_rows, center_rows) are never retried -- a second pass over a half-updated matrix
+    would report success with wrong norms.
+    """
     rc = fn(*args)
     if rc == _lib.ERR_HIP:
         with _cache_lock:
@@ -358,7 +372,7 @@ def release_handle(h):
 def order_columns(h):
     "csr/kernels/numba/__init__.py:47-52: sort each row by column, in place on the handle"
     _detach(h)
-    _call(lib.csrk_order_columns, _live(h))
+    check(lib.csrk_order_columns(_live(h)))         # in place: never retried (see _call)
 
 
 def mult_vec(h, v):
@@ -451,7 +465,7 @@ def _row_stat(fn, h):
         raise ValueError('matrix has no values')
     _detach(h)                     # unit_rows / center_rows rewrite the device copy's values
     out = np.empty(h.nrows, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
-    _call(fn, h.H, ptr(out))
+    check(fn(h.H, ptr(out)))                        # in place: never retried (see _call)
     return out
 
 

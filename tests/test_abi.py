@@ -99,3 +99,50 @@ def test_c_consumer_runs(tmp_path):
     r = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert 'c consumer ok' in r.stdout
+
+
+def test_entry_points_are_callable_by_raw_address():
+    """
+    SURVEY.md section 8f-4: a nopython caller binds an address + a C signature (the cffi pattern of
+    csr/kernels/mkl/_api.py:8-21).  Every exported entry is rebuilt from its raw address with CFUNCTYPE and must
+    behave like the bound symbol -- checked here with calls that need no GPU (status codes, error text).
+    """
+    import ctypes as C
+    from csr_amd import _lib
+    from csr_amd.kernels import raw
+    tab = raw.table()
+    assert set(tab) == set(_lib.SIGNATURES) and all(addr for addr, _, _ in tab.values())
+    assert len({addr for addr, _, _ in tab.values()}) == len(tab)                 # distinct symbols, distinct addresses
+    assert raw.function('csrk_version')() == _lib.lib.csrk_version()
+    spmv = C.CFUNCTYPE(C.c_int, C.c_ssize_t, C.c_void_p, C.c_void_p)(raw.address('csrk_spmv'))
+    x, y = np.ones(2), np.zeros(2)
+    assert spmv(12345, x.ctypes.data, y.ctypes.data) == _lib.lib.csrk_spmv(12345, x.ctypes.data, y.ctypes.data) == _lib.ERR_INVALID
+    assert b'invalid csrk handle' in raw.function('csrk_last_error')()
+    assert raw.function('csrk_free')(0) == _lib.OK and raw.function('csrk_free')(777) == _lib.ERR_INVALID
+    # create goes as far as the device: without one, the raw call reports CSRK_ERR_HIP exactly like the bound symbol
+    import torch
+    if torch.cuda.device_count() == 0:
+        rp, ci, vs = np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), np.array([1.0, 2.0])
+        h = _lib.handle_t(0)
+        rc = raw.function('csrk_create')(2, 2, 2, rp.ctypes.data, 0, ci.ctypes.data, vs.ctypes.data, _lib.VAL_F64, C.byref(h))
+        assert rc == _lib.ERR_HIP and h.value == 0
+
+
+@pytest.mark.gpu
+def test_raw_address_calls_compute_the_known_answers():
+    "the protocol sequence to_handle -> mult_vec -> transpose -> release through raw addresses only (tests/test_transpose.py:11-27 KAT)"
+    import ctypes as C
+    from csr_amd import _lib
+    from csr_amd.kernels import raw
+    f = {n: raw.function(n) for n in ('csrk_create', 'csrk_spmv', 'csrk_transpose', 'csrk_export', 'csrk_info', 'csrk_free')}
+    rp, ci, vs = np.array([0, 2, 3, 3, 4], np.int32), np.array([1, 2, 0, 1], np.int32), np.arange(4.0)
+    h, t = _lib.handle_t(0), _lib.handle_t(0)
+    assert f['csrk_create'](4, 3, 4, rp.ctypes.data, 0, ci.ctypes.data, vs.ctypes.data, _lib.VAL_F64, C.byref(h)) == 0
+    x, y = np.array([1.0, 10.0, 100.0]), np.empty(4)
+    assert f['csrk_spmv'](h.value, x.ctypes.data, y.ctypes.data) == 0
+    assert np.array_equal(y, [100.0, 2.0, 0.0, 30.0])
+    assert f['csrk_transpose'](h.value, 1, C.byref(t)) == 0
+    trp, tci, tvs = np.empty(4, np.int32), np.empty(4, np.int32), np.empty(4)
+    assert f['csrk_export'](t.value, trp.ctypes.data, tci.ctypes.data, tvs.ctypes.data) == 0
+    assert list(trp) == [0, 1, 3, 4] and list(tci) == [1, 0, 3, 0] and list(tvs) == [2.0, 0.0, 3.0, 1.0]
+    assert f['csrk_free'](t.value) == 0 and f['csrk_free'](h.value) == 0

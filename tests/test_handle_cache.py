@@ -232,3 +232,74 @@ def test_small_and_converted_matrices_are_not_cached(K):
     assert K.lib.created == 4
     K.flush_handle_cache()
     assert not K.lib.live
+
+
+def test_shared_structure_is_guarded_for_every_cached_copy(K):
+    "CSR.copy(copy_structure=False) shares rowptrs / colinds: each cached copy holds its own reference on the guard"
+    A = _mat()
+    B = A.copy(copy_structure=False)
+    assert B.rowptrs is A.rowptrs and B.colinds is A.colinds
+    K.release_handle(K.to_handle(A))
+    K.release_handle(K.to_handle(B))
+    assert K.lib.created == 2 and not A.colinds.flags.writeable
+    e_a = next(e for e in K._cache.values() if e.key[0] == id(A))
+    K._drop_entry(e_a)                                # A's copy goes (eviction): B's still guards the shared arrays
+    assert not A.colinds.flags.writeable and not B.rowptrs.flags.writeable
+    assert A.values.flags.writeable and not B.values.flags.writeable
+    with pytest.raises(ValueError):
+        A.colinds[0] = 3                              # would reach B's cached device copy unseen
+    K.invalidate(B)
+    assert A.colinds.flags.writeable and B.values.flags.writeable
+
+
+def test_invalidate_reaches_copies_that_share_an_array(K):
+    A = _mat()
+    B = A.copy(copy_structure=False)
+    K.release_handle(K.to_handle(A))
+    K.release_handle(K.to_handle(B))
+    K.invalidate(A)                                   # A's structure is about to change: so is B's
+    assert not K.lib.live and A.colinds.flags.writeable and B.values.flags.writeable
+    A.colinds[0] = 3
+    K.release_handle(K.to_handle(B))
+    assert K.lib.created == 3                         # B was copied afresh, with the edit
+
+
+def test_subset_rows_under_the_guard_gives_writeable_views(K, monkeypatch):
+    """
+    A product caches A and write-protects its arrays; a row range taken afterwards must still behave like the
+    reference's (csr/structure.py:70-81: views that write through), and its edits must drop A's device copy.
+    """
+    A = _mat()
+    K.release_handle(K.to_handle(A))
+    assert not A.values.flags.writeable
+    S = A.subset_rows(10, 5000)
+    assert S.values.flags.writeable and S.colinds.flags.writeable and np.shares_memory(S.values, A.values)
+    assert not K.lib.live                             # taking the views dropped the cached copy
+    K.release_handle(K.to_handle(A))                  # cached (and guarded) again while S is alive
+    assert K.lib.created == 2 and K.lib.live
+    before = A.values[10]
+    S._edited()                                       # what S.normalize_rows() / S.sort_rows() call before writing
+    S.values[...] = 7.0                               # a view of A's array: the write goes through
+    assert A.values[10] == 7.0 and before != 7.0 and not K.lib.live
+    K.release_handle(K.to_handle(A))
+    S.values = S.values * 2.0                         # replaces S's array: still announces the edit up the chain
+    assert not K.lib.live
+    K.release_handle(K.to_handle(A))
+    assert K.lib.created == 4
+
+
+def test_in_place_operations_are_not_retried(K, monkeypatch):
+    "a failed unit_rows / order_columns may have rewritten part of the matrix: a second pass would double-apply"
+    A, B = _mat(seed=0), _mat(seed=1)
+    K.release_handle(K.to_handle(B))                  # an idle copy that a retry would flush
+    h = K.to_handle(A)
+    calls = []
+    monkeypatch.setattr(K.lib, 'csrk_info', lambda H, nr, nc, nnz, p64, vt: (setattr(vt._obj, 'value', 2), 0)[1], raising=False)
+    monkeypatch.setattr(K.lib, 'csrk_unit_rows', lambda H, out: (calls.append('u'), -2)[1], raising=False)
+    monkeypatch.setattr(K.lib, 'csrk_order_columns', lambda H: (calls.append('o'), -2)[1], raising=False)
+    with pytest.raises(Exception):
+        K.unit_rows(h)
+    with pytest.raises(Exception):
+        K.order_columns(h)
+    assert calls == ['u', 'o'] and len(K.lib.live) == 2
+    K.release_handle(h)

@@ -175,3 +175,31 @@ def test_subset_rows_views():
     s = m.subset_rows(1, 4)
     assert (s.nrows, s.nnz) == (3, 2) and list(s.rowptrs) == [0, 1, 1, 2]
     assert np.shares_memory(s.colinds, m.colinds) and np.shares_memory(s.values, m.values)
+
+
+def test_scipy_round_trip_and_row_accessors():
+    "csr/csr.py:171-209 (from_scipy / to_scipy), :366-430 (rowinds, row, row_mask, row_cs, row_vs): host conveniences"
+    import scipy.sparse as sps
+    from csr_amd import CSR
+    rng = np.random.default_rng(5)
+    sp = sps.random(40, 30, density=0.1, format='csr', random_state=rng, dtype=np.float64)
+    m = CSR.from_scipy(sp)
+    assert (m.nrows, m.ncols, m.nnz) == (40, 30, sp.nnz)
+    assert m.rowptrs.dtype == np.intc and m.colinds.dtype == np.intc
+    assert not np.shares_memory(m.values, sp.data) and not np.shares_memory(m.colinds, sp.indices)
+    assert np.shares_memory(CSR.from_scipy(sp, copy=False).values, sp.data)
+    assert CSR.from_scipy(sp.tocoo()).nnz == sp.nnz and CSR.from_scipy(sp.tocsc()).to_scipy().nnz == sp.nnz
+    back = m.to_scipy()
+    assert (back != sp).nnz == 0 and np.shares_memory(back.data, m.values)
+    dense = sp.toarray()
+    assert np.array_equal(m.row(3), dense[3]) and m.row(3).shape == (30,)
+    assert np.array_equal(m.row([5, 0, 5]), dense[[5, 0, 5]])
+    assert np.array_equal(m.row_mask(7), dense[7] != 0) and m.row_mask([1, 2]).shape == (2, 30)
+    lo, hi = m.row_extent(9)
+    assert np.array_equal(m.row_cs(9), sp.indices[lo:hi]) and np.array_equal(m.row_vs(9), sp.data[lo:hi])
+    assert np.array_equal(m.rowinds(), sp.tocoo().row) and m.rowinds().dtype == np.intc
+    s = m.copy(include_values=False)
+    assert np.array_equal(s.row(3), (dense[3] != 0).astype(np.float32)) and s.row(3).dtype == np.float32
+    assert np.array_equal(s.row_vs(9), np.ones(hi - lo)) and np.array_equal(s.to_scipy().toarray(), (dense != 0) * 1.0)
+    e = CSR.empty(3, 4)
+    assert np.array_equal(e.row(1), np.zeros(4)) and e.rowinds().size == 0
