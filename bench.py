@@ -12,8 +12,7 @@ row-range partitioned (nnz balanced) with x replicated, and one step = local SpM
 that completes y on every rank.  xGMI is point-to-point and the exchange of the 80 MB y is link-bound, so
 how RCCL drives the links decides the step: before the warm-up the candidates of csr_amd/dist.py (padded
 all-gather; the unpadded all-gather; point-to-point sends straight into y with the slice travelling while the tiers'
-part of the product runs; with --calibrate-all also plain point-to-point, IPC pushes, and the exchange pipelined behind
-the product in 2 / 4 chunks per rank) are each timed for 8 steps and the fastest runs the timed region
+part of the product runs) are each timed for 8 steps and the fastest runs the timed region
 (`multi_gpu.candidates_ms_per_step`; a candidate that fails, disagrees or exceeds --calibrate-seconds is dropped and the
 padded all-gather is the fallback; `--collective allreduce` forces the all-reduce north_star names, `--collective NAME`
 any other).
@@ -58,11 +57,8 @@ def parse():
     ap.add_argument('--alpha', type=float, default=1.1)
     ap.add_argument('--algo', default='auto', choices=['auto', 'merge', 'vector', 'scalar'])
     ap.add_argument('--collective', default='auto',
-                    choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p', 'p2p-split', 'ipc-push', 'p2p-k2', 'p2p-k4', 'allgather-k2'],
+                    choices=['auto', 'allgather', 'allgatherv', 'allreduce', 'p2p-split'],
                     help='N > 1: how y is completed on every rank; auto = time the candidates before the warm-up and keep the fastest')
-    ap.add_argument('--calibrate-all', action='store_true',
-                    help='N > 1, --collective auto: also time the chunked (p2p-k2, p2p-k4), plain p2p and IPC-push exchanges '
-                         '(each builds extra per-chunk plans); default: allgather, allgatherv, p2p-split')
     ap.add_argument('--calibrate-seconds', type=float, default=20.0,
                     help='N > 1: a candidate whose build + 3 untimed steps take longer than this is dropped')
     ap.add_argument('--force-dist', action='store_true',
@@ -154,9 +150,7 @@ def main():
 
     from csr_amd import synth
     from csr_amd._lib import lib, check, handle_t, SPMV_AUTO, SPMV_MERGE, SPMV_VECTOR, SPMV_SCALAR
-    from csr_amd.dist import (RowPartitionedSpMV, PipelinedRowPartitionedSpMV, SplitPhaseRowPartitionedSpMV,
-                              IpcPushRowPartitionedSpMV, chunk_cuts,
-                              hip_local_spmv, hip_local_spmv_parts)
+    from csr_amd.dist import RowPartitionedSpMV, SplitPhaseRowPartitionedSpMV, hip_local_spmv, hip_local_spmv_parts
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -240,48 +234,15 @@ def main():
         sys.exit(f'[bench rank {rank}] the planned SpMV is not bitwise reproducible: {int(n_differ.item())} of {REPRO_CALLS} products differ')
     del y_tmp, y_ref
 
-    # N > 1: the ways of completing y on every rank (csr_amd/dist.py).  Chunked candidates hold one handle per chunk
-    # (views of this rank's arrays, row pointers rebased).
-    keep = []                  # tensors the chunk handles borrow
-
-    def chunk_handles(K):
-        cuts = chunk_cuts(rp, K)
-        hs = []
-        for c in range(K):
-            a, b = cuts[c], cuts[c + 1]
-            e0, e1 = int(rp[a].item()), int(rp[b].item())
-            rpc = (rp[a:b + 1] - rp[a]).contiguous()
-            cic, vsc = ci[e0:e1], vs[e0:e1]
-            keep.extend([rpc, cic, vsc])
-            hc = handle_t(0)
-            check(lib.csrk_create_device(b - a, ncols, e1 - e0, rpc.data_ptr(), int(rpc.dtype == torch.int64),
-                                         cic.data_ptr() if e1 > e0 else ci.data_ptr(),
-                                         vsc.data_ptr() if e1 > e0 else vs.data_ptr(), 2, C.byref(hc)))
-            check(lib.csrk_set_spmv_algo(hc, algo_code))
-            hs.append(hc)
-        table = [None] * world
-        dist.all_gather_object(table, [shard['row_begin'] + c for c in cuts])
-        return hs, table
-
+    # N > 1: the ways of completing y on every rank (csr_amd/dist.py)
     def make_op(name):
         "-> (operator, handles it owns)"
         if not distd or name in ('allgather', 'allgatherv', 'allreduce'):
             return RowPartitionedSpMV(shard['bounds'], rank, world, local, dev,
                                       mode=name if distd else 'allgather'), []
-        if name == 'p2p-split':
-            run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
-            return SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
-        if name == 'ipc-push':
-            run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
-            return IpcPushRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
-        exch, _, k = name.partition('-k')
-        K = int(k) if k else 1
-        if K == 1:
-            table = [[shard['bounds'][g], shard['bounds'][g + 1]] for g in range(world)]
-            return PipelinedRowPartitionedSpMV(table, rank, world, [local], dev, exchange=exch), []
-        hs, table = chunk_handles(K)
-        return PipelinedRowPartitionedSpMV(table, rank, world, [hip_local_spmv(hc.value) for hc in hs], dev,
-                                           exchange=exch), hs
+        assert name == 'p2p-split'
+        run_part, cut_rows = hip_local_spmv_parts(h.value, dev)
+        return SplitPhaseRowPartitionedSpMV(shard['bounds'], rank, world, run_part, cut_rows, dev), []
 
     calibration = None
     if distd and args.collective == 'auto':
@@ -290,12 +251,9 @@ def main():
         # plans) and 8 timed ones; the slowest rank's time decides, so every rank picks the same one.
         calibration, best = {}, None
         ref_sum = None
-        # Bounded by default: the padded all-gather (the safe fallback, always first), the unpadded all-gather and the
-        # split-phase point-to-point form, none of which builds another plan.  --calibrate-all adds the forms that
-        # hold extra per-chunk handles (2.4 GB of plan each on the headline matrix) or IPC mappings.
+        # the padded all-gather (the safe fallback, always first), the unpadded all-gather and the split-phase
+        # point-to-point form: none builds another plan
         names = ('allgather', 'allgatherv', 'p2p-split')
-        if args.calibrate_all:
-            names += ('p2p', 'ipc-push', 'p2p-k2', 'p2p-k4')
         for name in names:
             cand, hs, err = None, [], None
             try:

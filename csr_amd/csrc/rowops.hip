@@ -55,7 +55,7 @@ constexpr int RS_B = WAVE * RS_K;   // class B, one wavefront per row (512)
 #define CSRK_RS_THREADS 512      // (class C1 alone on the headline matrix: 1024 threads 0.357 ms, 512 0.270, 256 0.278)
 #endif
 constexpr int RS_THREADS = CSRK_RS_THREADS;
-constexpr int RS_CHUNK = RS_THREADS * RS_K;      // class C: entries per chunk (8192)
+constexpr int RS_CHUNK = RS_THREADS * RS_K;      // class C: entries per chunk (4096)
 
 // (m, e) = frexp(vmax); pnexp = clamp(-e, minexp, maxexp - 1); prenorm = 2^pnexp (transform.py:55-58); a NaN or infinite
 // maximum leaves the exponent at 0
@@ -472,6 +472,23 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     CSRK_TRY(list_b.alloc((size_t)(m->nnz / (RS_B8 + 1) + 1) * 4));
     CSRK_TRY(list_c.alloc((size_t)(m->nnz / (RS_B + 1) + 1) * 4));
     CSRK_TRY(counts.alloc((size_t)(3 * n_waves + 1) * 4));
+    // Every table of the long-row chain is allocated HERE, sized by its upper bound, before the first kernel that
+    // rewrites values: a failed allocation later would return an error with the matrix half-normalised.  At most
+    // nnz / 513 rows reach class C, and a long row has at most one partial chunk beyond its full ones.
+    const int64_t n_c_max = m->nnz / (RS_B + 1) + 1;
+    const int64_t n_chunks_max = n_c_max + m->nnz / RS_CHUNK;
+    DevBuf rc0, ck0, clen, crow, pa, pb, pe, sa, sb;
+    if (m->nnz > RS_B) {
+        CSRK_TRY(rc0.alloc((size_t)(n_c_max + 2) * 4));
+        CSRK_TRY(ck0.alloc((size_t)n_chunks_max * 8));
+        CSRK_TRY(clen.alloc((size_t)n_chunks_max * 4));
+        CSRK_TRY(crow.alloc((size_t)n_chunks_max * 4));
+        CSRK_TRY(pa.alloc((size_t)n_chunks_max * 8));
+        CSRK_TRY(pb.alloc((size_t)n_chunks_max * 8));
+        CSRK_TRY(pe.alloc((size_t)n_chunks_max * 4));
+        CSRK_TRY(sa.alloc((size_t)n_c_max * 8));
+        CSRK_TRY(sb.alloc((size_t)n_c_max * 8));
+    }
     const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
     SideStream side;
     CSRK_TRY(side_stream(&side));
@@ -504,22 +521,12 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
             CSRK_LAUNCH_CHECK();                                                                                       \
         }                                                                                                              \
         if (n_c > 0) {                                                                                                 \
-            DevBuf rc0, ck0, clen, crow, pa, pb, pe, sa, sb;                                                           \
-            CSRK_TRY(rc0.alloc((size_t)(n_c + 2) * 4));                                                                \
             const unsigned gc = (unsigned)ceil_div(n_c, 256);                                                          \
             row_chunk_count_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>()); \
             CSRK_LAUNCH_CHECK();                                                                                       \
             CSRK_TRY(exclusive_scan_i32(rc0.as<int32_t>(), rc0.as<int32_t>(), n_c, nullptr));                          \
             /* at most one partial chunk per long row beyond the full ones: no host round trip for the exact count */ \
             const int64_t n_chunks = (int64_t)n_c + m->nnz / RS_CHUNK;                                                 \
-            CSRK_TRY(ck0.alloc((size_t)n_chunks * 8));                                                                 \
-            CSRK_TRY(clen.alloc((size_t)n_chunks * 4));                                                                \
-            CSRK_TRY(crow.alloc((size_t)n_chunks * 4));                                                                \
-            CSRK_TRY(pa.alloc((size_t)n_chunks * 8));                                                                  \
-            CSRK_TRY(pb.alloc((size_t)n_chunks * 8));                                                                  \
-            CSRK_TRY(pe.alloc((size_t)n_chunks * 4));                                                                  \
-            CSRK_TRY(sa.alloc((size_t)n_c * sizeof(T)));                                                               \
-            CSRK_TRY(sb.alloc((size_t)n_c * sizeof(T)));                                                               \
             row_chunk_fill_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>(), \
                                                   ck0.as<int64_t>(), clen.as<int32_t>(), crow.as<int32_t>());           \
             CSRK_LAUNCH_CHECK();                                                                                       \

@@ -75,59 +75,6 @@ def test_row_partitioned_spmv_gloo(tmp_path, world, mode):
     assert max(per) - min(per) <= int(np.max(np.diff(rp))) + 1
 
 
-def _worker_pipelined(rank, world, port, exchange, K, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        from csr_amd import synth
-        from csr_amd.dist import PipelinedRowPartitionedSpMV, chunk_cuts
-        from oracle import oracle as O
-        nrows, ncols, nnz = 6000, 5000, 90000
-        shard = synth.powerlaw_csr(nrows, ncols, nnz, device='cpu', rank=rank, world=world)
-        x = synth.dense_vector(ncols, device='cpu')
-        rp, ci, vs = (shard[k].numpy() for k in ('rowptrs', 'colinds', 'values'))
-        r0 = shard['row_begin']
-        n_loc = shard['row_end'] - r0
-        cuts = chunk_cuts(shard['rowptrs'], K)
-        assert cuts[0] == 0 and cuts[-1] == n_loc and len(cuts) == K + 1
-        per = [int(rp[cuts[c + 1]] - rp[cuts[c]]) for c in range(K)]
-        assert max(per) - min(per) <= 2 * int(np.max(np.diff(rp))) + 1      # chunks balanced by nnz
-        table = [None] * world
-        dist.all_gather_object(table, [r0 + c for c in cuts])
-
-        def make(c):
-            a, b = cuts[c], cuts[c + 1]
-            rpc = rp[a:b + 1] - rp[a]
-            cic, vsc = ci[rp[a]:rp[b]], vs[rp[a]:rp[b]]
-
-            def run(xt, out):
-                out.copy_(torch.from_numpy(O.mult_vec(b - a, ncols, rpc, cic, vsc, xt.numpy())))
-            return run
-        op = PipelinedRowPartitionedSpMV(table, rank, world, [make(c) for c in range(K)], 'cpu', exchange=exchange)
-        y1 = op.step(x).clone()
-        y2 = op.step(x).clone()
-        assert torch.equal(y1, y2)
-        np.save(os.path.join(out_dir, f'yc_{rank}.npy'), y1.numpy())
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize('world', [2, 3])
-@pytest.mark.parametrize('exchange,K', [('p2p', 1), ('p2p', 3), ('allgather', 3)])
-def test_pipelined_row_partitioned_spmv_gloo(tmp_path, world, exchange, K):
-    "point-to-point exchange straight into y and K chunks per rank with asynchronous exchanges: the single-process y"
-    from csr_amd import synth
-    from oracle import oracle as O
-    mp.spawn(_worker_pipelined, args=(world, _free_port(), exchange, K, str(tmp_path)), nprocs=world, join=True)
-    full = synth.powerlaw_csr(6000, 5000, 90000, device='cpu')
-    x = synth.dense_vector(5000, device='cpu').numpy()
-    ref = O.mult_vec(6000, 5000, full['rowptrs'].numpy(), full['colinds'].numpy(), full['values'].numpy(), x)
-    for r in range(world):
-        assert np.array_equal(np.load(tmp_path / f'yc_{r}.npy'), ref)
-
-
 def _worker_split(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
