@@ -390,8 +390,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 26)()
-    check(lib.csrk_spmv_plan_stats(hp, st, 26))
+    st = (C.c_int64 * 29)()
+    check(lib.csrk_spmv_plan_stats(hp, st, 29))
     if op_handles:
         # the roofline block describes the first chunk's handle (the kernels that were timed)
         i_r, i_c, i_n, i_p, i_v = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int(0), C.c_int(0)
@@ -452,6 +452,9 @@ def main():
     k_sum_ms = sum(k['ms'] for k in kernels)
     frac_step = round(whole_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
     notes = []
+    if int(st[28]):
+        notes.append('tier 1\'s pair kernel runs on a side stream beside the tier-0 accumulator kernel: the per-kernel times overlap '
+                     'and add up to more than the step; frac_whole_spmv_over_step is the whole product over the wall time')
     if dom['stream_gbs'] > 6290.0 * 1.1:
         notes.append('accounting check: the dominant kernel\'s own-stream rate exceeds the measured copy rate by more than 10 %')
     roofline = {
@@ -493,7 +496,8 @@ def main():
                    'row_degree': f'power-law alpha={args.alpha}, max {int(min(1_000_000, ncols // 8))}',
                    'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
-                   'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9])},
+                   'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9]),
+                             'accumulator_workgroups': int(st[27]), 'tier1_kernel_beside_it': bool(st[28])},
                    'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
                    'hot_column_cache': {'columns': int(st[16]), 'entry_share_sampled': round(int(st[17]) / 1e6, 4), 'slots': int(st[19])},
                    'cold_staged_entries': int(st[24]),

@@ -188,10 +188,18 @@ struct SpmvPlan {
     int prof_calls = 0;
     int prof_mask = 0xf;          // channels that get event pairs (csrk_spmv_profile_channels)
     bool prof_this = false;       // the launch group in progress is being timed
+    // tier 1 beside tier 0 (see "the two tiers side by side"): the accumulator kernel runs on acc_wgs < #CUs workgroups
+    // and the pair kernel of tier 1 on a side stream takes the CUs it leaves free
+    bool t1_beside = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         for (AccPanel *a : acc) delete a;
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -2235,7 +2243,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
 // column-block-major (value, packed index) stream plus the persistent workgroups' segment lists.
 template <class P, int VT>
 static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const int64_t *lens, int32_t n, int64_t nnz_rows,
-                           hipStream_t s)
+                           hipStream_t s, int64_t wgs = 0)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
@@ -2282,7 +2290,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     // segments
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    int64_t n_wg = cus > 0 ? cus : 256;
+    int64_t n_wg = wgs > 0 ? wgs : (cus > 0 ? cus : 256);
     if (const char *e = getenv("CSRK_ACC_WGS")) n_wg = atoll(e) > 0 ? atoll(e) : n_wg;
     if (n_wg > n_tiles) n_wg = n_tiles;
     if (n_wg < 1) n_wg = 1;
@@ -2468,6 +2476,37 @@ static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
     int64_t nnz0 = 0;
     for (int64_t l : len0) nnz0 += l;
     const int64_t nnz1 = p->t1_nnz;
+    // The two tiers side by side.  The accumulator kernel is bound by HBM: with fewer workgroups than CUs it loses little
+    // (headline matrix: 256 workgroups 0.220 ms, 224: 0.218, 192: 0.232, 160: 0.265, 128: 0.316), while the pair kernel of
+    // tier 1 waits on L2 gathers and leaves HBM idle (0.096 ms for 19.5 M entries at 3.6 TB/s).  So the accumulator kernel
+    // gets W = 25/32 of the CUs as persistent workgroups -- each fills its CU's LDS, so nothing else lands there -- and
+    // the pair kernel, launched on a side stream of the plan's own, starts on the other CUs at the same time and takes the
+    // rest as they come free.  Measured (20-step runs as the driver launches them, several boxes): 0.522 ms against 0.533
+    // with W = 200 on every box; W = 160, where a cost model puts the two kernels' ends together, gave 0.500-0.506 on some
+    // boxes and 0.552-0.556 on others (the same on each box run after run; stream priorities and a head start for the
+    // accumulator kernel changed nothing), so the setting that never loses is the default.  CSRK_SPMV_T1_BESIDE=0 turns
+    // it off, =W forces W.  Results do not depend on the overlap; they do depend on W (the accumulator partials are per
+    // workgroup), which is fixed per plan.
+    int64_t acc_wgs = 0;
+    {
+        const char *e = getenv("CSRK_SPMV_T1_BESIDE");
+        const char *t1env = getenv("CSRK_SPMV_TIER1");
+        const bool t1_stream = t1env && !strcmp(t1env, "stream");
+        int cus = 0;
+        CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+        if (!(e && e[0] == '0') && acc_form && !t1_stream && !r0.empty() && !r1.empty() && r0.size() <= (size_t)ACC_MAXROWS &&
+            cus >= 64) {
+            // worth two more stream operations per product only when tier 1 is a real share of the tiers' work
+            if ((double)nnz1 * 4.9 >= 0.08 * (double)nnz0 * 1.58) acc_wgs = (cus * 25 / 32) & ~7;
+            if (e && atoi(e) >= 8 && atoi(e) < cus) acc_wgs = atoi(e) & ~7;      // (CSRK_SPMV_T1_BESIDE=W forces W)
+        }
+        if (acc_wgs) {
+            if (!p->side) CSRK_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            if (!p->ev_fork) CSRK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            if (!p->ev_join) CSRK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            p->t1_beside = true;
+        }
+    }
     int tpw0 = 8, tpw1 = 1;
     if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
     if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
@@ -2482,7 +2521,7 @@ static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
             AccPanel *ap = new (std::nothrow) AccPanel();                                                          \
             CSRK_REQUIRE(ap, "out of host memory");                                                                \
             p->acc.push_back(ap);                                                                                  \
-            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
+            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s, acc_wgs))); \
         }                                                                                                          \
         if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
     } while (0)
@@ -3502,6 +3541,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                                                                             p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
         }
+        // tier 1 beside tier 0: the pair kernel goes to the side stream, ordered after everything submitted to `s` so far
+        const bool beside = p->t1_beside && do_heavy && p->n_heavy && !p->acc.empty() && p->tier[1].on && !p->t1s.on;
+        if (beside) {
+            CSRK_HIP(hipEventRecord(p->ev_fork, s));
+            CSRK_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        }
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
@@ -3534,6 +3579,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 CSRK_LAUNCH_CHECK();
                 continue;
             }
+            hipStream_t s_main = s;
+            if (q == 1 && beside) s = p->side;
             KernelTimer kh(p, s, 1 + q);
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
@@ -3550,6 +3597,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
+            if (q == 1 && beside) {
+                CSRK_HIP(hipEventRecord(p->ev_join, p->side));
+                s = s_main;
+            }
             // (the pair kernel's carries are added by the tier's reduce: Panel::crp)
         }
         if (do_light) {
@@ -3623,6 +3674,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_LAUNCH_CHECK();
             }
         }
+        if (beside) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join, 0));      // the epilogue's reduces read tier 1's pair partials
         if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
                 CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 4, nullptr, nullptr, nullptr));
@@ -3999,8 +4051,9 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     }
     const bool af = !p->acc.empty();
     const int64_t plan_bytes = spmv_plan_bytes(p);      // [25]
-    // [26] tiles per staging round when the round is held in LDS (else 0)
-    const int64_t v[27] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    // [26] tiles per staging round when the round is held in LDS (else 0); [27] workgroups of the accumulator kernel;
+    // [28] 1 when tier 1's pair kernel runs beside it on the plan's side stream
+    const int64_t v[29] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
@@ -4008,8 +4061,9 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
                            p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
-                           p->ls.round_start.p ? p->ls.stage_tiles : 0};
-    for (int i = 0; i < n && i < 27; i++) out[i] = v[i];
+                           p->ls.round_start.p ? p->ls.stage_tiles : 0,
+                           af ? (int64_t)p->acc[0]->n_wg : 0, (p->t1_beside && t1.on && !p->t1s.on) ? 1 : 0};
+    for (int i = 0; i < n && i < 29; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

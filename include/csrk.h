@@ -144,7 +144,9 @@ CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *til
  * path's entries on packed columns (ppm), 18 tier-0 form (0 pairs, 1 accumulator), 19 pack slots,
  * 20 short rows on the light stream (1) or on the merge-path tile kernel (0), 21 light-stream tiles,
  * 22 non-empty rows of the light stream, 23 its workgroups, 24 light-stream entries whose x values are staged
- * per call (cold staging), 25 bytes of device memory the plan holds}; n <= 26. */
+ * per call (cold staging), 25 bytes of device memory the plan holds, 26 tiles per staging round held in LDS (0: none),
+ * 27 workgroups of the tier-0 accumulator kernel, 28 tier 1's kernel runs beside it on a side stream (1) or after it (0)};
+ * n <= 29. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on

@@ -233,7 +233,7 @@ def test_mult_abt_config5_large_block():
     assert np.all(np.abs(got - want) <= 1e-10 * scale + 1e-300)
 
 
-@pytest.mark.parametrize('collective', ['auto', 'allgatherv', 'p2p-split'])
+@pytest.mark.parametrize('collective', ['auto', 'allgather', 'p2p-split'])
 def test_bench_two_ranks_plumbing(collective):
     """
     bench.py's N > 1 path end to end on ONE GPU, started the way the driver starts N = 1 -- plain
