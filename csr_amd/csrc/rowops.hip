@@ -405,6 +405,45 @@ __global__ __launch_bounds__(256) void row_stat_c2_kernel(const P *__restrict__ 
     }
 }
 
+// Exclusive scan of cnt[0 .. n) in place, cnt[n] = total: ONE workgroup, no temporaries (the long rows are a few ten
+// thousand at most; the table-building chain runs on a side stream, where the pool-backed device scan must not be used)
+__global__ __launch_bounds__(1024) void row_chunk_scan_kernel(int32_t *__restrict__ cnt, int32_t n)
+{
+    __shared__ int32_t s_w[16];
+    __shared__ int32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int32_t b0 = 0; b0 < n; b0 += 1024 * 8) {
+        const int32_t b = b0 + tid * 8;
+        int32_t v[8], t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v[k] = b + k < n ? cnt[b + k] : 0;
+            t += v[k];
+        }
+        int32_t inc = t;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        int32_t run = s_carry + inc - t;
+        for (int k = 0; k < w; k++) run += s_w[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (b + k < n) cnt[b + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) cnt[n] = s_carry;
+}
+
 // C3: apply
 template <class T, bool UNIT>
 __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__ vs, const int64_t *__restrict__ chunk_k0,
@@ -433,8 +472,17 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
 // a non-blocking stream and an event per device, made on first use (small copies that should not queue behind a kernel)
 struct SideStream {
     hipStream_t st;
-    hipEvent_t ev;
+    hipEvent_t ev, ev2;
+    int32_t *pinned;      // 16 words of pinned host memory a kernel on `st` can store to (hipHostMalloc)
 };
+
+// the four list boundaries of the class scan -> pinned host memory, by a one-wavefront kernel on the side stream: a
+// hipMemcpyAsync into pageable memory waits for the kernel running on the default stream (measured: the four copies
+// started only when the class A kernel had finished, 73 us of idle card), a store from a kernel does not
+__global__ void row_list_bounds_kernel(const int32_t *__restrict__ counts, int64_t n_waves, int32_t *__restrict__ out)
+{
+    if (threadIdx.x < 4) out[threadIdx.x] = counts[(int64_t)threadIdx.x * n_waves];
+}
 static int side_stream(SideStream *out)
 {
     static std::mutex mu;
@@ -446,6 +494,8 @@ static int side_stream(SideStream *out)
     if (!per_dev[dev].st) {
         CSRK_HIP(hipStreamCreateWithFlags(&per_dev[dev].st, hipStreamNonBlocking));
         CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev, hipEventDisableTiming));
+        CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev2, hipEventDisableTiming));
+        CSRK_HIP(hipHostMalloc((void **)&per_dev[dev].pinned, 16 * sizeof(int32_t), hipHostMallocDefault));
     }
     *out = per_dev[dev];
     return CSRK_OK;
@@ -492,24 +542,47 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
     SideStream side;
     CSRK_TRY(side_stream(&side));
+    // declared after every DevBuf above: on ANY return the device drains (both streams) before the buffers go back to the pool
+    struct DrainOnExit {
+        ~DrainOnExit() { (void)hipDeviceSynchronize(); }
+    } drain_on_exit;
 #define GO(P, T)                                                                                                       \
     do {                                                                                                               \
         row_class_count_kernel<P><<<ga, 256>>>((const P *)m->d_rowptrs, m->nrows, n_waves, counts.as<int32_t>());       \
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_TRY(exclusive_scan_i32(counts.as<int32_t>(), counts.as<int32_t>(), 3 * n_waves, nullptr));                \
-        /* the list lengths come back on a side stream WHILE the class A kernel runs (behind it on the same stream the   \
-           card sat idle for the host's round trip: ~25 us of a 1.2-ms call) */                                        \
+        /* the list lengths come back on a side stream WHILE the class A kernel runs: that kernel is launched first, the   \
+           side stream waits only for the scan */                                                                      \
         CSRK_HIP(hipEventRecord(side.ev, nullptr));                                                                    \
-        CSRK_HIP(hipStreamWaitEvent(side.st, side.ev, 0));                                                             \
-        int32_t n_bc[4] = {0, 0, 0, 0};      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */         \
-        for (int c = 0; c < 4; c++)                                                                                    \
-            CSRK_HIP(hipMemcpyAsync(&n_bc[c], counts.as<int32_t>() + c * n_waves, 4, hipMemcpyDeviceToHost, side.st)); \
         row_stat_a_kernel<P, T, UNIT><<<ga, 256>>>((const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, m->nrows,       \
                                                    n_waves, counts.as<int32_t>(), list_b8.as<int32_t>(),               \
                                                    list_b.as<int32_t>(), list_c.as<int32_t>());                        \
         CSRK_LAUNCH_CHECK();                                                                                           \
+        CSRK_HIP(hipEventRecord(side.ev2, nullptr));      /* the lists exist */                                        \
+        CSRK_HIP(hipStreamWaitEvent(side.st, side.ev, 0));                                                             \
+        row_list_bounds_kernel<<<1, 64, 0, side.st>>>(counts.as<int32_t>(), n_waves, side.pinned);                     \
+        CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipStreamSynchronize(side.st));                                                                       \
+        int32_t n_bc[4];      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */                        \
+        for (int c = 0; c < 4; c++) n_bc[c] = ((volatile int32_t *)side.pinned)[c];                                    \
         const int32_t n_b8 = n_bc[1] - n_bc[0], n_b = n_bc[2] - n_bc[1], n_c = n_bc[3] - n_bc[2];                      \
+        /* the long rows' chunk tables (three small kernels, the card nearly idle under them) are built on the side     \
+           stream beside the class B kernels; every buffer they touch was allocated above */                           \
+        const int64_t n_chunks = (int64_t)n_c + m->nnz / RS_CHUNK;      /* at most one partial chunk per long row */     \
+        if (n_c > 0) {                                                                                                 \
+            const unsigned gc = (unsigned)ceil_div(n_c, 256);                                                          \
+            CSRK_HIP(hipStreamWaitEvent(side.st, side.ev2, 0));                                                        \
+            row_chunk_count_kernel<P><<<gc, 256, 0, side.st>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c,      \
+                                                               rc0.as<int32_t>());                                     \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            row_chunk_scan_kernel<<<1, 1024, 0, side.st>>>(rc0.as<int32_t>(), n_c);                                     \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            row_chunk_fill_kernel<P><<<gc, 256, 0, side.st>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c,       \
+                                                              rc0.as<int32_t>(), ck0.as<int64_t>(), clen.as<int32_t>(), \
+                                                              crow.as<int32_t>());                                     \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+            CSRK_HIP(hipEventRecord(side.ev, side.st));                                                                \
+        }                                                                                                              \
         if (n_b8 > 0) {                                                                                                \
             row_stat_b_kernel<P, T, UNIT, 8><<<(unsigned)ceil_div((int64_t)n_b8 * 8, 256), 256>>>(                     \
                 (const P *)m->d_rowptrs, (T *)m->d_values, (T *)out, list_b8.as<int32_t>(), n_b8);                      \
@@ -521,15 +594,7 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
             CSRK_LAUNCH_CHECK();                                                                                       \
         }                                                                                                              \
         if (n_c > 0) {                                                                                                 \
-            const unsigned gc = (unsigned)ceil_div(n_c, 256);                                                          \
-            row_chunk_count_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>()); \
-            CSRK_LAUNCH_CHECK();                                                                                       \
-            CSRK_TRY(exclusive_scan_i32(rc0.as<int32_t>(), rc0.as<int32_t>(), n_c, nullptr));                          \
-            /* at most one partial chunk per long row beyond the full ones: no host round trip for the exact count */ \
-            const int64_t n_chunks = (int64_t)n_c + m->nnz / RS_CHUNK;                                                 \
-            row_chunk_fill_kernel<P><<<gc, 256>>>((const P *)m->d_rowptrs, list_c.as<int32_t>(), n_c, rc0.as<int32_t>(), \
-                                                  ck0.as<int64_t>(), clen.as<int32_t>(), crow.as<int32_t>());           \
-            CSRK_LAUNCH_CHECK();                                                                                       \
+            CSRK_HIP(hipStreamWaitEvent(nullptr, side.ev, 0));      /* the chunk tables are ready */                   \
             row_stat_c1_kernel<T, UNIT><<<(unsigned)n_chunks, RS_THREADS>>>((T *)m->d_values, ck0.as<int64_t>(),        \
                                                                             clen.as<int32_t>(), crow.as<int32_t>(),     \
                                                                             rc0.as<int32_t>(), list_c.as<int32_t>(),    \
