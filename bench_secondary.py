@@ -202,6 +202,20 @@ def abt(dev, m=None, ra=2000, rb=20000, reps=3):
                   and torch.equal(o_vs[perm].view(torch.int64), g_vs.view(torch.int64)))
     abc = (ea + eb) * 12 + (ra + rb + 2) * 4 + nnzc.value * 12 + (ra + 1) * 4
     check(lib.csrk_free(c))
+    # the reference's own column order inside rows (reverse discovery, multiply.py:79-82, 94-97): row pointers, column
+    # indices and values bit for bit equal to the oracle's raw arrays, no sorting on either side
+    check(lib.csrk_spgemm_set_order(1))
+    try:
+        ms_ref, _ = _wall_ms(run, 2, warm=1)
+        c = run(keep=True)
+        check(lib.csrk_device_ptrs(c, C.byref(d_rp), C.byref(d_ci), C.byref(d_vs)))
+        r_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
+        r_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
+        ok_ref = bool(o_ci.numel() == nnzc.value and torch.equal(r_ci, o_ci.to(torch.int32))
+                      and torch.equal(r_vs.view(torch.int64), o_vs.view(torch.int64)))
+        check(lib.csrk_free(c))
+    finally:
+        check(lib.csrk_spgemm_set_order(-1))
     check(lib.csrk_free(ha))
     check(lib.csrk_free(hb))
     return {'config': f'mult_abt ({ra} x {nc}) x ({rb} x {nc})^T, rows of the MovieLens-25M-shaped matrix', 'entry': 'csrk_spgemm_abt',
@@ -209,7 +223,9 @@ def abt(dev, m=None, ra=2000, rb=20000, reps=3):
             'products_per_s': round(products / ms * 1e3, -6), 'gflops_2_per_product': round(2.0 * products / ms / 1e6, 1),
             'product_nnz': int(nnzc.value), 'bound': 'data-dependent (no roofline stated: DESIGN.md section 6)',
             'a_bt_c_bytes': int(abc), 'a_bt_c_gbs': round(abc / ms / 1e6, 1),
-            'parity': {'rowptrs_colsets_and_values_bit_exact_vs_oracle': ok, 'ok': ok},
+            'ms_reference_order': round(ms_ref, 3),
+            'parity': {'rowptrs_colsets_and_values_bit_exact_vs_oracle': ok,
+                       'reference_order_colinds_and_values_bit_exact_vs_oracle_raw': ok_ref, 'ok': bool(ok and ok_ref)},
             'cpu_baseline': {'value': round(2.0 * products / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'ms': round(t_cpu * 1e3, 1), 'cores': 1,
                              'kind': 'port', 'sample': 'the same block, one pass of orc_transpose + orc_mult_ab'}}
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     'csrk_spmv_profile_end4': (_int, [handle_t, C.POINTER(_int), C.POINTER(C.c_float)]),
     'csrk_spgemm_ab': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
+    'csrk_spgemm_set_order': (_int, [_int]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),
     'csrk_spmm_dense_device': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64, _vp]),
     'csrk_from_coo': (_int, [_i32, _i32, _i64, _vp, _vp, _vp, _int, C.POINTER(handle_t)]),

@@ -39,6 +39,8 @@
 namespace csrk {
 
 int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s);   // transpose.hip
+bool spgemm_reference_order_wanted();                                            // spgemm_order.hip
+int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c);
 
 struct MatView {
     const void *rp;
@@ -2003,7 +2005,16 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 {
     const bool fast = !a->ptr64 && !b->ptr64 && a->val_type == CSRK_VAL_F64 && b->val_type == CSRK_VAL_F64;
-    return fast ? spgemm_run<true>(a, b, out, b_rows_ascend) : spgemm_run<false>(a, b, out, b_rows_ascend);
+    CSRK_TRY(fast ? spgemm_run<true>(a, b, out, b_rows_ascend) : spgemm_run<false>(a, b, out, b_rows_ascend));
+    if (spgemm_reference_order_wanted()) {      // columns in the reference's reverse-discovery order (spgemm_order.hip)
+        const int rc = spgemm_apply_reference_order(a, b, *out);
+        if (rc != CSRK_OK) {
+            delete *out;
+            *out = nullptr;
+            return rc;
+        }
+    }
+    return CSRK_OK;
 }
 
 }  // namespace csrk

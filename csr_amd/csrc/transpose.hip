@@ -578,6 +578,17 @@ static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
                                      a->ncols, a->nrows, (P *)t->d_rowptrs, t->d_colinds, (double *)t->d_values, s);
 }
 
+// Stable sort of the int32 payloads by int32 keys in [0, key_range) -- the same radix passes, structure only.  Exposed to
+// spgemm_order.hip (the reference's output order of mult_ab).
+int stable_sort_payload_by_key(const int32_t *keys, const int32_t *payload, int64_t n, int32_t key_range,
+                               int64_t payload_range, int32_t *out_payload, hipStream_t s)
+{
+    DevBuf ptrs;
+    CSRK_TRY(ptrs.alloc((size_t)((int64_t)key_range + 1) * 8));
+    return sort_records<int64_t, CSRK_VAL_NONE, false>(keys, payload, nullptr, (const int64_t *)nullptr, 0, n, key_range,
+                                                       payload_range, ptrs.as<int64_t>(), out_payload, nullptr, s);
+}
+
 // Transpose `a` into a new matrix.  Exposed to the other translation units (spgemm_abt,
 // order_columns).
 int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s)

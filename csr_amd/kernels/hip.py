@@ -518,6 +518,16 @@ def mult_dense(h, B):
     return out
 
 
+def set_spgemm_order(order):
+    """
+    Column order inside the rows mult_ab / mult_abt return: 'ascending' (default), 'reference' -- reverse order of
+    first discovery, what csr/kernels/numba/multiply.py:79-82, 94-97 emit -- or None (follow CSRK_SPGEMM_ORDER).
+    Process-wide.  The values are the same bits either way.
+    """
+    code = {None: -1, 'ascending': 0, 'reference': 1}[order]
+    check(lib.csrk_spgemm_set_order(code))
+
+
 def set_spmv_algo(h, name):
     "select the SpMV kernel for this handle: 'auto' | 'merge' | 'vector' | 'scalar'"
     code = {'auto': _lib.SPMV_AUTO, 'merge': _lib.SPMV_MERGE, 'vector': _lib.SPMV_VECTOR,

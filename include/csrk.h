@@ -178,6 +178,12 @@ CSRK_API int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean
  * has more than INT32_MAX entries.                                                     */
 CSRK_API int csrk_spgemm_ab(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
 CSRK_API int csrk_spgemm_abt(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
+/* Column order inside the rows of a product: 0 = ascending (default: what the kernels emit), 1 = the reference's --
+ * _sym_mm pushes a newly discovered column onto the front of the row's list (csr/kernels/numba/multiply.py:79-82) and
+ * copies the list out front to back (:94-97): reverse order of first discovery --, -1 = follow the environment variable
+ * CSRK_SPGEMM_ORDER ("reference" selects 1).  Process-wide; values are the same bits either way.  The reference order
+ * costs a pass over the products and three stable sorts of the result (csrc/spgemm_order.hip). */
+CSRK_API int csrk_spgemm_set_order(int order);
 
 /* ---- dense-panel SpMM: C = A B, B dense row-major [ncols x k] --------------------------
  * Not a reference entry point (the reference's mult_ab is sparse x sparse only); serves

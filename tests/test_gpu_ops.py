@@ -291,6 +291,98 @@ def test_spgemm_vs_oracle(case):
         assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64))
 
 
+@pytest.fixture
+def reference_order():
+    "mult_ab / mult_abt emit the reference's column order inside rows for the duration of a test"
+    from csr_amd.kernels import hip as K
+    K.set_spgemm_order('reference')
+    yield K
+    K.set_spgemm_order(None)
+
+
+def test_spgemm_reference_order_golden(golden, reference_order):
+    """
+    _sym_mm emits each row's columns in REVERSE order of first discovery (csr/kernels/numba/multiply.py:79-82, 94-97).
+    With the reference order switched on, mult_ab returns the reference's own raw arrays: row pointers and column
+    indices bit for bit, values bit for bit wherever B's rows hold no column twice.
+    """
+    K = reference_order
+    g = golden('spgemm')
+    n_reordered = 0
+    for c in range(int(g['n'])):
+        A, B, raw = Mat(g, f'c{c}_a_'), Mat(g, f'c{c}_b_'), Mat(g, f'c{c}_raw_')
+        ah, bh = K.to_handle(_csr(A)), K.to_handle(_csr(B))
+        try:
+            ch = K.mult_ab(ah, bh)
+            C = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(ah)
+            K.release_handle(bh)
+        assert np.array_equal(C.rowptrs, raw.rowptrs) and np.array_equal(C.colinds, raw.colinds), c
+        sci, _ = sort_within_rows(raw.rowptrs, raw.colinds, raw.values)
+        n_reordered += int(not np.array_equal(sci, raw.colinds))
+        if _rows_hold_no_column_twice(B):
+            assert np.array_equal(C.values.view(np.int64), raw.values.view(np.int64)), c
+        else:
+            bound = 1e-6 * (np.abs(A.dense()) @ np.abs(B.dense())) + 1e-300
+            assert np.all(np.abs(C.values - raw.values) <= bound[np.repeat(np.arange(C.nrows), np.diff(C.rowptrs)), C.colinds]), c
+    assert n_reordered > 0            # the fixtures do hold rows whose reference order is not ascending
+
+
+@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'unsorted_b', 'abt_block'])
+def test_spgemm_reference_order_vs_oracle(case, reference_order):
+    "the same on products that take every accumulator path (hash, strips, expand-sort-compress), against the oracle's raw output"
+    from oracle import oracle as O
+    from csr_amd import CSR, synth
+    K = reference_order
+    rng = np.random.default_rng(abs(hash('ro' + case)) % 2**32)
+    abt = case == 'abt_block'
+    if case == 'sparse':
+        A = _rand(rng, 3000, 2000, rng.integers(0, 12, 3000), sort=True)
+        B = _rand(rng, 2000, 5000, rng.integers(0, 12, 2000), sort=True)
+    elif case == 'heavy_rows':
+        la = rng.integers(0, 8, 1500)
+        la[::50] = 400
+        A = _rand(rng, 1500, 1200, la)
+        lb = rng.integers(0, 30, 1200)
+        lb[::40] = 900
+        B = _rand(rng, 1200, 3000, lb)
+    elif case == 'unsorted_b':        # discovery order follows B's STORAGE order, not its columns
+        A = _rand(rng, 800, 600, rng.integers(0, 25, 800))
+        B = _rand(rng, 600, 900, rng.integers(0, 40, 600))
+    else:
+        m = synth.movielens_like(device='cpu')
+        M = CSR(m['nrows'], m['ncols'], int(m['colinds'].numel()), m['rowptrs'].numpy(), m['colinds'].numpy(),
+                m['values'].numpy(), _cast=False)
+        A, B = M.subset_rows(0, 600), M.subset_rows(0, 8000)
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        ch = K.mult_abt(ah, bh) if abt else K.mult_ab(ah, bh)
+        C = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    b = O.transpose(B.nrows, B.ncols, B.rowptrs, B.colinds, B.values) if abt else (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values)
+    _, _, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), b)
+    assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, cci)
+    assert not np.array_equal(sort_within_rows(crp, cci, cvs)[0], cci)
+    if abt or _rows_hold_no_column_twice(B):
+        assert np.array_equal(C.values.view(np.int64), cvs.view(np.int64))
+    # ascending again once the switch is off
+    K.set_spgemm_order('ascending')
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        ch = K.mult_abt(ah, bh) if abt else K.mult_ab(ah, bh)
+        C2 = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    assert np.array_equal(C2.colinds, sort_within_rows(crp, cci, cvs)[0])
+
+
 def test_mult_abt_movielens_shape_blocks():
     """
     BASELINE.json configs[4], the mult_abt half, on its own workload shape: row blocks of a MovieLens-25M-shaped

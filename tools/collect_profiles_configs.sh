@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats and FETCH/WRITE PMC passes for
-# tools/bench_configs.py (BASELINE configs[2] dense-panel SpMM, configs[4] transpose + A B^T).
+# tools/bench_configs.py (unit_rows on the headline matrix, BASELINE configs[2] dense-panel SpMM, configs[4] transpose + A B^T).
 # Output: gpurun_out/$1cfg/...   Summarise with tools/summarise_profiles_configs.py.
 set -u
 TAG=${1:-r01}
@@ -9,6 +9,8 @@ export PYTHONPATH=$GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}cfg
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
+# a plain run first: its JSON lines are profiles/${TAG}_configs.json (timings without the profiler attached)
+python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/write.log 2>&1

@@ -8,7 +8,11 @@ def newest(pattern):
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = f'gpurun_out/{tag}cfg'
-keep = ('csrk::spmm', 'csrk::mm_', 'csrk::rx_', 'csrk::rowptr_from', 'csrk::sg_')
+keep = ('csrk::spmm', 'csrk::mm_', 'csrk::rx_', 'csrk::rowptr_from', 'csrk::sg_', 'csrk::row_')
+with open(f'profiles/{tag}_configs.json', 'w') as f:      # the plain (unprofiled) run's lines
+    for ln in open(f'{src}/plain.log'):
+        if ln.startswith('{'):
+            f.write(ln)
 rows = list(csv.DictReader(open(newest(f'{src}/kt/*/*_kernel_stats.csv'))))
 with open(f'profiles/{tag}_configs_kernel_stats.csv', 'w', newline='') as f:
     w = csv.writer(f)
@@ -40,7 +44,7 @@ for d in ('mfma', 'tcp'):
             other.setdefault(k, {})[c] = round(v)
     except (ValueError, OSError):
         pass
-json.dump({'workload': 'tools/bench_configs.py all (configs[2] SpMM, configs[4] transpose + A B^T block)',
+json.dump({'workload': 'tools/bench_configs.py all (unit_rows on the headline matrix, configs[2] SpMM, configs[4] transpose + A B^T blocks, power-law A B)',
            'hbm_bytes_per_launch': {k: round(v) for k, v in sorted(traffic.items())},
            'counters_per_launch': other,
            'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace only; mean per launch; '
