@@ -336,7 +336,10 @@ def main():
             check(lib.csrk_spmv_profile_end4(hp, C.byref(n_w), k_w))
             k_warm, n_warm = [float(v) for v in k_w], n_w.value
             if n_warm > 0 and max(k_warm) > 0:
-                chan_mask = 1 << max(range(4), key=lambda c: k_warm[c])
+                stb = (C.c_int64 * 29)()
+                check(lib.csrk_spmv_plan_stats(hp, stb, 29))
+                cands = [c for c in range(4) if not (c == 2 and int(stb[28]))]      # (tier 1 beside tier 0: see `dom` below)
+                chan_mask = 1 << max(cands, key=lambda c: k_warm[c])
         if events:
             every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)
             check(lib.csrk_spmv_profile_channels(hp, chan_mask))
@@ -448,7 +451,13 @@ def main():
             traffic_all[k['kernel']] = tr
             k['traffic_gbs'] = round(tr / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
             k['traffic_over_algorithmic'] = round(tr / k['algorithmic_bytes'], 3) if k['algorithmic_bytes'] else None
-    dom = max(kernels, key=lambda k: k['ms'])
+    # the dominant kernel: the slowest one on the main stream.  A kernel that runs on the plan's side stream BESIDE another
+    # (tier 1's pair kernel next to the accumulator kernel) lasts as long as its neighbour lets it; its duration is
+    # reported, but it does not bound the step
+    for k in kernels:
+        if int(st[28]) and k['kernel'] == 'spmv_panel_kernel<tier1>':
+            k['runs_beside'] = 'spmv_acc_kernel'
+    dom = max((k for k in kernels if 'runs_beside' not in k), key=lambda k: k['ms'])
     k_sum_ms = sum(k['ms'] for k in kernels)
     frac_step = round(whole_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
     notes = []
@@ -597,6 +606,29 @@ def main():
             print(json.dumps(out))
             sys.exit('PARITY FAILURE: GPU result differs from the oracle')
 
+    if world == 1 and not distd:
+        # What a caller WITHOUT a kept handle gets (the reference makes one per product, csr/csr.py:580-583): the first
+        # product on a fresh handle runs the plan-less merge-path kernel over the CSR arrays as they are.  Timed here on a
+        # second handle over the same resident arrays (kernels already loaded), outside the timed region.
+        h2 = handle_t(0)
+        check(lib.csrk_create_device(n_loc, ncols, nnz_loc, rp.data_ptr(), int(rp.dtype == torch.int64),
+                                     ci.data_ptr(), vs.data_ptr(), 2, C.byref(h2)))
+        y2 = torch.empty(n_loc, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.csrk_spmv_device(h2.value, x.data_ptr(), y2.data_ptr(), None))
+        e1.record()
+        torch.cuda.synchronize()
+        pl_ms = e0.elapsed_time(e1)
+        check(lib.csrk_free(h2))
+        del y2
+        roofline['without_a_plan'] = {
+            'what': 'first product on a handle: spmv_merge_kernel on the raw CSR arrays, x gathered from HBM / L2',
+            'ms': round(pl_ms, 4), 'frac_whole_spmv': round(whole_bytes / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'plan_build_call_ms': None if plan_ms is None else round(plan_ms, 2), 'plan_bytes': int(st[25]),
+            'planned_products_to_amortise_the_plan': None if plan_ms is None or pl_ms <= ms_per_step else
+            int(np.ceil(plan_ms / (pl_ms - ms_per_step)))}
     for hc in op_handles:
         check(lib.csrk_free(hc))
     check(lib.csrk_free(h))
