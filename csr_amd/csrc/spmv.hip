@@ -2476,17 +2476,18 @@ static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
     int64_t nnz0 = 0;
     for (int64_t l : len0) nnz0 += l;
     const int64_t nnz1 = p->t1_nnz;
-    // The two tiers side by side.  The accumulator kernel is bound by HBM: with fewer workgroups than CUs it loses little
-    // (headline matrix: 256 workgroups 0.220 ms, 224: 0.218, 192: 0.232, 160: 0.265, 128: 0.316), while the pair kernel of
-    // tier 1 waits on L2 gathers and leaves HBM idle (0.096 ms for 19.5 M entries at 3.6 TB/s).  So the accumulator kernel
-    // gets W = 25/32 of the CUs as persistent workgroups -- each fills its CU's LDS, so nothing else lands there -- and
-    // the pair kernel, launched on a side stream of the plan's own, starts on the other CUs at the same time and takes the
-    // rest as they come free.  Measured (20-step runs as the driver launches them, several boxes): 0.522 ms against 0.533
-    // with W = 200 on every box; W = 160, where a cost model puts the two kernels' ends together, gave 0.500-0.506 on some
-    // boxes and 0.552-0.556 on others (the same on each box run after run; stream priorities and a head start for the
-    // accumulator kernel changed nothing), so the setting that never loses is the default.  CSRK_SPMV_T1_BESIDE=0 turns
-    // it off, =W forces W.  Results do not depend on the overlap; they do depend on W (the accumulator partials are per
-    // workgroup), which is fixed per plan.
+    // The two tiers side by side (OPT-IN: CSRK_SPMV_T1_BESIDE=1, or =W to force W).  The accumulator kernel is bound by HBM:
+    // with fewer workgroups than CUs it loses little (headline matrix: 256 workgroups 0.220 ms, 224: 0.218, 192: 0.232,
+    // 160: 0.265, 128: 0.316), while the pair kernel of tier 1 waits on L2 gathers and leaves HBM idle (0.096 ms for 19.5 M
+    // entries at 3.6 TB/s).  So the accumulator kernel gets W = 25/32 of the CUs as persistent workgroups -- each fills its
+    // CU's LDS, so nothing else lands there -- and the pair kernel, launched on a side stream of the plan's own, starts on
+    // the other CUs at the same time and takes the rest as they come free.  Measured (20-step runs as the driver launches
+    // them, ten boxes): 0.515-0.523 ms against 0.531-0.537 on seven of them, no gain on three (0.532-0.534: the same on
+    // each box run after run); W = 160 gave 0.500-0.506 on some boxes and 0.552-0.556 on others.  Nothing available makes
+    // the split exact (stream priorities, a head start for the accumulator kernel: no change; CU-masked streams slow
+    // every kernel down), and with two queues busy the event pairs around the accumulator kernel stop meaning its
+    // duration (0.43 ms reported inside a 0.533-ms step).  Hence off by default.  Results do not depend on the overlap;
+    // they do depend on W (the accumulator partials are per workgroup), which is fixed per plan.
     int64_t acc_wgs = 0;
     {
         const char *e = getenv("CSRK_SPMV_T1_BESIDE");
@@ -2494,7 +2495,7 @@ static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
         const bool t1_stream = t1env && !strcmp(t1env, "stream");
         int cus = 0;
         CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-        if (!(e && e[0] == '0') && acc_form && !t1_stream && !r0.empty() && !r1.empty() && r0.size() <= (size_t)ACC_MAXROWS &&
+        if (e && e[0] != '0' && acc_form && !t1_stream && !r0.empty() && !r1.empty() && r0.size() <= (size_t)ACC_MAXROWS &&
             cus >= 64) {
             // worth two more stream operations per product only when tier 1 is a real share of the tiers' work
             if ((double)nnz1 * 4.9 >= 0.08 * (double)nnz0 * 1.58) acc_wgs = (cus * 25 / 32) & ~7;
