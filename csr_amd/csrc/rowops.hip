@@ -55,6 +55,10 @@ constexpr int RS_B = WAVE * RS_K;   // class B, one wavefront per row (512)
 #define CSRK_RS_THREADS 512      // (class C1 alone on the headline matrix: 1024 threads 0.357 ms, 512 0.270, 256 0.278)
 #endif
 constexpr int RS_THREADS = CSRK_RS_THREADS;
+#ifndef CSRK_RS_C3_REVERSE
+#define CSRK_RS_C3_REVERSE 1
+#endif
+constexpr bool RS_C3_REVERSE = CSRK_RS_C3_REVERSE != 0;
 constexpr int RS_CHUNK = RS_THREADS * RS_K;      // class C: entries per chunk (4096)
 
 // (m, e) = frexp(vmax); pnexp = clamp(-e, minexp, maxexp - 1); prenorm = 2^pnexp (transform.py:55-58); a NaN or infinite
@@ -454,9 +458,11 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
                                                                 const int32_t *__restrict__ n_chunks)
 {
     if ((int32_t)blockIdx.x >= *n_chunks) return;
-    const int64_t k0 = chunk_k0[blockIdx.x];
-    const int len = chunk_len[blockIdx.x];
-    const int32_t i = chunk_row[blockIdx.x];
+    // last chunk first: what C1 read last is what the 256-MiB memory-side cache still holds
+    const int32_t cq = RS_C3_REVERSE ? *n_chunks - 1 - (int32_t)blockIdx.x : (int32_t)blockIdx.x;
+    const int64_t k0 = chunk_k0[cq];
+    const int len = chunk_len[cq];
+    const int32_t i = chunk_row[cq];
     if (row_chunk0[i + 1] - row_chunk0[i] == 1) return;      // (finished by C1)
     const T a = scale_a[i], b = UNIT ? scale_b[i] : (T)0;
 #pragma unroll

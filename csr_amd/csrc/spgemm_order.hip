@@ -89,7 +89,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_first_row_kernel(const PA *__re
         // row next to fifteen short ones costs every thread the same (a wavefront per entry: 26 ms on the block above,
         // the popular items' rows setting the pace of every batch)
         __shared__ int64_t s_bs[SO_BATCH];
-        __shared__ int32_t s_off[SO_BATCH + 1];
+        __shared__ int64_t s_off[SO_BATCH + 1];      // (32 B rows can hold more than 2^31 entries between them)
         for (int64_t e0 = a0; e0 < a1; e0 += SO_BATCH) {
             if (tid < SO_BATCH) {
                 const int64_t e = e0 + tid;
@@ -101,22 +101,22 @@ __global__ __launch_bounds__(SO_THREADS) void so_first_row_kernel(const PA *__re
                 }
                 s_bs[tid] = bs;
                 // inclusive scan of the lengths over the first SO_BATCH lanes (SO_BATCH <= WAVE)
-                int32_t inc = (int32_t)len;
+                int64_t inc = len;
 #pragma unroll
                 for (int off = 1; off < SO_BATCH; off <<= 1) {
-                    const int32_t o = __shfl_up(inc, off, WAVE);
+                    const int64_t o = __shfl_up(inc, off, WAVE);
                     if (tid >= off) inc += o;
                 }
                 s_off[tid + 1] = inc;
                 if (tid == 0) s_off[0] = 0;
             }
             __syncthreads();
-            const int32_t total = s_off[SO_BATCH];
-            for (int32_t pidx = tid; pidx < total; pidx += SO_THREADS) {
+            const int64_t total = s_off[SO_BATCH];
+            for (int64_t pidx = tid; pidx < total; pidx += SO_THREADS) {
                 int q = 0;                               // entry of the batch this product belongs to
 #pragma unroll
                 for (int u = 1; u < SO_BATCH; u++) q += s_off[u] <= pidx;
-                const int32_t tb = pidx - s_off[q];
+                const int32_t tb = (int32_t)(pidx - s_off[q]);
                 const int32_t k = b_ci[s_bs[q] + tb];
                 int32_t lo = 0, hi = nc;                 // first position with column >= k
                 while (lo < hi) {
