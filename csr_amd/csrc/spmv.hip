@@ -627,6 +627,36 @@ __global__ __launch_bounds__(256) void hot_census_kernel(const int32_t *__restri
     }
 }
 
+// The whole census in one pass: hist[v] = {#columns with count == v, sum of their counts} for v < HOT_HIST (counts at or
+// above it share the last bin), so that the host finds the threshold for any slot budget from ONE copy instead of a
+// binary search of ~27 launches and round trips (2.5 ms of the headline matrix's plan).  Small counts -- nearly all
+// columns -- go through an LDS histogram.
+constexpr int HOT_HIST = 65536, HOT_HIST_LDS = 2048;
+__global__ __launch_bounds__(256) void hot_hist_kernel(const int32_t *__restrict__ cnt, int32_t ncols,
+                                                      unsigned long long *__restrict__ hist_n,
+                                                      unsigned long long *__restrict__ hist_sum)
+{
+    __shared__ unsigned int s_n[HOT_HIST_LDS];
+    for (int k = threadIdx.x; k < HOT_HIST_LDS; k += 256) s_n[k] = 0u;
+    __syncthreads();
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * 256) {
+        const int32_t v = cnt[c];
+        if (v < HOT_HIST_LDS) {
+            atomicAdd(&s_n[v], 1u);
+        } else {
+            const int b = v < HOT_HIST ? v : HOT_HIST;
+            atomicAdd(&hist_n[b], 1ull);
+            atomicAdd(&hist_sum[b], (unsigned long long)v);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < HOT_HIST_LDS; k += 256)
+        if (s_n[k]) {
+            atomicAdd(&hist_n[k], (unsigned long long)s_n[k]);
+            atomicAdd(&hist_sum[k], (unsigned long long)s_n[k] * (unsigned long long)k);
+        }
+}
+
 __global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr, int32_t *__restrict__ flag)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -711,8 +741,22 @@ __global__ void heavy_sorted_kernel(const P *__restrict__ rp, const int32_t *__r
     if (c >= n_heavy) return;
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
+    // (a 10^6-entry row is one workgroup's: 1024 threads with four comparisons in flight each; 256 threads one at a time
+    // made this check 1.8 ms of the headline matrix's plan)
     bool b = false;
-    for (int64_t k = s + threadIdx.x; k + 1 < e; k += blockDim.x) b |= ci[k] > ci[k + 1];
+    const int64_t step = (int64_t)blockDim.x * 4;
+    for (int64_t k0 = s + threadIdx.x; k0 + 1 < e; k0 += step) {
+        int32_t a[4], n[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t k = k0 + (int64_t)u * blockDim.x;
+            const bool in = k + 1 < e;
+            a[u] = in ? ci[k] : 0;
+            n[u] = in ? ci[k + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) b |= a[u] > n[u];
+    }
     if (b) atomicOr(bad, 1);
 }
 
@@ -2398,7 +2442,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(bad.alloc(4));
     CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, s));
-    heavy_sorted_kernel<P><<<(unsigned)n_cut, 256, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_cut,
+    heavy_sorted_kernel<P><<<(unsigned)n_cut, 1024, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_cut,
                                                          bad.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     int32_t is_bad = 0;
@@ -2583,8 +2627,38 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     };
     unsigned long long c[2];
     int64_t lo = 2, hi = n_samples + 1;     // invariant: census(hi).n <= HOT_SLOTS
-    CSRK_TRY(census_at((int32_t)lo, c));
-    if (c[0] > (unsigned long long)HOT_SLOTS) {
+    // one histogram pass decides it unless more than HOT_SLOTS columns sit in the shared top bin (then: the search below)
+    bool decided = false;
+    {
+        DevBuf hist;
+        CSRK_TRY(hist.alloc((size_t)2 * (HOT_HIST + 1) * 8));
+        CSRK_HIP(hipMemsetAsync(hist.p, 0, (size_t)2 * (HOT_HIST + 1) * 8, s));
+        hot_hist_kernel<<<1024, 256, 0, s>>>(cnt.as<int32_t>(), nc, hist.as<unsigned long long>(),
+                                             hist.as<unsigned long long>() + (HOT_HIST + 1));
+        CSRK_LAUNCH_CHECK();
+        std::vector<unsigned long long> hh((size_t)2 * (HOT_HIST + 1));
+        CSRK_HIP(hipMemcpyAsync(hh.data(), hist.p, hh.size() * 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        const unsigned long long *hn = hh.data(), *hs = hh.data() + (HOT_HIST + 1);
+        if (hn[HOT_HIST] <= (unsigned long long)HOT_SLOTS) {
+            unsigned long long n_ge = 0, s_ge = 0;      // columns / references with count >= v
+            int64_t thr0 = HOT_HIST;                     // smallest threshold >= 2 that leaves at most HOT_SLOTS columns
+            n_ge = hn[HOT_HIST];
+            s_ge = hs[HOT_HIST];
+            for (int64_t v = HOT_HIST - 1; v >= 2; v--) {
+                if (n_ge + hn[v] > (unsigned long long)HOT_SLOTS) break;
+                n_ge += hn[v];
+                s_ge += hs[v];
+                thr0 = v;
+            }
+            lo = thr0;
+            c[0] = n_ge;
+            c[1] = s_ge;
+            decided = true;
+        }
+    }
+    if (!decided) CSRK_TRY(census_at((int32_t)lo, c));
+    if (!decided && c[0] > (unsigned long long)HOT_SLOTS) {
         while (lo + 1 < hi) {
             const int64_t mid = lo + (hi - lo) / 2;
             CSRK_TRY(census_at((int32_t)(mid > INT32_MAX ? INT32_MAX : mid), c));
