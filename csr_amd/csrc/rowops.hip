@@ -21,6 +21,8 @@
 // HBM traffic: values 1 read + 1 write (A, B), 2 reads + 1 write (C); row pointers once; norms once.
 #include "common.h"
 
+#include <atomic>
+
 namespace csrk {
 
 int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s);   // transpose.hip
@@ -475,11 +477,14 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
     }
 }
 
+constexpr int RS_PIN_SLOTS = 256;
+static std::atomic<unsigned> g_pin_next{0};
 // a non-blocking stream and an event per device, made on first use (small copies that should not queue behind a kernel)
 struct SideStream {
     hipStream_t st;
     hipEvent_t ev, ev2;
-    int32_t *pinned;      // 16 words of pinned host memory a kernel on `st` can store to (hipHostMalloc)
+    int32_t *pinned;      // RS_PIN_SLOTS x 4 words of pinned host memory a kernel on `st` can store to (hipHostMalloc); a call
+                          // takes the next slot, so calls on different handles (threads) never read each other's lengths
 };
 
 // the four list boundaries of the class scan -> pinned host memory, by a one-wavefront kernel on the side stream: a
@@ -501,7 +506,7 @@ static int side_stream(SideStream *out)
         CSRK_HIP(hipStreamCreateWithFlags(&per_dev[dev].st, hipStreamNonBlocking));
         CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev, hipEventDisableTiming));
         CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev2, hipEventDisableTiming));
-        CSRK_HIP(hipHostMalloc((void **)&per_dev[dev].pinned, 16 * sizeof(int32_t), hipHostMallocDefault));
+        CSRK_HIP(hipHostMalloc((void **)&per_dev[dev].pinned, RS_PIN_SLOTS * 4 * sizeof(int32_t), hipHostMallocDefault));
     }
     *out = per_dev[dev];
     return CSRK_OK;
@@ -548,6 +553,10 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
     SideStream side;
     CSRK_TRY(side_stream(&side));
+    // The side stream and its two events are the device's, not this call's: calls from several threads (different
+    // handles) take turns.  Nothing is lost: every call ends by draining the device.
+    static std::mutex side_mu;
+    std::lock_guard<std::mutex> side_lk(side_mu);
     // declared after every DevBuf above: on ANY return the device drains (both streams) before the buffers go back to the pool
     struct DrainOnExit {
         ~DrainOnExit() { (void)hipDeviceSynchronize(); }
@@ -566,11 +575,12 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipEventRecord(side.ev2, nullptr));      /* the lists exist */                                        \
         CSRK_HIP(hipStreamWaitEvent(side.st, side.ev, 0));                                                             \
-        row_list_bounds_kernel<<<1, 64, 0, side.st>>>(counts.as<int32_t>(), n_waves, side.pinned);                     \
+        int32_t *pin = side.pinned + (size_t)(g_pin_next.fetch_add(1) % RS_PIN_SLOTS) * 4;                              \
+        row_list_bounds_kernel<<<1, 64, 0, side.st>>>(counts.as<int32_t>(), n_waves, pin);                             \
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipStreamSynchronize(side.st));                                                                       \
         int32_t n_bc[4];      /* list starts in the scan: [0], [n_waves], [2 n_waves], total */                        \
-        for (int c = 0; c < 4; c++) n_bc[c] = ((volatile int32_t *)side.pinned)[c];                                    \
+        for (int c = 0; c < 4; c++) n_bc[c] = ((volatile int32_t *)pin)[c];                                            \
         const int32_t n_b8 = n_bc[1] - n_bc[0], n_b = n_bc[2] - n_bc[1], n_c = n_bc[3] - n_bc[2];                      \
         /* the long rows' chunk tables (three small kernels, the card nearly idle under them) are built on the side     \
            stream beside the class B kernels; every buffer they touch was allocated above */                           \

@@ -881,3 +881,48 @@ def test_spgemm_unsorted_b_rows():
     rci, rvs = sort_within_rows(crp, cci, cvs)
     assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, rci)
     assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64))
+
+
+def test_row_ops_from_several_threads():
+    """
+    The kernels are nogil in the reference (csr/transform.py runs under @njit(nogil=True) callers) and ctypes releases the
+    GIL: unit_rows / center_rows on DIFFERENT handles from several threads at once.  Inside the library the calls share
+    one side stream, two events and the pinned words the list lengths come back through: every thread must get exactly what
+    it gets alone.
+    """
+    import threading
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(77)
+    mats = []
+    for t in range(6):
+        lens = rng.integers(0, 40, 30000 + 1000 * t)
+        lens[::97] = 700 + 50 * t              # class B / C rows
+        lens[5 + t] = 9000 + 4096 * t          # rows of several chunks
+        mats.append(_rand(rng, len(lens), 5000, lens))
+
+    def run(A, op):
+        h = K.to_handle(A)
+        try:
+            stat = (K.unit_rows if op == 'unit' else K.center_rows)(h)
+            return stat, K.values_of(h)
+        finally:
+            K.release_handle(h)
+    ops = ['unit', 'center', 'unit', 'center', 'unit', 'center']
+    alone = [run(A, op) for A, op in zip(mats, ops)]
+    for _ in range(3):
+        got = [None] * len(mats)
+        errs = []
+
+        def work(i):
+            try:
+                got[i] = run(mats[i], ops[i])
+            except Exception as e:          # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(mats))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for (s0, v0), (s1, v1) in zip(alone, got):
+            assert np.array_equal(s0, s1, equal_nan=True) and np.array_equal(v0, v1, equal_nan=True)
