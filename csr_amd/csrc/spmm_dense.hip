@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace csrk {
@@ -56,13 +57,22 @@ struct SpmmPlan {
     DevBuf seg;                // SegDesc[n_segs]
     DevBuf part;               // double[n_segs * k] (allocated on demand)
     int32_t part_k = 0;
+    // opt-in (CSRK_SPMM_HOT=1): light rows with the hottest B rows resident in LDS (spmm_lseg_kernel) -- the columns the
+    // light rows reference most, by popularity; the first n_hot of them (as many B rows as 128 KiB of LDS hold at the
+    // panel width) are LDS slots, and ci_hot is a private copy of colinds in which an entry on slot s is stored as ~s
+    std::vector<int32_t> hot_sorted;
+    DevBuf hot_cols;           // int32[n_hot]
+    DevBuf ci_hot;             // int32[nnz]
+    int32_t n_hot = 0;         // slots ci_hot was encoded for (0: not built)
+    bool hot_tried = false;
 };
 
 void free_spmm_plan(SpmmPlan *p) { delete p; }
 int64_t spmm_plan_bytes(const SpmmPlan *p)
 {
     int64_t b = 0;
-    for (const DevBuf *d : {&p->slice, &p->slice_first, &p->hpart, &p->part_off, &p->split_rows, &p->seg_off, &p->seg, &p->part})
+    for (const DevBuf *d : {&p->slice, &p->slice_first, &p->hpart, &p->part_off, &p->split_rows, &p->seg_off, &p->seg, &p->part,
+                            &p->hot_cols, &p->ci_hot})
         b += (int64_t)d->bytes;
     return b;
 }
@@ -324,6 +334,144 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const int32_t *__restrict
     }
 }
 
+// ---- opt-in: light rows with the hottest B rows resident in LDS (north_star's "B tile staged in LDS") -----------------
+// CSRK_SPMM_HOT=1.  Column popularity is as skewed as row length: on the BASELINE matrix the light rows put 29 % of their
+// entries on the 256 most referenced columns.  One persistent 1024-thread workgroup per CU copies the n_hot most referenced
+// B rows into LDS once (128 KiB: 256 rows at k = 64) and an entry on such a column reads its B row from there; the plan's
+// private column array marks those entries (~slot), the padding lanes of a batch read slot 0 instead of B row 0.  Lane
+// `sub` of a 16-lane unit owns panel columns {2 sub, 2 sub + 1} and {32 + 2 sub, 33 + 2 sub} of a 64-column chunk: each of
+// its two 16-B loads then covers, with its 15 neighbours, 256 contiguous bytes -- all 64 LDS banks once -- so the lane
+// groups ds_read_b128 is served in (which mix lanes of two units, i.e. two different rows) never clash when the row
+// stride is a multiple of 256 B.  Sums in storage order, as in spmm_seg_kernel: same bits.
+// MEASURED AND NOT THE DEFAULT: 1.61 ms against spmm_seg_kernel's 1.34 on the BASELINE matrix -- the
+// rows it serves from LDS were L2 hits before, the cheapest line fills, and the persistent form runs 16 wavefronts per CU
+// where the plain one runs 28.
+constexpr int MM_L_THREADS = 1024;
+constexpr int MM_L_UNITS = MM_L_THREADS / MM_G;
+constexpr int MM_LDS_BYTES = 128 * 1024;
+constexpr int MM_HOT_MAX = 8192;           // columns ranked at plan time (k = 2 fills the LDS budget with 8192 rows)
+
+template <int VT>
+__device__ __forceinline__ void mm_unit_h(const int32_t *__restrict__ ci, const void *__restrict__ vs, int64_t s, int n,
+                                          int nmax, const double *__restrict__ B, int64_t ldb,
+                                          const double *__restrict__ hotB, int32_t k, int32_t ca, int32_t cb, bool va,
+                                          bool vb, int sub, double acc[4])
+{
+    for (int base = 0; base < nmax; base += MM_G) {
+        const int idx = base + sub;
+        const int32_t mycol = idx < n ? ci[s + idx] : -1;              // padding: LDS slot 0
+        const double myval = idx < n ? mm_val<VT>(vs, s + idx) : 0.0;
+        const int nb = nmax - base < MM_G ? nmax - base : MM_G;
+        for (int j = 0; j < nb; j += MM_UNROLL) {
+            mm_f64x2 ta[MM_UNROLL], tb[MM_UNROLL];
+            double av[MM_UNROLL];
+            int32_t w[MM_UNROLL];
+            // the LDS reads first (short latency), then the global loads of the other entries into the SAME registers:
+            // a global load with the hot lanes masked off leaves their LDS values in place, and the only wait between
+            // the two groups is for the LDS.  (Either source chosen in one if / else per entry made the compiler wait for
+            // every global load before the next entry's LDS read -- same destination registers, different return
+            // queues: 2.08 ms instead of 1.61.)
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                w[u] = __shfl(mycol, j + u, MM_G);
+                av[u] = __shfl(myval, j + u, MM_G);
+                ta[u] = mm_f64x2{0.0, 0.0};
+                tb[u] = mm_f64x2{0.0, 0.0};
+                if (w[u] < 0) {
+                    const double *p = hotB + (int64_t)(~w[u]) * k;
+                    if (va) ta[u] = *(const mm_f64x2 *)(p + ca);
+                    if (vb) tb[u] = *(const mm_f64x2 *)(p + cb);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                if (w[u] >= 0) {
+                    const double *p = B + (int64_t)w[u] * ldb;
+                    if (va) ta[u] = *(const MMF64x2 *)(p + ca);
+                    if (vb) tb[u] = *(const MMF64x2 *)(p + cb);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                const bool ok = base + j + u < n;
+                const double t0 = av[u] * ta[u].x, t1 = av[u] * ta[u].y, t2 = av[u] * tb[u].x, t3 = av[u] * tb[u].y;
+                acc[0] += ok ? t0 : 0.0;                                // masked after the multiply (0 * inf)
+                acc[1] += ok ? t1 : 0.0;
+                acc[2] += ok ? t2 : 0.0;
+                acc[3] += ok ? t3 : 0.0;
+            }
+        }
+    }
+}
+
+// k even.  Dynamic LDS: n_hot * k doubles.
+template <int VT>
+__global__ __launch_bounds__(MM_L_THREADS) void spmm_lseg_kernel(const int32_t *__restrict__ ci_hot, const void *__restrict__ vs,
+                                                                const double *__restrict__ B, int32_t k, int64_t ldb,
+                                                                double *__restrict__ C, int64_t ldc,
+                                                                const SegDesc *__restrict__ seg, int64_t n_segs,
+                                                                double *__restrict__ part,
+                                                                const int32_t *__restrict__ hot_cols, int32_t n_hot)
+{
+    extern __shared__ __align__(16) double mm_hotB[];
+    const int32_t k2 = k / 2;
+    for (int32_t i = threadIdx.x; i < n_hot * k2; i += MM_L_THREADS) {
+        const int32_t r = i / k2, c = (i - r * k2) * 2;
+        *(mm_f64x2 *)(mm_hotB + (int64_t)r * k + c) = *(const MMF64x2 *)(B + (int64_t)hot_cols[r] * ldb + c);
+    }
+    __syncthreads();
+    const int unit = threadIdx.x / MM_G, sub = threadIdx.x & (MM_G - 1);
+    const int64_t stride = (int64_t)gridDim.x * MM_L_UNITS;
+    // a wavefront's four units take four consecutive segments: the trip count is uniform inside the wavefront
+    for (int64_t q0 = (int64_t)blockIdx.x * MM_L_UNITS + (unit & ~3); q0 < n_segs; q0 += stride) {
+        const int64_t q = q0 + (unit & 3);
+        SegDesc d;
+        d.start = 0, d.n = 0, d.row = 0, d.part = -1;
+        if (q < n_segs) d = seg[q];
+        const int nmax = mm_wave_max4(d.n);
+        double *dst = d.part < 0 ? C + (int64_t)d.row * ldc : part + d.part * (int64_t)k;
+        for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
+            const int32_t ca = c0 + 2 * sub, cb = c0 + 32 + 2 * sub;
+            const bool va = ca < k, vb = cb < k;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            mm_unit_h<VT>(ci_hot, vs, d.start, d.n, nmax, B, ldb, mm_hotB, k, ca, cb, va, vb, sub, acc);
+            if (q < n_segs) {
+                if (va) __builtin_nontemporal_store(mm_f64x2{acc[0], acc[1]}, (MMF64x2 *)(dst + ca));
+                if (vb) __builtin_nontemporal_store(mm_f64x2{acc[2], acc[3]}, (MMF64x2 *)(dst + cb));
+            }
+        }
+    }
+}
+
+// plan time: how often the light rows reference each column (sampled rows; rows the heavy kernels serve are skipped)
+template <class P>
+__global__ void mm_col_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, int32_t nrows,
+                                    int64_t row_stride, int32_t heavy_min, int32_t *__restrict__ cnt)
+{
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MM_G;
+    const int sub = threadIdx.x & (MM_G - 1);
+    const int64_t r = q * row_stride;
+    if (r >= nrows) return;
+    const int64_t s = rp[r], e = rp[r + 1];
+    if (heavy_min > 0 && e - s >= heavy_min) return;
+    for (int64_t i = s + sub; i < e; i += MM_G) atomicAdd(&cnt[ci[i]], 1);
+}
+
+__global__ void mm_slot_scatter_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t *__restrict__ slot_of)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_hot) slot_of[hot_cols[i]] = i;
+}
+
+__global__ void mm_encode_hot_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ slot_of,
+                                     int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    const int32_t c = ci[i], sl = slot_of[c];
+    out[i] = sl >= 0 ? ~sl : c;
+}
+
 __global__ void mm_list_split_kernel(const int64_t *__restrict__ seg_off, int32_t nrows, int32_t *__restrict__ list,
                                      int32_t *__restrict__ n_list)
 {
@@ -452,6 +600,55 @@ static int build_heavy_slices(Matrix *m, SpmmPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
+// the columns the light rows reference most, by popularity (plan time: a sampled count on the device, the ranking of
+// the few thousand candidates on the host)
+static int build_hot_columns(Matrix *m, SpmmPlan *p)
+{
+    p->hot_tried = true;
+    if (m->ncols <= 0 || m->nnz <= 0 || p->n_segs == 0) return CSRK_OK;
+    DevBuf cnt;
+    CSRK_TRY(cnt.alloc((size_t)m->ncols * 4));
+    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)m->ncols * 4, nullptr));
+    const int64_t row_stride = m->nnz > (1ll << 25) ? m->nnz >> 25 : 1;
+    const int64_t units = ceil_div((int64_t)m->nrows, row_stride);
+    const unsigned g = (unsigned)ceil_div(units * MM_G, 256);
+    const int32_t hmin = p->heavy.on ? p->heavy.min_entries : 0;
+    if (m->ptr64)
+        mm_col_count_kernel<int64_t><<<g, 256>>>((const int64_t *)m->d_rowptrs, m->d_colinds, m->nrows, row_stride, hmin, cnt.as<int32_t>());
+    else
+        mm_col_count_kernel<int32_t><<<g, 256>>>((const int32_t *)m->d_rowptrs, m->d_colinds, m->nrows, row_stride, hmin, cnt.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    std::vector<int32_t> c((size_t)m->ncols);
+    CSRK_HIP(hipMemcpy(c.data(), cnt.p, (size_t)m->ncols * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> cand;
+    for (int32_t j = 0; j < m->ncols; j++)
+        if (c[(size_t)j] >= 2) cand.push_back(j);
+    const size_t keep = std::min(cand.size(), (size_t)MM_HOT_MAX);
+    auto hotter = [&](int32_t a, int32_t b) { return c[(size_t)a] != c[(size_t)b] ? c[(size_t)a] > c[(size_t)b] : a < b; };
+    std::partial_sort(cand.begin(), cand.begin() + (std::ptrdiff_t)keep, cand.end(), hotter);
+    cand.resize(keep);
+    p->hot_sorted = std::move(cand);
+    return CSRK_OK;
+}
+
+static int encode_hot_columns(Matrix *m, SpmmPlan *p, int32_t n_hot)
+{
+    DevBuf slot_of;
+    CSRK_TRY(slot_of.alloc((size_t)m->ncols * 4));
+    CSRK_HIP(hipMemsetAsync(slot_of.p, 0xff, (size_t)m->ncols * 4, nullptr));
+    CSRK_HIP(hipDeviceSynchronize());      // earlier launches (any stream) may still read the old tables
+    CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
+    CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, p->hot_sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, nullptr));
+    if (!p->ci_hot.p) CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
+    mm_slot_scatter_kernel<<<(unsigned)ceil_div(n_hot, 256), 256>>>(p->hot_cols.as<int32_t>(), n_hot, slot_of.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    mm_encode_hot_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256>>>(m->d_colinds, m->nnz, slot_of.as<int32_t>(), p->ci_hot.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipDeviceSynchronize());      // slot_of is released here; the product may run on another stream
+    p->n_hot = n_hot;
+    return CSRK_OK;
+}
+
 static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, double *dC, int64_t ldc, hipStream_t s)
 {
     CSRK_REQUIRE(k >= 0 && ldb >= k && ldc >= k, "bad panel geometry k=%d ldb=%lld ldc=%lld", k, (long long)ldb, (long long)ldc);
@@ -517,6 +714,41 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
         CSRK_LAUNCH_CHECK();
     }
     if (p->n_segs == 0) return CSRK_OK;
+    // opt-in (CSRK_SPMM_HOT=1; k even, >= 16 B rows fit 128 KiB): the light rows with the hottest B rows in LDS
+    int32_t want_hot = 0;
+    {
+        const char *env = getenv("CSRK_SPMM_HOT");
+        if (env && env[0] == '1' && k % 2 == 0 && (int64_t)k * 8 * 16 <= MM_LDS_BYTES) {
+            if (!p->hot_tried) CSRK_TRY(build_hot_columns(m, p));
+            want_hot = (int32_t)std::min<int64_t>((int64_t)p->hot_sorted.size(), MM_LDS_BYTES / ((int64_t)k * 8));
+            if (want_hot < 16) want_hot = 0;
+            if (want_hot && p->n_hot != want_hot) CSRK_TRY(encode_hot_columns(m, p, want_hot));
+        }
+    }
+    if (want_hot) {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            for (const void *f : {(const void *)spmm_lseg_kernel<CSRK_VAL_F64>, (const void *)spmm_lseg_kernel<CSRK_VAL_F32>,
+                                  (const void *)spmm_lseg_kernel<CSRK_VAL_NONE>}) {
+                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS_BYTES);
+                if (e != hipSuccess) attr_err = e;
+            }
+        });
+        CSRK_HIP(attr_err);
+        int cus = 0;
+        CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+        const unsigned lgrid = (unsigned)std::min<int64_t>(cus > 0 ? cus : 256, ceil_div(p->n_segs, MM_L_UNITS));
+        const size_t lds = (size_t)want_hot * k * 8;
+#define GOH(VT)                                                                                                        \
+    spmm_lseg_kernel<VT><<<lgrid, MM_L_THREADS, lds, s>>>(p->ci_hot.as<int32_t>(), m->d_values, dB, k, ldb, dC, ldc,     \
+                                                         p->seg.as<SegDesc>(), p->n_segs, p->part.as<double>(),        \
+                                                         p->hot_cols.as<int32_t>(), want_hot)
+        if (m->val_type == CSRK_VAL_F64) GOH(CSRK_VAL_F64);
+        else if (m->val_type == CSRK_VAL_F32) GOH(CSRK_VAL_F32);
+        else GOH(CSRK_VAL_NONE);
+#undef GOH
+    } else {
     const unsigned grid = (unsigned)ceil_div(p->n_segs * MM_G, 256);
 #define GO(VT, F4)                                                                                                     \
     spmm_seg_kernel<VT, F4><<<grid, 256, 0, s>>>(m->d_colinds, m->d_values, dB, k, ldb, dC, ldc, p->seg.as<SegDesc>(),   \
@@ -532,6 +764,7 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
         else GO(CSRK_VAL_NONE, false);
     }
 #undef GO
+    }
     CSRK_LAUNCH_CHECK();
     if (p->n_multi > 0) {
         spmm_fixup_kernel<<<(unsigned)ceil_div((int64_t)p->n_split * WAVE, 256), 256, 0, s>>>(

@@ -694,6 +694,49 @@ def test_spmm_dense(k):
     assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
 
 
+@pytest.mark.parametrize('k,dtype', [(64, np.float64), (6, np.float64), (130, np.float32), (512, np.float64)])
+def test_spmm_dense_hot_rows_in_lds(k, dtype, monkeypatch):
+    """
+    CSRK_SPMM_HOT=1 (north_star's "dense B tile staged in LDS"): the light rows' most referenced B rows
+    are held in LDS by a persistent kernel.  Same sums in the same order as the default kernel: the panel must come out
+    bit for bit equal to it (and to the oracle within the usual bound), for panel widths that fill a 64-column chunk,
+    fall short of it, exceed it, and leave only 32 LDS rows.
+    """
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(1000 + k)
+    n, ncols = 20000, 9000
+    lens = np.minimum((rng.pareto(1.0, n) * 4).astype(np.int64), 3000)
+    # a popular set of columns, so that LDS slots are worth having: Zipf-like column choice, distinct inside a row
+    pop = rng.permutation(ncols)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.empty(int(rp[-1]), np.int32)
+    for i in range(n):
+        m = int(lens[i])
+        if m:
+            draw = np.unique(np.minimum((np.exp(rng.uniform(0, np.log(ncols), size=2 * m + 8)) - 1).astype(np.int64), ncols - 1))
+            draw = draw[:m] if len(draw) >= m else np.concatenate([draw, np.setdiff1d(np.arange(ncols), draw)[:m - len(draw)]])
+            ci[rp[i]:rp[i + 1]] = np.sort(pop[draw])
+    from csr_amd import CSR
+    A = CSR(n, ncols, int(rp[-1]), rp, ci, rng.uniform(-1, 1, int(rp[-1])).astype(dtype), _cast=False)
+    B = rng.uniform(-1, 1, (ncols, k))
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('CSRK_SPMM_HOT', mode)
+        h = K.to_handle(A)
+        try:
+            outs[mode] = K.mult_dense(h, B)
+            again = K.mult_dense(h, B)
+        finally:
+            K.release_handle(h)
+        assert np.array_equal(outs[mode], again)
+    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, A.values, B)
+    bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
+    assert np.all(np.abs(outs['1'] - ref) <= 1e-12 * bound + 1e-300)
+    assert np.array_equal(outs['1'].view(np.int64), outs['0'].view(np.int64))
+
+
 # ---- COO ingest on the device ----------------------------------------------------------------------------
 
 def test_from_coo_golden(golden):
