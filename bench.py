@@ -635,11 +635,15 @@ def main():
     if world == 1 and not distd and not args.no_secondary and args.scale == 1.0:
         # the other BASELINE configs, AFTER the SpMV has been timed and checked (nothing above depends on this):
         # each entry carries ms, algorithmic bytes, frac of 8 TB/s, a parity flag and the oracle's time on a stated sample
-        import bench_secondary
-        del y
-        check(lib.csrk_trim_cache())
-        out['secondary'] = bench_secondary.run_all(dev, headline=(rp, ci, vs, nrows, ncols),
-                                                   log=lambda m: print(m, file=sys.stderr, flush=True))
+        # (a Python error anywhere in here must not cost the line that has been timed and verified above)
+        try:
+            import bench_secondary
+            del y
+            check(lib.csrk_trim_cache())
+            out['secondary'] = bench_secondary.run_all(dev, headline=(rp, ci, vs, nrows, ncols), product_ms=ms_per_step,
+                                                       log=lambda m: print(m, file=sys.stderr, flush=True))
+        except Exception as e:                # noqa: BLE001
+            out['secondary'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distd:

@@ -12,6 +12,8 @@ roofline, a parity flag against the CPU oracle, and the oracle timed on a stated
   abt        configs[4]: mult_abt of ratings blocks A[2000] x B[20000]^T (csr/kernels/numba/multiply.py:41-57),
              values compared bit for bit with the oracle (columns compared as sets per row: DESIGN.md section 3)
   unit_rows  csrk_unit_rows_device on the headline matrix (csr/transform.py:29-66)
+  protocol   what a caller of the kernel protocol pays for mult_vec on the headline matrix with HOST vectors
+             (csr/csr.py:569-590), next to the box's PCIe rates
 """
 import ctypes as C
 import time
@@ -274,9 +276,82 @@ def unit_rows(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, reps=5, cp
                              'sample': f'the first {r_s} rows ({e_s} entries), one pass of orc_unit_rows ({t_cpu:.2f} s)'}}
 
 
-def run_all(dev, headline=None, log=None):
+def protocol(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, product_ms=None, reps=10):
     """
-    -> {'spmm': ..., 'transpose': ..., 'abt': ..., 'unit_rows': ..., 'seconds': ...}; a part that raises is reported as
+    What a caller of the kernel PROTOCOL pays for mult_vec on the headline matrix: host vector in, fresh host vector
+    out (csr/csr.py:569-590; csr/kernels/mkl/multiply.py:31-41), through csr_amd.CSR.mult_vec -> hip.to_handle (handle
+    cache warm: the matrix and its plan are in HBM) -> csrk_spmv -> release_handle.  Wall time per call, next to the
+    PCIe rates of this box (80 MB each way, measured here with pinned and with pageable memory) and the product alone.
+    """
+    from csr_amd import CSR
+    from csr_amd.kernels import hip
+    if rp is None:
+        nrows = ncols = 10_000_000
+        m = synth.powerlaw_csr(nrows, ncols, 200_000_000, device=dev)
+        rp, ci, vs = m['rowptrs'], m['colinds'], m['values']
+    nnz = int(ci.numel())
+    A = CSR(nrows, ncols, nnz, np.array(rp.cpu().numpy()), np.array(ci.cpu().numpy()), np.array(vs.cpu().numpy()), _cast=False)
+    x_d = synth.dense_vector(ncols, device=dev)
+    x = np.array(x_d.cpu().numpy())
+
+    def med(fn, n=reps, warm=2):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts)), float(np.min(ts))
+    # the box's PCIe rates for a vector of this size
+    d = torch.empty(ncols, dtype=torch.float64, device=dev)
+    hp = torch.empty(ncols, dtype=torch.float64).pin_memory()
+    hq = torch.from_numpy(x.copy())
+    h2d_pin, _ = med(lambda: d.copy_(hp, non_blocking=True), 5)
+    d2h_pin, _ = med(lambda: hp.copy_(d, non_blocking=True), 5)
+    h2d_page, _ = med(lambda: d.copy_(hq), 5)
+    d2h_page, _ = med(lambda: hq.copy_(d), 5)
+    d2h_fresh, _ = med(lambda: torch.from_numpy(np.empty(ncols)).copy_(d), 3, 1)
+    del hp, hq
+    t0 = time.perf_counter()
+    A.mult_vec(x)                              # copies the matrix to HBM (2.44 GB over PCIe)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    A.mult_vec(x)                              # builds the plan
+    second_ms = (time.perf_counter() - t0) * 1e3
+    ms, ms_min = med(lambda: A.mult_vec(x))
+    y = A.mult_vec(x)
+    h = hip.to_handle(A)
+    y_d = torch.empty(nrows, dtype=torch.float64, device=dev)
+    if product_ms is None:
+        product_ms, _ = med(lambda: check(lib.csrk_spmv_device(h.H, x_d.data_ptr(), y_d.data_ptr(), None)))
+    check(lib.csrk_spmv_device(h.H, x_d.data_ptr(), y_d.data_ptr(), None))
+    same = bool(np.array_equal(y, y_d.cpu().numpy()))
+    x32 = x.astype(np.float32)
+    ms32, _ = med(lambda: hip.mult_vec(h, x32), 5)
+    hip.release_handle(h)
+    hip.invalidate(A)
+    hip.flush_result_pool()
+    bound = product_ms + h2d_pin + d2h_pin
+    return {'config': f'csr_amd.CSR.mult_vec(x) on the headline matrix {nrows}x{ncols} nnz {nnz}: host x in, fresh host y out, handle cache warm',
+            'entry': 'CSR.mult_vec -> hip.to_handle / mult_vec / release_handle -> csrk_spmv', 'ms': round(ms, 3), 'ms_min': round(ms_min, 3),
+            'timing': f'wall per call, median of {reps}',
+            'split_ms': {'h2d_x': round(h2d_page, 3), 'product': round(product_ms, 4), 'd2h_y': round(d2h_page, 3),
+                         'everything_else': round(ms - h2d_page - product_ms - d2h_page, 3)},
+            'pcie_this_box': {'bytes_each_way': ncols * 8, 'pinned_h2d_ms': round(h2d_pin, 3), 'pinned_d2h_ms': round(d2h_pin, 3),
+                              'pageable_h2d_ms': round(h2d_page, 3), 'pageable_d2h_ms': round(d2h_page, 3),
+                              'pageable_d2h_into_a_fresh_array_ms': round(d2h_fresh, 3),
+                              'pinned_gbs': round(ncols * 8 / (h2d_pin * 1e-3) / 1e9, 1)},
+            'bound_ms': round(bound, 3), 'bound': 'product + 2 x 80 MB at the pinned PCIe rate', 'within_10pct_of_bound': bool(ms <= 1.1 * bound),
+            'f32_x_ms': round(ms32, 3), 'first_call_ms_copies_the_matrix': round(first_ms, 1), 'second_call_ms_builds_the_plan': round(second_ms, 1),
+            'parity': {'y_bitwise_equal_to_the_device_product': same, 'ok': same}}
+
+
+def run_all(dev, headline=None, log=None, product_ms=None):
+    """
+    -> {'protocol': ..., 'spmm': ..., 'transpose': ..., 'abt': ..., 'unit_rows': ..., 'seconds': ...}; a part that raises is reported as
     {'error': ...} (the headline line must still be printed).  `headline` = (rp, ci, vs, nrows, ncols) resident arrays.
     """
     out = {}
@@ -292,14 +367,24 @@ def run_all(dev, headline=None, log=None):
         if log:
             log(f'[bench secondary] {name}: {out[name].get("ms", out[name].get("error"))} ms, {out[name]["seconds"]} s')
     if headline is not None:
+        part('protocol', lambda: protocol(dev, *headline, product_ms=product_ms))
         part('unit_rows', lambda: unit_rows(dev, *headline))
     else:
+        part('protocol', lambda: protocol(dev))
         part('unit_rows', lambda: unit_rows(dev))
     part('spmm', lambda: spmm(dev))
-    ml = ml_matrix(dev)
-    part('transpose', lambda: transpose(dev, ml))
-    part('abt', lambda: abt(dev, ml))
+    ml = None
+    try:
+        ml = ml_matrix(dev)
+    except Exception as e:                    # noqa: BLE001
+        out['transpose'] = out['abt'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    if ml is not None:
+        part('transpose', lambda: transpose(dev, ml))
+        part('abt', lambda: abt(dev, ml))
     del ml
-    check(lib.csrk_trim_cache())
+    try:
+        check(lib.csrk_trim_cache())
+    except Exception:                         # noqa: BLE001
+        pass
     out['seconds'] = round(time.perf_counter() - t_all, 2)
     return out

@@ -221,6 +221,75 @@ def _call(fn, *args):
     check(rc)
 
 
+# ---- result arrays -----------------------------------------------------------------------------------------
+# The protocol returns FRESH host arrays (mult_vec: csr/kernels/numba/__init__.py:57, from_handle: :30-36).  A fresh
+# np.empty of 80 MB is 20 000 unmapped pages: the device-to-host copy into it faults every one of them in (measured on
+# the MI355X host: 8.3 ms against 1.43 ms into memory that has been touched before -- the product itself is 0.54 ms).
+# Large results therefore come from blocks that have been through that once: a result array is a view of a LEASE on a
+# block; when the caller has dropped the array and every view of it, the block goes back to the idle list (at most
+# CSRK_RESULT_POOL_BYTES idle, default 2 GiB; 0 = plain np.empty everywhere).  The caller sees an ordinary writable
+# ndarray that nobody else holds (`owndata` is False: its memory belongs to the lease).
+_POOL_MIN = 1 << 20
+_pool_lock = threading.Lock()
+_pool = []                      # idle blocks: uint8 arrays whose pages are mapped
+_pool_bytes = 0
+_leases = {}                    # id(lease) -> weak reference: the leases behind live result arrays (an array whose base
+                                # is one owns its memory alone)
+
+
+def _pool_cap():
+    return int(os.environ.get('CSRK_RESULT_POOL_BYTES', str(2 << 30)))
+
+
+def _give_back(blk, lease_id):
+    global _pool_bytes
+    with _pool_lock:
+        _leases.pop(lease_id, None)
+        if _pool_bytes + blk.nbytes <= _pool_cap():
+            _pool.append(blk)
+            _pool_bytes += blk.nbytes
+
+
+def _is_lease(obj):
+    r = _leases.get(id(obj))
+    return r is not None and r() is obj
+
+
+def flush_result_pool():
+    "free the idle result blocks"
+    global _pool_bytes
+    with _pool_lock:
+        _pool.clear()
+        _pool_bytes = 0
+
+
+def _out(shape, dtype):
+    "an uninitialised array for a library call to fill: recycled memory for large results (see above)"
+    global _pool_bytes
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64))
+    nbytes = n * dtype.itemsize
+    if nbytes < _POOL_MIN or _pool_cap() <= 0:
+        return np.empty(shape, dtype=dtype)
+    blk = None
+    with _pool_lock:
+        best = -1
+        for i, b in enumerate(_pool):      # smallest idle block that fits without wasting more than a quarter
+            if nbytes <= b.nbytes <= nbytes + nbytes // 4 and (best < 0 or b.nbytes < _pool[best].nbytes):
+                best = i
+        if best >= 0:
+            blk = _pool.pop(best)
+            _pool_bytes -= blk.nbytes
+    if blk is None:
+        blk = np.empty(nbytes, dtype=np.uint8)
+    lease = (C.c_char * blk.nbytes).from_buffer(blk)
+    weakref.finalize(lease, _give_back, blk, id(lease)).atexit = False
+    with _pool_lock:
+        _leases[id(lease)] = weakref.ref(lease)
+    arr = np.frombuffer(lease, dtype=dtype, count=n)      # (its base is the lease itself: what the handle cache checks)
+    return arr if np.ndim(shape) == 0 or len(shape) == 1 else arr.reshape(shape)
+
+
 def _create(csr, rps, cis, vs):
     out = handle_t(0)
     _call(lib.csrk_create, int(csr.nrows), int(csr.ncols), int(csr.nnz), ptr(rps), int(rps.dtype == np.dtype('i8')), ptr(cis),
@@ -258,7 +327,7 @@ def to_handle(csr):
             return True
         if not (isinstance(orig, np.ndarray) and a.ctypes.data == orig.ctypes.data):
             return False
-        return not guarded or orig.base is None
+        return not guarded or orig.base is None or _is_lease(orig.base)      # (a result array of this module: _out)
     cacheable = (mode != 'off' and nnz >= 4096 and (not guarded or getattr(type(csr), '__csrk_cacheable__', False))
                  and own(rps, csr.rowptrs) and own(cis, csr.colinds) and own(vs, csr.values))
     if cacheable:
@@ -337,9 +406,9 @@ def from_handle(h):
     """
     from ..csr import CSR
     nr, nc, nnz, p64, vt = _info(_live(h))
-    rps = np.empty(nr + 1, dtype=np.int64 if p64 else np.int32)
-    cis = np.empty(nnz, dtype=np.int32)
-    vs = None if vt == _lib.VAL_NONE else np.empty(nnz, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
+    rps = _out(nr + 1, np.int64 if p64 else np.int32)
+    cis = _out(nnz, np.int32)
+    vs = None if vt == _lib.VAL_NONE else _out(nnz, np.float32 if vt == _lib.VAL_F32 else np.float64)
     check(lib.csrk_export(h.H, ptr(rps), ptr(cis), ptr(vs)))
     return CSR(nr, nc, nnz, rps, cis, vs, _cast=False)
 
@@ -386,7 +455,7 @@ def mult_vec(h, v):
     v = np.asarray(v)
     if v.shape != (h.ncols,):
         raise ValueError(f'vector has shape {v.shape}, expected ({h.ncols},)')
-    y = np.empty(h.nrows, dtype=np.float64)
+    y = _out(h.nrows, np.float64)
     if v.dtype == np.float32:
         x = np.ascontiguousarray(v)
         _call(lib.csrk_spmv_f32x, _live(h), ptr(x), ptr(y))
@@ -447,7 +516,7 @@ def from_coo(rows, cols, vals, shape):
 def row_nnzs(h):
     "csr/csr.py:432-441"
     _, _, _, p64, _ = _info(_live(h))
-    out = np.empty(h.nrows, dtype=np.int64 if p64 else np.int32)
+    out = _out(h.nrows, np.int64 if p64 else np.int32)
     check(lib.csrk_row_nnzs(h.H, ptr(out)))
     return out
 
@@ -464,7 +533,7 @@ def _row_stat(fn, h):
     if vt == _lib.VAL_NONE:
         raise ValueError('matrix has no values')
     _detach(h)                     # unit_rows / center_rows rewrite the device copy's values
-    out = np.empty(h.nrows, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
+    out = _out(h.nrows, np.float32 if vt == _lib.VAL_F32 else np.float64)
     check(fn(h.H, ptr(out)))                        # in place: never retried (see _call)
     return out
 
@@ -499,7 +568,7 @@ def values_of(h):
     _, _, nnz, _, vt = _info(_live(h))
     if vt == _lib.VAL_NONE:
         return None
-    vs = np.empty(nnz, dtype=np.float32 if vt == _lib.VAL_F32 else np.float64)
+    vs = _out(nnz, np.float32 if vt == _lib.VAL_F32 else np.float64)
     check(lib.csrk_export(h.H, None, None, ptr(vs)))
     return vs
 
@@ -513,7 +582,7 @@ def mult_dense(h, B):
     if B.ndim != 2 or B.shape[0] != h.ncols:
         raise ValueError(f'panel has shape {B.shape}, expected ({h.ncols}, k)')
     k = B.shape[1]
-    out = np.empty((h.nrows, k), dtype=np.float64)
+    out = _out((h.nrows, k), np.float64)
     _call(lib.csrk_spmm_dense, _live(h), ptr(B), k, k, ptr(out), k)
     return out
 

@@ -303,3 +303,62 @@ def test_in_place_operations_are_not_retried(K, monkeypatch):
         K.order_columns(h)
     assert calls == ['u', 'o'] and len(K.lib.live) == 2
     K.release_handle(h)
+
+
+# ---- result arrays (hip._out): large results come from recycled, already mapped memory -------------------------
+def test_result_arrays_are_recycled_only_when_nobody_holds_them(K, monkeypatch):
+    K.flush_result_pool()
+    small = K._out(100, np.float64)
+    assert small.flags.owndata                        # below 1 MiB: plain np.empty
+    n = 300_000                                       # 2.4 MB
+    a = K._out(n, np.float64)
+    assert a.shape == (n,) and a.dtype == np.float64 and a.flags.writeable and a.flags.c_contiguous
+    a[:] = 1.0
+    addr = a.ctypes.data
+    view = a[10:20]
+    del a
+    gc.collect()
+    b = K._out(n, np.float64)                         # a view of the first result is alive: its memory is NOT handed out
+    assert b.ctypes.data != addr and view[0] == 1.0
+    del view
+    gc.collect()
+    assert K._pool_bytes == n * 8                     # now it is idle ...
+    c = K._out((n // 2, 2), np.float64)               # ... and serves the next result of that size (any shape / dtype)
+    assert c.ctypes.data == addr and c.shape == (n // 2, 2) and K._pool_bytes == 0
+    d = K._out(n // 4, np.float32)                    # a quarter of the size: the idle block would be mostly waste
+    del b, c
+    gc.collect()
+    assert d.ctypes.data != addr
+    monkeypatch.setenv('CSRK_RESULT_POOL_BYTES', '0')
+    e = K._out(n, np.float64)
+    assert e.flags.owndata                            # pool off: plain arrays, nothing kept
+    del d, e
+    gc.collect()
+    K.flush_result_pool()
+    assert K._pool_bytes == 0 and not K._pool
+
+
+def test_a_matrix_made_of_result_arrays_is_cacheable(K):
+    "from_handle's arrays come from _out: a CSR built on them must still reach the handle cache (they own their memory alone)"
+    from csr_amd import CSR
+    n = 400_000
+    rp = K._out(n + 1, np.int32)
+    rp[:] = np.arange(n + 1, dtype=np.int32)
+    ci = K._out(n, np.int32)
+    ci[:] = 0
+    vs = K._out(n, np.float64)
+    vs[:] = 1.0
+    assert not rp.flags.owndata
+    A = CSR(n, n, n, rp, ci, vs, _cast=False)
+    h = K.to_handle(A)
+    K.release_handle(h)
+    h2 = K.to_handle(A)
+    assert K.lib.created == 1 and h2.H == 1           # cached, like a matrix on plain arrays
+    with pytest.raises(ValueError):
+        A.values[0] = 2.0                             # ... and guarded like one
+    K.release_handle(h2)
+    K.invalidate(A)
+    A.values[0] = 2.0
+    del A, rp, ci, vs
+    gc.collect()
+    K.flush_result_pool()

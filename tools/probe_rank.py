@@ -1,5 +1,6 @@
 # scratch: local SpMV time of ONE rank's row range for world = 1, 2, 4, 8 (what the N-GPU bench computes per rank
-# before the exchange); usage: PYTHONPATH=. python tools/probe_rank.py
+# before the exchange); usage: PYTHONPATH=. python tools/probe_rank.py ["ENV=1 ENV2=2" ...]   (one pass per argument: the
+# CSRK_* settings a plan is built under; none = defaults)
 import ctypes as C, torch, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from csr_amd import synth
@@ -8,7 +9,16 @@ dev = 'cuda'
 n = 10_000_000; nnz = 200_000_000
 x = synth.dense_vector(n, device=dev)
 import os
+base_env = dict(os.environ)
 for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
+  for cfg in sys.argv[1:] or ['']:
+    for k in [k for k in os.environ if k.startswith('CSRK_') and k not in base_env]:
+        del os.environ[k]
+    for kv in cfg.split():
+        k, _, v = kv.partition('=')
+        os.environ[k] = v
+    if cfg:
+        print(f'[{cfg}]')
     for rank in sorted({0}):
         sh = synth.powerlaw_csr(n, n, nnz, device=dev, rank=rank, world=world)
         rp, ci, vs = sh['rowptrs'], sh['colinds'], sh['values']
