@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -38,16 +39,49 @@ struct SegDesc {
     int64_t part;
 };
 
+// ---- heavy rows: accumulators in registers, B tiles staged in LDS (north_star: "dense B tile staged in LDS") ----------
+// The longest rows hold most of a power-law matrix (BASELINE matrix: 58 % of the entries in 2039 rows of >= 2048
+// entries): read row by row, each entry pulls a 512-B row of B into a CU, and nothing is reused.  Turned round: a
+// persistent 1024-thread workgroup owns HR_ROWS = 512 heavy rows -- wavefront w holds rows 32 w .. 32 w + 31, one
+// accumulator per (row, panel column) in REGISTERS (lane = panel column: 32 doubles = 64 VGPRs per lane) -- and sweeps a
+// range of column TILES of HR_TILE = 128 rows of B (64 KiB at 64 panel columns), copied into LDS with coalesced 16-B loads,
+// double-buffered (tile t + 1 is in flight while tile t is used).  The tile's entries on the workgroup's rows come from a
+// private stream bucketed by (tile, row group, wavefront): {slot of the row in its wavefront, row of B inside the tile,
+// value}; an entry is one ds_read_b64 per lane (the 64 lanes read one contiguous 512-B row: no bank conflicts) and one
+// FMA into the accumulator of its row.  The row is wavefront-uniform, so that accumulator is a dynamically indexed
+// REGISTER: s_set_gpr_idx_on + v_fma_f64 with relative destination (the accumulators are pinned to v[64:127]; the
+// compiler alone puts a dynamically indexed array of this size into scratch memory).  Entries, values and bucket
+// bounds are wavefront-uniform too: scalar loads.
+// With G row groups and R column ranges (G R = number of CUs; the G workgroups of a column range sit on ONE XCD and walk
+// the same tiles at the same pace, so the tile a workgroup stages is usually in that XCD's L2) every staged B row serves
+// all the entries the workgroup's 512 rows have on it (3.6 on average on the BASELINE matrix) instead of one: 4 GB of
+// coalesced tile loads from L2 instead of 14.8 GB of 128-B line fills.  Each workgroup writes the partial panel of its
+// rows over its column range; the reduce kernel adds a row's R partials in range order (fixed order: bitwise
+// reproducible; inside a tile a row's entries keep their storage order).
+constexpr int HR_THREADS = 1024;
+constexpr int HR_WAVES = HR_THREADS / WAVE;      // 16
+constexpr int HR_RPW = 32;                       // rows per wavefront
+constexpr int HR_ROWS = HR_WAVES * HR_RPW;       // 512 rows per workgroup
+constexpr int HR_TILE = 128;                     // rows of B per tile
+constexpr int HR_KC = 64;                        // panel columns per launch (wider panels: one launch per 64 columns)
+constexpr int HR_PAD = 2 * WAVE;                 // the entry arrays' padding: a wavefront loads 64 entries from a bucket's start whatever its length
+constexpr int HR_MAXG = 8;                       // at most 8 row groups (4096 heavy rows)
+constexpr size_t HR_LDS = (size_t)2 * HR_TILE * HR_KC * 8;
+
 struct SpmmPlan {
-    Tier0View heavy;           // heavy rows come from the SpMV plan's column-block-major panel (or .on == false)
-    // heavy rows: a row of L entries is cut into ceil(L / slice) parallel SLICES; slice p of P takes the p-th P-th of
-    // every (column block, row) pair's entries, so all slices have about the same work in every block
-    DevBuf slice;              // HeavySlice[n_slices]
-    DevBuf slice_first;        // int32[n_rows + 1]: first slice of each heavy row
-    int64_t n_slices = 0;
-    int32_t n_wg = 0;          // persistent workgroups per XCD stream (CUs / 8)
-    DevBuf hpart;              // double[n_slices * MM_STREAMS * k]: one partial panel per (slice, XCD stream)
-    int32_t hpart_k = 0;
+    // heavy rows (spmm_hrows_kernel)
+    bool hr_on = false;
+    int32_t hr_min = 0;        // rows with at least this many entries are heavy
+    int32_t hr_n = 0;          // heavy rows
+    int32_t hr_G = 0, hr_R = 0, hr_tiles = 0;
+    int64_t hr_nnz = 0;
+    DevBuf hr_rows;            // int32[hr_n]: row id of heavy row i
+    DevBuf hr_code;            // int32[hr_n]: its place (group << 9 | wavefront << 5 | slot)
+    DevBuf hr_bp;              // int64[hr_tiles * G * 16 + 1]: bucket bounds, bucket = (tile * G + group) * 16 + wavefront
+    DevBuf hr_idx;             // uint32[hr_nnz + padding]: 2 slot | row of B inside the tile << 9
+    DevBuf hr_vals;            // double[hr_nnz + padding]
+    DevBuf hr_range;           // int32[R + 1]: first tile of each column range
+    DevBuf hr_part;            // double[R * G * 512 * 64]
     int64_t n_segs = 0;
     int64_t n_multi = 0;       // segments belonging to split rows (need a partial panel)
     DevBuf part_off;           // int64[nrows + 1]: first partial slot of each split row
@@ -57,22 +91,14 @@ struct SpmmPlan {
     DevBuf seg;                // SegDesc[n_segs]
     DevBuf part;               // double[n_segs * k] (allocated on demand)
     int32_t part_k = 0;
-    // opt-in (CSRK_SPMM_HOT=1): light rows with the hottest B rows resident in LDS (spmm_lseg_kernel) -- the columns the
-    // light rows reference most, by popularity; the first n_hot of them (as many B rows as 128 KiB of LDS hold at the
-    // panel width) are LDS slots, and ci_hot is a private copy of colinds in which an entry on slot s is stored as ~s
-    std::vector<int32_t> hot_sorted;
-    DevBuf hot_cols;           // int32[n_hot]
-    DevBuf ci_hot;             // int32[nnz]
-    int32_t n_hot = 0;         // slots ci_hot was encoded for (0: not built)
-    bool hot_tried = false;
 };
 
 void free_spmm_plan(SpmmPlan *p) { delete p; }
 int64_t spmm_plan_bytes(const SpmmPlan *p)
 {
     int64_t b = 0;
-    for (const DevBuf *d : {&p->slice, &p->slice_first, &p->hpart, &p->part_off, &p->split_rows, &p->seg_off, &p->seg, &p->part,
-                            &p->hot_cols, &p->ci_hot})
+    for (const DevBuf *d : {&p->hr_rows, &p->hr_code, &p->hr_bp, &p->hr_idx, &p->hr_vals, &p->hr_range, &p->hr_part, &p->part_off,
+                            &p->split_rows, &p->seg_off, &p->seg, &p->part})
         b += (int64_t)d->bytes;
     return b;
 }
@@ -176,121 +202,263 @@ __global__ void mm_count_kernel(const P *__restrict__ rp, int32_t nrows, int64_t
     pcnt[r] = n > 1 ? n : 0;         // only split rows need partial panels
 }
 
-// ---- heavy rows: column-block-major, B window resident in L2 -------------------------------------------
-// A row with thousands of entries reads thousands of different B rows; row after row that is a pure
-// HBM stream (B does not fit the Infinity Cache).  The SpMV plan already holds the heavy rows re-sorted
-// into (column block, row) pairs of 4096 columns; per block the B rows it needs are 4096 * k * 8 B = 2 MiB
-// at k = 64, which stays in an XCD's L2 when the block is served by one XCD (workgroups with
-// blockIdx % 8 == block % 8; a speed assumption only).
-//
-// Block-synchronous slices.  The first version ran one wavefront per pair and wrote a partial panel per pair
-// (1.5 * 10^6 pairs of ~16 entries on the BASELINE matrix: 0.75 GB written and read again, and the window shared L2
-// with that stream: 73 % hit rate, the kernel bound by L1 line fills and partial traffic).  Now a heavy row of L
-// entries is cut into ceil(L / slice) SLICES (slice p of P takes the p-th P-th of every pair of the row, so every slice
-// has about the same number of entries in every block), and one persistent 1024-thread workgroup per CU -- 32 per XCD
-// stream g -- holds MM_R slices per 16-lane unit with their four panel columns per lane in REGISTERS and walks the
-// stream's blocks g, g + 8, ... with a workgroup barrier per block.  A workgroup's slices are a uniform sample of all
-// slices (slice s goes to workgroup s mod 32), so the workgroups of a stream do the same amount of work per block to
-// within a few per cent and move through the blocks together with no synchronisation between them: the B rows of the
-// block they are at are what their XCD's L2 holds (a speed assumption only: any placement computes the same bits).
-// One partial per (slice, stream) is written at the end and the reduce kernel adds a row's partials in order.
-// (Units that walk the blocks on their own, without the barrier, drift apart by several blocks and lose the window:
-// 22 % L2 hit rate, 12.5 GB of fabric reads -- measured; with it 91 % and 1.4 GB.)
-constexpr int MM_STREAMS = 8;
-constexpr int MM_R = 4;                      // slices per unit (their accumulators: 4 x 4 doubles per lane)
-constexpr int MM_HEAVY_THREADS = 1024;
-constexpr int MM_HEAVY_UNITS = MM_HEAVY_THREADS / MM_G;      // 64
-#ifndef CSRK_MM_SLICE
-#define CSRK_MM_SLICE 2048
-#endif
-constexpr int MM_SLICE = CSRK_MM_SLICE;     // smallest slice; doubled until the slices fit the persistent grid
+typedef double hr_d8 __attribute__((ext_vector_type(8)));
 
-struct HeavySlice {
-    int32_t h;       // heavy-row index
-    int32_t p, P;    // slice p of P
-};
+// acc[I / 2] += V * Bv for eight entries, the accumulators being v[64:127] (A0 .. A3): VGPR index mode with relative
+// destination and addend, switched on ONCE for the eight (s_set_gpr_idx_idx moves the index; entering and leaving the
+// mode per entry cost more than everything else the entry needs).  Nothing but the FMAs may execute in between -- the
+// mode applies to every vector instruction -- hence one asm statement.
+#define HR_FMA8(I, V, Bv) \
+    asm volatile("s_set_gpr_idx_on %[i0], 0xc\n\t" \
+                 "v_fma_f64 v[64:65], %[v0], %[b0], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i1]\n\t" \
+                 "v_fma_f64 v[64:65], %[v1], %[b1], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i2]\n\t" \
+                 "v_fma_f64 v[64:65], %[v2], %[b2], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i3]\n\t" \
+                 "v_fma_f64 v[64:65], %[v3], %[b3], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i4]\n\t" \
+                 "v_fma_f64 v[64:65], %[v4], %[b4], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i5]\n\t" \
+                 "v_fma_f64 v[64:65], %[v5], %[b5], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i6]\n\t" \
+                 "v_fma_f64 v[64:65], %[v6], %[b6], v[64:65]\n\t" \
+                 "s_set_gpr_idx_idx %[i7]\n\t" \
+                 "v_fma_f64 v[64:65], %[v7], %[b7], v[64:65]\n\t" \
+                 "s_set_gpr_idx_off" \
+                 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3) \
+                 : [i0] "s"(I[0]), [i1] "s"(I[1]), [i2] "s"(I[2]), [i3] "s"(I[3]), [i4] "s"(I[4]), [i5] "s"(I[5]), [i6] "s"(I[6]), [i7] "s"(I[7]), [v0] "s"(V[0]), [v1] "s"(V[1]), [v2] "s"(V[2]), [v3] "s"(V[3]), [v4] "s"(V[4]), [v5] "s"(V[5]), [v6] "s"(V[6]), [v7] "s"(V[7]), [b0] "v"(Bv[0]), [b1] "v"(Bv[1]), [b2] "v"(Bv[2]), [b3] "v"(Bv[3]), [b4] "v"(Bv[4]), [b5] "v"(Bv[5]), [b6] "v"(Bv[6]), [b7] "v"(Bv[7]))
 
-template <class PP, bool FULL4>
-__global__ __launch_bounds__(MM_HEAVY_THREADS) void spmm_heavy_kernel(
-    const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
-    const double *__restrict__ B, int32_t k, int64_t ldb, int32_t n_rows, int32_t n_blocks,
-    const HeavySlice *__restrict__ slice, int64_t n_slices, int32_t n_wg, double *__restrict__ part)
+// The first M (<= 64) entries of a chunk held one per lane in CI (entry words) / CV (values): batches of eight at
+// CONSTANT lanes (the loop is unrolled: v_readlane takes the lane as an immediate, no scalar arithmetic for it).  A batch
+// that is not full multiplies what is not its own -- valid entries of the next bucket, or the arrays' padding -- by 0.
+#define HR_CHUNK(CI, CV, M)                                                                                            \
+    do {                                                                                                               \
+        const int32_t m_ = (M);                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < WAVE / HR_BATCH; k_++)                                                 \
+        {                                                                                                              \
+            if (k_ * HR_BATCH >= m_) break;                                                                            \
+            uint32_t ix_[HR_BATCH];                                                                                    \
+            double v_[HR_BATCH], b_[HR_BATCH];                                                                         \
+            _Pragma("unroll") for (int u_ = 0; u_ < HR_BATCH; u_++)                                                    \
+            {                                                                                                          \
+                ix_[u_] = (uint32_t)__builtin_amdgcn_readlane((int)(CI), k_ * HR_BATCH + u_);                          \
+                v_[u_] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(CV), k_ * HR_BATCH + u_),           \
+                                          __builtin_amdgcn_readlane(__double2loint(CV), k_ * HR_BATCH + u_));          \
+                b_[u_] = *(const double *)(cur + (ix_[u_] & 0xfe00u));                                                 \
+            }                                                                                                          \
+            if ((k_ + 1) * HR_BATCH > m_) {                                                                            \
+                _Pragma("unroll") for (int u_ = 0; u_ < HR_BATCH; u_++)                                                \
+                {                                                                                                      \
+                    const bool mine_ = k_ * HR_BATCH + u_ < m_;                                                        \
+                    b_[u_] = mine_ ? b_[u_] : 0.0;                                                                     \
+                    v_[u_] = mine_ ? v_[u_] : 0.0;                                                                     \
+                }                                                                                                      \
+            }                                                                                                          \
+            HR_FMA8(ix_, v_, b_);                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+// rows [row0, row0 + HR_TILE) x columns [0, kc) of B into registers: thread p owns the 16-B pieces p, p + 1024, ...
+// (piece = (row, column pair)).  A tile inside the matrix under a full 64-column panel (`whole`, uniform) is four plain
+// loads at a scalar base + the thread's fixed offset `voff`.  Otherwise: branch-free, so that the loads stay in flight
+// until hr_tile_store needs them: a piece past the matrix or the panel reads a valid address instead and is zeroed when
+// it is stored.  EVEN: kc is even (a piece is inside the panel or outside it: one 16-B load); else two 8-B loads.
+template <bool EVEN>
+__device__ __forceinline__ void hr_tile_load(const double *__restrict__ B, int64_t ldb, int32_t ncols, int32_t kc, int64_t row0,
+                                             int tid, uint32_t voff, bool whole, mm_f64x2 v[4])
 {
-    const int g = blockIdx.x % MM_STREAMS;
-    const int wg = blockIdx.x / MM_STREAMS;
-    const int unit = threadIdx.x / MM_G, sub = threadIdx.x & (MM_G - 1);
-    // slice r of this unit: s = wg + n_wg * (unit + 64 r); (row, p, P) packed in two registers per slice
-    const int64_t sid0 = wg + (int64_t)n_wg * unit, sstep = (int64_t)n_wg * MM_HEAVY_UNITS;
-    int32_t sh[MM_R];
-    uint32_t spP[MM_R];      // p in the low 16 bits, P in the high 16
+    if (whole) {
+        const char *sb = (const char *)(B + row0 * ldb);
 #pragma unroll
-    for (int r = 0; r < MM_R; r++) {
-        sh[r] = 0, spP[r] = 1u << 16;
-        if (sid0 + sstep * r < n_slices) {
-            const HeavySlice t = slice[sid0 + sstep * r];
-            sh[r] = t.h;
-            spP[r] = (uint32_t)t.p | ((uint32_t)t.P << 16);
-        }
+        for (int i = 0; i < 4; i++) v[i] = *(const MMF64x2 *)(sb + (size_t)i * 32 * (size_t)ldb * 8 + voff);
+        return;
     }
-    for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
-        const int32_t c = c0 + 4 * sub;
-        double acc[MM_R][4];
 #pragma unroll
-        for (int r = 0; r < MM_R; r++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[r][i] = 0.0;
-        for (int64_t b = g; b < n_blocks; b += MM_STREAMS) {
-            int32_t a0[MM_R], n0[MM_R];
-#pragma unroll
-            for (int r = 0; r < MM_R; r++) {                       // all pair ranges first: independent loads
-                const int64_t q = b * n_rows + sh[r];
-                const bool in = sid0 + sstep * r < n_slices;
-                const int64_t t0 = in ? (int64_t)prp[q] : 0;
-                n0[r] = in ? (int32_t)((int64_t)prp[q + 1] - t0) : 0;
-                a0[r] = (int32_t)(t0 - (int64_t)prp[b * n_rows]);      // relative to the block's first entry (fits 32 bits)
-            }
-            const int64_t blk0 = (int64_t)prp[b * n_rows];
-#pragma unroll
-            for (int r = 0; r < MM_R; r++) {
-                const int64_t p_ = spP[r] & 0xffffu, P_ = spP[r] >> 16;
-                const int64_t lo = (int64_t)n0[r] * p_ / P_, hi = (int64_t)n0[r] * (p_ + 1) / P_;
-                const int n = (int)(hi - lo);
-                const int nmax = mm_wave_max4(n);
-                if (nmax) mm_unit<CSRK_VAL_F64, FULL4>(pci, pvs, blk0 + a0[r] + lo, n, nmax, B, ldb, c, k, sub, acc[r]);
-            }
-            __syncthreads();      // the workgroup's 64 units enter the next block together
+    for (int i = 0; i < 4; i++) {
+        const int p = tid + i * HR_THREADS;
+        const int64_t row = row0 + (p >> 5);
+        const int c = (p & 31) * 2;
+        const double *src = B + (row < ncols ? row : (int64_t)ncols - 1) * ldb;
+        if (EVEN) {
+            v[i] = *(const MMF64x2 *)(src + (c < kc ? c : 0));
+        } else {
+            v[i].x = src[c < kc ? c : 0];
+            v[i].y = src[c + 1 < kc ? c + 1 : 0];
         }
-#pragma unroll
-        for (int r = 0; r < MM_R; r++)
-            if (sid0 + sstep * r < n_slices)
-                mm_store4<FULL4>(part + ((sid0 + sstep * r) * MM_STREAMS + g) * (int64_t)k, c, k, acc[r]);
     }
 }
 
-// C[row] = sum of the row's partials, slices in order, streams in order inside a slice: one wavefront per heavy row
-__global__ __launch_bounds__(256) void spmm_heavy_reduce_kernel(const int32_t *__restrict__ slice_first,
-                                                               const int32_t *__restrict__ row_list, int32_t n_rows,
-                                                               int32_t k, const double *__restrict__ part,
-                                                               double *__restrict__ C, int64_t ldc)
+__device__ __forceinline__ void hr_tile_store(double *__restrict__ buf, int32_t ncols, int32_t kc, int64_t row0, int tid, bool whole,
+                                              const mm_f64x2 v[4])
 {
-    const int64_t h = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (h >= n_rows) return;
-    const int64_t r = row_list[h];
-    const int64_t p0 = (int64_t)slice_first[h] * MM_STREAMS, p1 = (int64_t)slice_first[h + 1] * MM_STREAMS;
-    for (int32_t c = lane; c < k; c += WAVE) {
-        double acc = 0.0;
-        int64_t q = p0;
-        for (; q + 8 <= p1; q += 8) {                                 // 8 partial rows in flight, added in order
-            double v[8];
+    if (whole) {
 #pragma unroll
-            for (int t = 0; t < 8; t++) v[t] = part[(q + t) * (int64_t)k + c];
-#pragma unroll
-            for (int t = 0; t < 8; t++) acc += v[t];
-        }
-        for (; q < p1; q++) acc += part[q * (int64_t)k + c];
-        C[r * ldc + c] = acc;
+        for (int i = 0; i < 4; i++) *(mm_f64x2 *)(buf + (size_t)(tid + i * HR_THREADS) * 2) = v[i];
+        return;
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = tid + i * HR_THREADS;
+        const bool in = row0 + (p >> 5) < ncols;
+        const int c = (p & 31) * 2;
+        mm_f64x2 t;
+        t.x = in && c < kc ? v[i].x : 0.0;
+        t.y = in && c + 1 < kc ? v[i].y : 0.0;
+        *(mm_f64x2 *)(buf + (size_t)p * 2) = t;
+    }
+}
+
+constexpr int HR_BATCH = 8;       // entries per HR_FMA8
+
+// Entry word: bits [7:0] = 2 x slot of the row in its wavefront (what s_set_gpr_idx_* take as the register index: they
+// read only those bits), bits [15:9] = row of B inside the tile (so word & 0xfe00 = the row's byte offset in the tile).
+// Per entry that leaves: three v_readlane (word, value), one s_and + v_or for the LDS address, the LDS read, one
+// s_set_gpr_idx_idx and the FMA -- the CU's ONE scalar unit and the four instructions a SIMD can start per entry time are
+// what bound this kernel, not bytes.
+template <bool EVEN>
+__global__ __launch_bounds__(HR_THREADS) void spmm_hrows_kernel(const int64_t *__restrict__ bp, const uint32_t *__restrict__ idx,
+                                                               const double *__restrict__ vals, const double *__restrict__ B,
+                                                               int32_t kc, int64_t ldb, int32_t ncols,
+                                                               const int32_t *__restrict__ range_tile, int32_t G,
+                                                               double *__restrict__ part)
+{
+    extern __shared__ __align__(16) double hr_lds[];      // two tiles of HR_TILE x 64 doubles
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (column range r, row group g): the G groups of a range share an XCD (blockIdx % 8)
+    const int xcd = blockIdx.x & 7, place = blockIdx.x >> 3;
+    const bool by_xcd = ((gridDim.x / G) & 7) == 0;       // (a small matrix may have fewer tiles than that allows)
+    const int r = by_xcd ? xcd + 8 * (place / G) : blockIdx.x / G, g = by_xcd ? place % G : blockIdx.x % G;
+    const int32_t t0 = range_tile[r], t1 = range_tile[r + 1];
+    hr_d8 A0 = 0.0, A1 = 0.0, A2 = 0.0, A3 = 0.0;
+    mm_f64x2 pre[4];
+    // The wavefront's entries of a tile are loaded a tile ahead, one entry per lane (a bucket holds ~30 entries on the
+    // BASELINE matrix; longer buckets fetch their later chunks of 64 when they get there), and handed out with
+    // v_readlane at constant lanes: vector loads have a counter of their own, so they stay in flight across the LDS
+    // waits -- scalar loads share theirs with the LDS reads, and every batch then pays a full memory latency.
+    const int64_t bstep = (int64_t)G * HR_WAVES;
+    int64_t bk = ((int64_t)t0 * G + g) * HR_WAVES + w;
+    int64_t e0 = bp[bk];
+    int32_t n = (int32_t)(bp[bk + 1] - e0);
+    uint32_t ci = idx[e0 + lane];
+    double cv = vals[e0 + lane];
+    int64_t e0n = 0;
+    int32_t nn = 0;
+    if (t0 + 1 < t1) {
+        e0n = bp[bk + bstep];
+        nn = (int32_t)(bp[bk + bstep + 1] - e0n);
+    }
+    // (thread's offset inside a tile of B: row tid / 32, column pair tid % 32; fits 32 bits when a tile's rows do)
+    const bool can_whole = kc == HR_KC && (int64_t)HR_TILE * ldb * 8 < (1ll << 31);
+    const uint32_t voff = (uint32_t)(((int64_t)(tid >> 5) * ldb + (tid & 31) * 2) * 8);
+    {
+        const bool whole = can_whole && (int64_t)(t0 + 1) * HR_TILE <= ncols;
+        hr_tile_load<EVEN>(B, ldb, ncols, kc, (int64_t)t0 * HR_TILE, tid, voff, whole, pre);
+        hr_tile_store(hr_lds, ncols, kc, (int64_t)t0 * HR_TILE, tid, whole, pre);
+    }
+    __syncthreads();
+    // (the entries must have ARRIVED where the loop starts -- and again at its end, below -- or the compiler, which cannot
+    // tell which loads a register still waits for across the back edge, waits for everything in flight before the first
+    // v_readlane: the prefetches just issued)
+    asm volatile("" : "+v"(ci), "+v"(cv));
+    const char *my = (const char *)hr_lds + lane * 8;
+    for (int32_t t = t0; t < t1; t++) {
+        const char *cur = my + (size_t)((t - t0) & 1) * (HR_TILE * HR_KC * 8);
+        const bool more = t + 1 < t1;
+        const bool whole_next = can_whole && (int64_t)(t + 2) * HR_TILE <= ncols;
+        uint32_t ni = 0;
+        double nv = 0.0;
+        int64_t e0nn = 0;
+        int32_t nnn = 0;
+        if (more) {      // in flight while tile t is used: the next tile of B, the next bucket's first chunk, the bounds after it
+            hr_tile_load<EVEN>(B, ldb, ncols, kc, (int64_t)(t + 1) * HR_TILE, tid, voff, whole_next, pre);
+            ni = idx[e0n + lane];
+            nv = vals[e0n + lane];
+            if (t + 2 < t1) {
+                e0nn = bp[bk + 2 * bstep];
+                nnn = (int32_t)(bp[bk + 2 * bstep + 1] - e0nn);
+            }
+        }
+        HR_CHUNK(ci, cv, n < WAVE ? n : WAVE);      // the bucket's first 64 entries: in registers since the previous tile
+        for (int32_t c0 = WAVE; c0 < n; c0 += WAVE) {      // a bucket of more than 64 entries: the later chunks on demand
+            const uint32_t di = idx[e0 + c0 + lane];
+            const double dv = vals[e0 + c0 + lane];
+            HR_CHUNK(di, dv, n - c0 < WAVE ? n - c0 : WAVE);
+        }
+        if (more) hr_tile_store(hr_lds + (size_t)((t + 1 - t0) & 1) * (HR_TILE * HR_KC), ncols, kc, (int64_t)(t + 1) * HR_TILE, tid, whole_next, pre);
+        __syncthreads();      // tile t + 1 is complete; nobody reads tile t any more
+        bk += bstep;
+        e0 = e0n, n = nn, ci = ni, cv = nv;
+        e0n = e0nn, nn = nnn;
+        asm volatile("" : "+v"(ci), "+v"(cv));
+    }
+    // the workgroup's partial panel: part[((r * G + g) * 512 + 32 w + slot) * 64 + lane]
+    double *o = part + (((int64_t)r * G + g) * HR_ROWS + (int64_t)w * HR_RPW) * HR_KC + lane;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        __builtin_nontemporal_store(A0[i], o + (size_t)i * HR_KC);
+        __builtin_nontemporal_store(A1[i], o + (size_t)(8 + i) * HR_KC);
+        __builtin_nontemporal_store(A2[i], o + (size_t)(16 + i) * HR_KC);
+        __builtin_nontemporal_store(A3[i], o + (size_t)(24 + i) * HR_KC);
+    }
+}
+
+// C[row of heavy row i, c] = sum over the column ranges, in order, of the workgroups' partials: one wavefront per row
+__global__ __launch_bounds__(256) void spmm_hrows_reduce_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ code,
+                                                               int32_t n, int32_t G, int32_t R, int32_t kc,
+                                                               const double *__restrict__ part, double *__restrict__ C, int64_t ldc)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (i >= n || lane >= kc) return;
+    const int32_t cd = code[i];
+    const int64_t g = cd >> 9, in_wg = cd & (HR_ROWS - 1);
+    const double *p = part + (g * HR_ROWS + in_wg) * HR_KC + lane;
+    const int64_t step = (int64_t)G * HR_ROWS * HR_KC;
+    double acc = 0.0;
+    int32_t q = 0;
+    for (; q + 8 <= R; q += 8) {                                      // 8 partial rows in flight, added in order
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = p[(q + t) * step];
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc += v[t];
+    }
+    for (; q < R; q++) acc += p[q * step];
+    C[(int64_t)rows[i] * ldc + lane] = acc;
+}
+
+// plan time: the entries of heavy row i as sortable records, in the order (i, storage order)
+template <class P, int VT>
+__global__ __launch_bounds__(256) void hr_emit_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
+                                                     const int32_t *__restrict__ rows, const int32_t *__restrict__ code,
+                                                     const int64_t *__restrict__ off, int32_t G, int32_t *__restrict__ key,
+                                                     int32_t *__restrict__ payload, double *__restrict__ val)
+{
+    const int i = blockIdx.x;
+    const int64_t s = (int64_t)rp[rows[i]], e = (int64_t)rp[rows[i] + 1], o = off[i];
+    const int32_t cd = code[i];
+    const int32_t g = cd >> 9, w = (cd >> 5) & 15, slot = cd & 31;
+    for (int64_t q = s + threadIdx.x; q < e; q += 256) {
+        const int32_t c = ci[q];
+        key[o + q - s] = ((c / HR_TILE) * G + g) * HR_WAVES + w;
+        payload[o + q - s] = (slot << 1) | ((c % HR_TILE) << 9);      // (see spmm_hrows_kernel)
+        val[o + q - s] = mm_val<VT>(vs, q);
+    }
+}
+
+template <class P>
+__global__ void hr_len_kernel(const P *__restrict__ rp, int32_t nrows, int64_t *__restrict__ len)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) len[r] = (int64_t)rp[r + 1] - (int64_t)rp[r];
+}
+
+__global__ void hr_tile_totals_kernel(const int64_t *__restrict__ bp, int32_t n_tiles, int32_t per_tile, int64_t *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n_tiles) out[t] = bp[(int64_t)t * per_tile];
 }
 
 // one thread per row: descriptors of its segments (plan time)
@@ -334,144 +502,6 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const int32_t *__restrict
     }
 }
 
-// ---- opt-in: light rows with the hottest B rows resident in LDS (north_star's "B tile staged in LDS") -----------------
-// CSRK_SPMM_HOT=1.  Column popularity is as skewed as row length: on the BASELINE matrix the light rows put 29 % of their
-// entries on the 256 most referenced columns.  One persistent 1024-thread workgroup per CU copies the n_hot most referenced
-// B rows into LDS once (128 KiB: 256 rows at k = 64) and an entry on such a column reads its B row from there; the plan's
-// private column array marks those entries (~slot), the padding lanes of a batch read slot 0 instead of B row 0.  Lane
-// `sub` of a 16-lane unit owns panel columns {2 sub, 2 sub + 1} and {32 + 2 sub, 33 + 2 sub} of a 64-column chunk: each of
-// its two 16-B loads then covers, with its 15 neighbours, 256 contiguous bytes -- all 64 LDS banks once -- so the lane
-// groups ds_read_b128 is served in (which mix lanes of two units, i.e. two different rows) never clash when the row
-// stride is a multiple of 256 B.  Sums in storage order, as in spmm_seg_kernel: same bits.
-// MEASURED AND NOT THE DEFAULT: 1.61 ms against spmm_seg_kernel's 1.34 on the BASELINE matrix -- the
-// rows it serves from LDS were L2 hits before, the cheapest line fills, and the persistent form runs 16 wavefronts per CU
-// where the plain one runs 28.
-constexpr int MM_L_THREADS = 1024;
-constexpr int MM_L_UNITS = MM_L_THREADS / MM_G;
-constexpr int MM_LDS_BYTES = 128 * 1024;
-constexpr int MM_HOT_MAX = 8192;           // columns ranked at plan time (k = 2 fills the LDS budget with 8192 rows)
-
-template <int VT>
-__device__ __forceinline__ void mm_unit_h(const int32_t *__restrict__ ci, const void *__restrict__ vs, int64_t s, int n,
-                                          int nmax, const double *__restrict__ B, int64_t ldb,
-                                          const double *__restrict__ hotB, int32_t k, int32_t ca, int32_t cb, bool va,
-                                          bool vb, int sub, double acc[4])
-{
-    for (int base = 0; base < nmax; base += MM_G) {
-        const int idx = base + sub;
-        const int32_t mycol = idx < n ? ci[s + idx] : -1;              // padding: LDS slot 0
-        const double myval = idx < n ? mm_val<VT>(vs, s + idx) : 0.0;
-        const int nb = nmax - base < MM_G ? nmax - base : MM_G;
-        for (int j = 0; j < nb; j += MM_UNROLL) {
-            mm_f64x2 ta[MM_UNROLL], tb[MM_UNROLL];
-            double av[MM_UNROLL];
-            int32_t w[MM_UNROLL];
-            // the LDS reads first (short latency), then the global loads of the other entries into the SAME registers:
-            // a global load with the hot lanes masked off leaves their LDS values in place, and the only wait between
-            // the two groups is for the LDS.  (Either source chosen in one if / else per entry made the compiler wait for
-            // every global load before the next entry's LDS read -- same destination registers, different return
-            // queues: 2.08 ms instead of 1.61.)
-#pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                w[u] = __shfl(mycol, j + u, MM_G);
-                av[u] = __shfl(myval, j + u, MM_G);
-                ta[u] = mm_f64x2{0.0, 0.0};
-                tb[u] = mm_f64x2{0.0, 0.0};
-                if (w[u] < 0) {
-                    const double *p = hotB + (int64_t)(~w[u]) * k;
-                    if (va) ta[u] = *(const mm_f64x2 *)(p + ca);
-                    if (vb) tb[u] = *(const mm_f64x2 *)(p + cb);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                if (w[u] >= 0) {
-                    const double *p = B + (int64_t)w[u] * ldb;
-                    if (va) ta[u] = *(const MMF64x2 *)(p + ca);
-                    if (vb) tb[u] = *(const MMF64x2 *)(p + cb);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                const bool ok = base + j + u < n;
-                const double t0 = av[u] * ta[u].x, t1 = av[u] * ta[u].y, t2 = av[u] * tb[u].x, t3 = av[u] * tb[u].y;
-                acc[0] += ok ? t0 : 0.0;                                // masked after the multiply (0 * inf)
-                acc[1] += ok ? t1 : 0.0;
-                acc[2] += ok ? t2 : 0.0;
-                acc[3] += ok ? t3 : 0.0;
-            }
-        }
-    }
-}
-
-// k even.  Dynamic LDS: n_hot * k doubles.
-template <int VT>
-__global__ __launch_bounds__(MM_L_THREADS) void spmm_lseg_kernel(const int32_t *__restrict__ ci_hot, const void *__restrict__ vs,
-                                                                const double *__restrict__ B, int32_t k, int64_t ldb,
-                                                                double *__restrict__ C, int64_t ldc,
-                                                                const SegDesc *__restrict__ seg, int64_t n_segs,
-                                                                double *__restrict__ part,
-                                                                const int32_t *__restrict__ hot_cols, int32_t n_hot)
-{
-    extern __shared__ __align__(16) double mm_hotB[];
-    const int32_t k2 = k / 2;
-    for (int32_t i = threadIdx.x; i < n_hot * k2; i += MM_L_THREADS) {
-        const int32_t r = i / k2, c = (i - r * k2) * 2;
-        *(mm_f64x2 *)(mm_hotB + (int64_t)r * k + c) = *(const MMF64x2 *)(B + (int64_t)hot_cols[r] * ldb + c);
-    }
-    __syncthreads();
-    const int unit = threadIdx.x / MM_G, sub = threadIdx.x & (MM_G - 1);
-    const int64_t stride = (int64_t)gridDim.x * MM_L_UNITS;
-    // a wavefront's four units take four consecutive segments: the trip count is uniform inside the wavefront
-    for (int64_t q0 = (int64_t)blockIdx.x * MM_L_UNITS + (unit & ~3); q0 < n_segs; q0 += stride) {
-        const int64_t q = q0 + (unit & 3);
-        SegDesc d;
-        d.start = 0, d.n = 0, d.row = 0, d.part = -1;
-        if (q < n_segs) d = seg[q];
-        const int nmax = mm_wave_max4(d.n);
-        double *dst = d.part < 0 ? C + (int64_t)d.row * ldc : part + d.part * (int64_t)k;
-        for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
-            const int32_t ca = c0 + 2 * sub, cb = c0 + 32 + 2 * sub;
-            const bool va = ca < k, vb = cb < k;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            mm_unit_h<VT>(ci_hot, vs, d.start, d.n, nmax, B, ldb, mm_hotB, k, ca, cb, va, vb, sub, acc);
-            if (q < n_segs) {
-                if (va) __builtin_nontemporal_store(mm_f64x2{acc[0], acc[1]}, (MMF64x2 *)(dst + ca));
-                if (vb) __builtin_nontemporal_store(mm_f64x2{acc[2], acc[3]}, (MMF64x2 *)(dst + cb));
-            }
-        }
-    }
-}
-
-// plan time: how often the light rows reference each column (sampled rows; rows the heavy kernels serve are skipped)
-template <class P>
-__global__ void mm_col_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, int32_t nrows,
-                                    int64_t row_stride, int32_t heavy_min, int32_t *__restrict__ cnt)
-{
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MM_G;
-    const int sub = threadIdx.x & (MM_G - 1);
-    const int64_t r = q * row_stride;
-    if (r >= nrows) return;
-    const int64_t s = rp[r], e = rp[r + 1];
-    if (heavy_min > 0 && e - s >= heavy_min) return;
-    for (int64_t i = s + sub; i < e; i += MM_G) atomicAdd(&cnt[ci[i]], 1);
-}
-
-__global__ void mm_slot_scatter_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t *__restrict__ slot_of)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_hot) slot_of[hot_cols[i]] = i;
-}
-
-__global__ void mm_encode_hot_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ slot_of,
-                                     int32_t *__restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nnz) return;
-    const int32_t c = ci[i], sl = slot_of[c];
-    out[i] = sl >= 0 ? ~sl : c;
-}
-
 __global__ void mm_list_split_kernel(const int64_t *__restrict__ seg_off, int32_t nrows, int32_t *__restrict__ list,
                                      int32_t *__restrict__ n_list)
 {
@@ -509,7 +539,7 @@ static int build_mm_plan(Matrix *m, SpmmPlan *p, hipStream_t s)
         mm_count_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>((const P *)m->d_rowptrs, m->nrows,
                                                                             p->seg_off.as<int64_t>(),
                                                                             p->part_off.as<int64_t>(),
-                                                                            p->heavy.on ? p->heavy.min_entries : 0);
+                                                                            p->hr_on ? p->hr_min : 0);
         CSRK_LAUNCH_CHECK();
     }
     CSRK_TRY(exclusive_scan_i64(p->seg_off.as<int64_t>(), p->seg_off.as<int64_t>(), m->nrows, s));
@@ -541,111 +571,160 @@ static int build_mm_plan(Matrix *m, SpmmPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
-// the slice table of the heavy rows (host: a few thousand rows)
-template <class P>
-__global__ void mm_heavy_len_kernel(const P *__restrict__ rp, const int32_t *__restrict__ row_list, int32_t n_rows,
-                                    int64_t *__restrict__ len)
-{
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h < n_rows) len[h] = (int64_t)rp[row_list[h] + 1] - (int64_t)rp[row_list[h]];
-}
+int stable_sort_records_f64(const int32_t *keys, const int32_t *payload, const double *vals, int64_t n, int32_t key_range,
+                            int64_t payload_range, int64_t *out_ptr, int32_t *out_payload, double *out_vals, hipStream_t s);   // transpose.hip
 
-static int build_heavy_slices(Matrix *m, SpmmPlan *p, hipStream_t s)
+// Choose the heavy rows and build their bucketed stream (plan time).  `force`: CSRK_SPMM_HEAVY=1 (small test matrices).
+template <class P>
+static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_t s)
 {
-    const Tier0View &hv = p->heavy;
-    DevBuf dlen;
-    CSRK_TRY(dlen.alloc((size_t)hv.n_rows * 8));
-    const unsigned g = (unsigned)ceil_div(hv.n_rows, 256);
-    if (m->ptr64)
-        mm_heavy_len_kernel<int64_t><<<g, 256, 0, s>>>((const int64_t *)m->d_rowptrs, hv.row_list, hv.n_rows, dlen.as<int64_t>());
-    else
-        mm_heavy_len_kernel<int32_t><<<g, 256, 0, s>>>((const int32_t *)m->d_rowptrs, hv.row_list, hv.n_rows, dlen.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    std::vector<int64_t> len((size_t)hv.n_rows);
-    CSRK_HIP(hipMemcpyAsync(len.data(), dlen.p, (size_t)hv.n_rows * 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
+    p->hr_on = false;
+    if (m->nrows < 1 || m->ncols < 1 || m->nnz < 1) return CSRK_OK;
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    p->n_wg = (cus > 0 ? cus : 256) / MM_STREAMS;
-    if (p->n_wg < 1) p->n_wg = 1;
-    const int64_t cap = (int64_t)p->n_wg * MM_HEAVY_UNITS * MM_R;      // slices the persistent grid holds per stream
-    if (hv.n_rows > cap) {      // more heavy rows than accumulators: the pair panel is not used
-        p->heavy.on = false;
-        return CSRK_OK;
+    // row lengths -> the threshold that leaves at most HR_MAXG * 512 rows (and, unless forced, pays for its sweeps of B)
+    std::vector<int64_t> len((size_t)m->nrows);
+    {
+        DevBuf dlen;
+        CSRK_TRY(dlen.alloc((size_t)m->nrows * 8));
+        hr_len_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>((const P *)m->d_rowptrs, m->nrows, dlen.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipMemcpyAsync(len.data(), dlen.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
     }
-    int64_t slice_len = MM_SLICE;
-    for (;; slice_len *= 2) {
-        int64_t cnt = 0, pmax = 0;
-        for (int32_t h = 0; h < hv.n_rows; h++) {
-            const int64_t P = len[(size_t)h] > slice_len ? ceil_div(len[(size_t)h], slice_len) : 1;
-            cnt += P;
-            pmax = std::max(pmax, P);
-        }
-        if ((cnt <= cap && pmax < 65536) || slice_len > (1ll << 40)) break;
-    }
-    std::vector<HeavySlice> sl;
-    std::vector<int32_t> first((size_t)hv.n_rows + 1);
-    for (int32_t h = 0; h < hv.n_rows; h++) {
-        first[(size_t)h] = (int32_t)sl.size();
-        const int32_t P = (int32_t)(len[(size_t)h] > slice_len ? ceil_div(len[(size_t)h], slice_len) : 1);
-        for (int32_t q = 0; q < P; q++) sl.push_back(HeavySlice{h, q, P});
-    }
-    first[(size_t)hv.n_rows] = (int32_t)sl.size();
-    p->n_slices = (int64_t)sl.size();
-    CSRK_TRY(p->slice.alloc(sl.size() * sizeof(HeavySlice)));
-    CSRK_TRY(p->slice_first.alloc(first.size() * 4));
-    CSRK_HIP(hipMemcpyAsync(p->slice.p, sl.data(), sl.size() * sizeof(HeavySlice), hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(p->slice_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipStreamSynchronize(s));      // `sl`, `first` are host temporaries
-    return CSRK_OK;
-}
-
-// the columns the light rows reference most, by popularity (plan time: a sampled count on the device, the ranking of
-// the few thousand candidates on the host)
-static int build_hot_columns(Matrix *m, SpmmPlan *p)
-{
-    p->hot_tried = true;
-    if (m->ncols <= 0 || m->nnz <= 0 || p->n_segs == 0) return CSRK_OK;
-    DevBuf cnt;
-    CSRK_TRY(cnt.alloc((size_t)m->ncols * 4));
-    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)m->ncols * 4, nullptr));
-    const int64_t row_stride = m->nnz > (1ll << 25) ? m->nnz >> 25 : 1;
-    const int64_t units = ceil_div((int64_t)m->nrows, row_stride);
-    const unsigned g = (unsigned)ceil_div(units * MM_G, 256);
-    const int32_t hmin = p->heavy.on ? p->heavy.min_entries : 0;
-    if (m->ptr64)
-        mm_col_count_kernel<int64_t><<<g, 256>>>((const int64_t *)m->d_rowptrs, m->d_colinds, m->nrows, row_stride, hmin, cnt.as<int32_t>());
-    else
-        mm_col_count_kernel<int32_t><<<g, 256>>>((const int32_t *)m->d_rowptrs, m->d_colinds, m->nrows, row_stride, hmin, cnt.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    std::vector<int32_t> c((size_t)m->ncols);
-    CSRK_HIP(hipMemcpy(c.data(), cnt.p, (size_t)m->ncols * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> cand;
-    for (int32_t j = 0; j < m->ncols; j++)
-        if (c[(size_t)j] >= 2) cand.push_back(j);
-    const size_t keep = std::min(cand.size(), (size_t)MM_HOT_MAX);
-    auto hotter = [&](int32_t a, int32_t b) { return c[(size_t)a] != c[(size_t)b] ? c[(size_t)a] > c[(size_t)b] : a < b; };
-    std::partial_sort(cand.begin(), cand.begin() + (std::ptrdiff_t)keep, cand.end(), hotter);
-    cand.resize(keep);
-    p->hot_sorted = std::move(cand);
-    return CSRK_OK;
-}
-
-static int encode_hot_columns(Matrix *m, SpmmPlan *p, int32_t n_hot)
-{
-    DevBuf slot_of;
-    CSRK_TRY(slot_of.alloc((size_t)m->ncols * 4));
-    CSRK_HIP(hipMemsetAsync(slot_of.p, 0xff, (size_t)m->ncols * 4, nullptr));
-    CSRK_HIP(hipDeviceSynchronize());      // earlier launches (any stream) may still read the old tables
-    CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
-    CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, p->hot_sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, nullptr));
-    if (!p->ci_hot.p) CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
-    mm_slot_scatter_kernel<<<(unsigned)ceil_div(n_hot, 256), 256>>>(p->hot_cols.as<int32_t>(), n_hot, slot_of.as<int32_t>());
+    const int64_t floor_len = force ? 256 : 512;                            // shorter rows never pay for a register slot
+    for (int32_t r = 0; r < m->nrows; r++)
+        if (len[(size_t)r] >= floor_len) cand.push_back(r);
+    if (cand.empty()) return CSRK_OK;
+    std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return len[(size_t)a] != len[(size_t)b] ? len[(size_t)a] > len[(size_t)b] : a < b; });
+    // Every row group sweeps all of B once (G n_cols rows of B staged in all), tile by tile, whatever it finds there: a
+    // group costs its tiles (staging, a barrier, a partial batch per wavefront) plus ~21 ps per entry, and saves the ~63 ps
+    // per entry of the light-row kernel.  Measured on the BASELINE matrix (2M columns): the second group of 512 rows
+    // (4.9 M entries... see DESIGN.md section 7) pays, the third and fourth (2 M each) do not.  Take row groups, longest
+    // rows first, while the group's entries are at least 1.25 x the rows of B it stages.
+    int G = 0;
+    int64_t nnz_h = 0;
+    size_t taken = 0;
+    const char *genv = getenv("CSRK_SPMM_HEAVY_GROUPS");
+    const int g_forced = genv ? atoi(genv) : 0;
+    while (G < HR_MAXG && taken < cand.size()) {
+        const size_t end = std::min(cand.size(), taken + (size_t)HR_ROWS);
+        int64_t gn = 0;
+        for (size_t c = taken; c < end; c++) gn += len[(size_t)cand[c]];
+        const bool pays = gn * 4 >= 5 * (int64_t)m->ncols;
+        if (getenv("CSRK_PLAN_TRACE"))
+            fprintf(stderr, "[csrk spmm plan] heavy row group %d: rows %zu..%zu (lengths %lld..%lld), %lld entries, %s\n", G, taken, end,
+                    (long long)len[(size_t)cand[taken]], (long long)len[(size_t)cand[end - 1]], (long long)gn, pays ? "pays" : "does not pay");
+        if (g_forced > 0 ? G >= g_forced : (!pays && !(force && G == 0))) break;
+        nnz_h += gn;
+        taken = end;
+        G++;
+    }
+    if (G == 0) return CSRK_OK;
+    // the threshold is a row LENGTH (the light path skips rows by length): rows as long as the last one taken come along
+    // when they fit, else the threshold moves up to the next length
+    int64_t hmin = len[(size_t)cand[taken - 1]];
+    size_t n = taken;
+    while (n < cand.size() && len[(size_t)cand[n]] >= hmin) n++;
+    if (n > (size_t)G * HR_ROWS) {
+        hmin++;
+        n = taken;
+        while (n > 0 && len[(size_t)cand[n - 1]] < hmin) n--;
+    }
+    if (n == 0 || hmin > INT32_MAX) return CSRK_OK;
+    cand.resize(n);
+    nnz_h = 0;
+    for (int32_t r : cand) nnz_h += len[(size_t)r];
+    while (G > 1 && (size_t)(G - 1) * HR_ROWS >= n) G--;
+    // G R workgroups, one per CU; a range needs a tile; with R a multiple of 8 the G workgroups of a column range sit
+    // side by side on one XCD (spmm_hrows_kernel)
+    const int64_t n_tiles = ceil_div((int64_t)m->ncols, HR_TILE);
+    int R = (int)std::min<int64_t>(std::max(cus, G) / G, n_tiles);
+    if (R >= 8) R = R / 8 * 8;
+    const int64_t n_buckets = n_tiles * G * HR_WAVES;
+    if (n_buckets >= (1ll << 30)) return CSRK_OK;                           // (keys are 32-bit)
+    if (!force && n_buckets * 8 > nnz_h * 12) return CSRK_OK;               // the bucket table would outweigh the stream
+    size_t mfree = 0, mtotal = 0;
+    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
+    if ((size_t)nnz_h * 40 + (size_t)n_buckets * 8 + (64u << 20) > mfree) return CSRK_OK;
+    // places: rank i (longest first) -> group i % G, then wavefront and slot round robin, so every wavefront of every
+    // group holds the same mix of lengths
+    std::vector<int32_t> code(n);
+    std::vector<int64_t> off(n + 1);
+    for (size_t i = 0; i < n; i++) {
+        const int32_t g = (int32_t)(i % (size_t)G), j = (int32_t)(i / (size_t)G);
+        code[i] = (g << 9) | ((j % HR_WAVES) << 5) | (j / HR_WAVES);
+        off[i] = i ? off[i - 1] + len[(size_t)cand[i - 1]] : 0;
+    }
+    off[n] = off[n - 1] + len[(size_t)cand[n - 1]];
+    DevBuf doff, key, pay, val;
+    CSRK_TRY(p->hr_rows.alloc(n * 4));
+    CSRK_TRY(p->hr_code.alloc(n * 4));
+    CSRK_TRY(doff.alloc((n + 1) * 8));
+    CSRK_TRY(key.alloc((size_t)nnz_h * 4));
+    CSRK_TRY(pay.alloc((size_t)nnz_h * 4));
+    CSRK_TRY(val.alloc((size_t)nnz_h * 8));
+    CSRK_TRY(p->hr_bp.alloc((size_t)(n_buckets + 1) * 8));
+    CSRK_TRY(p->hr_idx.alloc((size_t)(nnz_h + HR_PAD) * 4));
+    CSRK_TRY(p->hr_vals.alloc((size_t)(nnz_h + HR_PAD) * 8));
+    CSRK_HIP(hipMemsetAsync(p->hr_idx.as<uint32_t>() + nnz_h, 0, HR_PAD * 4, s));      // (the batches of four read a little past a bucket)
+    CSRK_HIP(hipMemsetAsync(p->hr_vals.as<double>() + nnz_h, 0, HR_PAD * 8, s));
+    CSRK_HIP(hipMemcpyAsync(p->hr_rows.p, cand.data(), n * 4, hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(p->hr_code.p, code.data(), n * 4, hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(doff.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+#define EMIT(VT)                                                                                                       \
+    hr_emit_kernel<P, VT><<<(unsigned)n, 256, 0, s>>>((const P *)m->d_rowptrs, m->d_colinds, m->d_values, p->hr_rows.as<int32_t>(), \
+                                                      p->hr_code.as<int32_t>(), doff.as<int64_t>(), G, key.as<int32_t>(),  \
+                                                      pay.as<int32_t>(), val.as<double>())
+    if (m->val_type == CSRK_VAL_F64) EMIT(CSRK_VAL_F64);
+    else if (m->val_type == CSRK_VAL_F32) EMIT(CSRK_VAL_F32);
+    else EMIT(CSRK_VAL_NONE);
+#undef EMIT
     CSRK_LAUNCH_CHECK();
-    mm_encode_hot_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256>>>(m->d_colinds, m->nnz, slot_of.as<int32_t>(), p->ci_hot.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipDeviceSynchronize());      // slot_of is released here; the product may run on another stream
-    p->n_hot = n_hot;
+    CSRK_TRY(stable_sort_records_f64(key.as<int32_t>(), pay.as<int32_t>(), val.as<double>(), nnz_h, (int32_t)n_buckets, 1 << 16,
+                                     p->hr_bp.as<int64_t>(), (int32_t *)p->hr_idx.p, p->hr_vals.as<double>(), s));
+    // column ranges: whole tiles, balanced by entries plus a fixed cost per tile (staging + barrier ~ 200 entries' worth)
+    std::vector<int64_t> tot((size_t)n_tiles + 1);
+    {
+        DevBuf dt;
+        CSRK_TRY(dt.alloc((size_t)(n_tiles + 1) * 8));
+        hr_tile_totals_kernel<<<(unsigned)ceil_div(n_tiles + 1, 256), 256, 0, s>>>(p->hr_bp.as<int64_t>(), (int32_t)n_tiles, G * HR_WAVES,
+                                                                                 dt.as<int64_t>());
+        CSRK_LAUNCH_CHECK();
+        CSRK_HIP(hipMemcpyAsync(tot.data(), dt.p, (size_t)(n_tiles + 1) * 8, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+    }
+    const int64_t tile_cost = 200 * (int64_t)G;
+    const double total_cost = (double)nnz_h + (double)tile_cost * (double)n_tiles;
+    std::vector<int32_t> range((size_t)R + 1);
+    range[0] = 0;
+    {
+        int64_t t = 0;
+        for (int q = 1; q < R; q++) {
+            const double goal = total_cost * q / R;
+            while (t < n_tiles && (double)tot[(size_t)t + 1] + (double)tile_cost * (double)(t + 1) <= goal) t++;
+            // every range keeps at least one tile, and leaves one for each range after it
+            t = std::max<int64_t>(t, (int64_t)range[(size_t)q - 1] + 1);
+            t = std::min<int64_t>(t, n_tiles - (R - q));
+            range[(size_t)q] = (int32_t)t;
+        }
+    }
+    range[(size_t)R] = (int32_t)n_tiles;
+    CSRK_TRY(p->hr_range.alloc(((size_t)R + 1) * 4));
+    CSRK_HIP(hipMemcpyAsync(p->hr_range.p, range.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(p->hr_part.alloc((size_t)R * G * HR_ROWS * HR_KC * 8));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmm_hrows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HR_LDS));
+    CSRK_HIP(hipFuncSetAttribute((const void *)spmm_hrows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HR_LDS));
+    CSRK_HIP(hipStreamSynchronize(s));      // host vectors of the async copies; the temporaries are freed on return
+    p->hr_on = true;
+    p->hr_min = (int32_t)hmin;
+    p->hr_n = (int32_t)n;
+    p->hr_G = G;
+    p->hr_R = R;
+    p->hr_tiles = (int32_t)n_tiles;
+    p->hr_nnz = nnz_h;
+    (void)k;
     return CSRK_OK;
 }
 
@@ -654,12 +733,7 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     CSRK_REQUIRE(k >= 0 && ldb >= k && ldc >= k, "bad panel geometry k=%d ldb=%lld ldc=%lld", k, (long long)ldb, (long long)ldc);
     if (m->nrows == 0 || k == 0) return CSRK_OK;
     SpmmPlan *p;
-    Tier0View hv;
-    const char *env = getenv("CSRK_SPMM_HEAVY");
-    // heavy-row blocking pays when the B rows a block needs fit in L2 but B as a whole does not
-    if (!(env && env[0] == '0') && !m->spmm_plan && ((int64_t)m->ncols * k * 8 > (64ll << 20) || (env && env[0] == '1')))
-        CSRK_TRY(spmv_tier0_view(m, &hv));
-    // The launch group below shares the plan's partial-panel buffers (hpart, part): the per-handle lock is held
+    // The launch group below shares the plan's partial-panel buffers (hr_part, part): the per-handle lock is held
     // across it, as spmv_dispatch does, so that concurrent callers are ordered by the stream instead of interleaving
     // (csrk.h: calls on the same handle serialise).
     std::lock_guard<std::mutex> lk(m->mu);
@@ -667,10 +741,13 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     if (!m->spmm_plan) {
         SpmmPlan *np = new (std::nothrow) SpmmPlan();
         CSRK_REQUIRE(np, "out of host memory");
-        if (hv.on) np->heavy = hv;
         // default stream + completion before use: see the caching allocator's contract (common.h)
         int rc = CSRK_OK;
-        if (np->heavy.on) rc = build_heavy_slices(m, np, nullptr);      // (may turn the heavy path off: before the segment count)
+        // the heavy-row form pays when B as a whole does not fit the caches (CSRK_SPMM_HEAVY=0 / 1: never / always)
+        const char *env = getenv("CSRK_SPMM_HEAVY");
+        const bool force = env && env[0] == '1';
+        if (!(env && env[0] == '0') && ((int64_t)m->ncols * k * 8 > (64ll << 20) || force))
+            rc = m->ptr64 ? build_hrows<int64_t>(m, np, k, force, nullptr) : build_hrows<int32_t>(m, np, k, force, nullptr);
         if (rc == CSRK_OK) rc = m->ptr64 ? build_mm_plan<int64_t>(m, np, nullptr) : build_mm_plan<int32_t>(m, np, nullptr);
         if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
         if (rc != CSRK_OK) {
@@ -680,75 +757,34 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
         m->spmm_plan = np;
     }
     p = m->spmm_plan;
-    // a wider panel than any before needs larger partial buffers: earlier launches (any stream) may still be using the
-    // old blocks, which DevBuf::alloc returns to the pool at once -- wait for the device first
-    const bool grow_h = p->heavy.on && p->hpart_k < k, grow_p = p->n_multi > 0 && p->part_k < k;
-    if ((grow_h && p->hpart.p) || (grow_p && p->part.p)) CSRK_HIP(hipDeviceSynchronize());
-    if (grow_h) {
-        CSRK_TRY(p->hpart.alloc((size_t)p->n_slices * MM_STREAMS * k * 8));
-        p->hpart_k = k;
-    }
+    // a wider panel than any before needs a larger partial buffer: earlier launches (any stream) may still be using the
+    // old block, which DevBuf::alloc returns to the pool at once -- wait for the device first
+    const bool grow_p = p->n_multi > 0 && p->part_k < k;
+    if (grow_p && p->part.p) CSRK_HIP(hipDeviceSynchronize());
     if (grow_p) {           // some row is split: partial panels needed
         CSRK_TRY(p->part.alloc((size_t)p->n_multi * k * 8));
         p->part_k = k;
     }
     const bool full4 = (k % 4) == 0;
-    if (p->heavy.on) {
-        const Tier0View &hvw = p->heavy;
-        const unsigned wgs = (unsigned)(MM_STREAMS * p->n_wg);
-        const unsigned rgrid = (unsigned)ceil_div((int64_t)hvw.n_rows * WAVE, 256);
-#define HEAVY(PP, F4)                                                                                                  \
-    spmm_heavy_kernel<PP, F4><<<wgs, MM_HEAVY_THREADS, 0, s>>>((const PP *)hvw.rp, hvw.ci, hvw.vs, dB, k, ldb,         \
-                                                              hvw.n_rows, hvw.n_blocks, p->slice.as<HeavySlice>(),     \
-                                                              p->n_slices, p->n_wg, p->hpart.as<double>())
-        if (hvw.p64) {
-            if (full4) HEAVY(int64_t, true);
-            else HEAVY(int64_t, false);
-        } else {
-            if (full4) HEAVY(int32_t, true);
-            else HEAVY(int32_t, false);
+    if (p->hr_on) {
+        const unsigned wgs = (unsigned)(p->hr_G * p->hr_R);
+        const unsigned rgrid = (unsigned)ceil_div((int64_t)p->hr_n * WAVE, 256);
+        for (int32_t c0 = 0; c0 < k; c0 += HR_KC) {        // 64 panel columns per launch (stream order: hr_part is reused)
+            const int32_t kc = k - c0 < HR_KC ? k - c0 : HR_KC;
+#define HROWS(EVEN)                                                                                                    \
+    spmm_hrows_kernel<EVEN><<<wgs, HR_THREADS, HR_LDS, s>>>(p->hr_bp.as<int64_t>(), p->hr_idx.as<uint32_t>(),             \
+                                                           p->hr_vals.as<double>(), dB + c0, kc, ldb, m->ncols,          \
+                                                           p->hr_range.as<int32_t>(), p->hr_G, p->hr_part.as<double>())
+            if (kc % 2 == 0) HROWS(true);
+            else HROWS(false);
+#undef HROWS
+            CSRK_LAUNCH_CHECK();
+            spmm_hrows_reduce_kernel<<<rgrid, 256, 0, s>>>(p->hr_rows.as<int32_t>(), p->hr_code.as<int32_t>(), p->hr_n, p->hr_G, p->hr_R,
+                                                          kc, p->hr_part.as<double>(), dC + c0, ldc);
+            CSRK_LAUNCH_CHECK();
         }
-#undef HEAVY
-        spmm_heavy_reduce_kernel<<<rgrid, 256, 0, s>>>(p->slice_first.as<int32_t>(), hvw.row_list, hvw.n_rows, k,
-                                                      p->hpart.as<double>(), dC, ldc);
-        CSRK_LAUNCH_CHECK();
     }
     if (p->n_segs == 0) return CSRK_OK;
-    // opt-in (CSRK_SPMM_HOT=1; k even, >= 16 B rows fit 128 KiB): the light rows with the hottest B rows in LDS
-    int32_t want_hot = 0;
-    {
-        const char *env = getenv("CSRK_SPMM_HOT");
-        if (env && env[0] == '1' && k % 2 == 0 && (int64_t)k * 8 * 16 <= MM_LDS_BYTES) {
-            if (!p->hot_tried) CSRK_TRY(build_hot_columns(m, p));
-            want_hot = (int32_t)std::min<int64_t>((int64_t)p->hot_sorted.size(), MM_LDS_BYTES / ((int64_t)k * 8));
-            if (want_hot < 16) want_hot = 0;
-            if (want_hot && p->n_hot != want_hot) CSRK_TRY(encode_hot_columns(m, p, want_hot));
-        }
-    }
-    if (want_hot) {
-        static std::once_flag once;
-        static hipError_t attr_err = hipSuccess;
-        std::call_once(once, [] {
-            for (const void *f : {(const void *)spmm_lseg_kernel<CSRK_VAL_F64>, (const void *)spmm_lseg_kernel<CSRK_VAL_F32>,
-                                  (const void *)spmm_lseg_kernel<CSRK_VAL_NONE>}) {
-                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MM_LDS_BYTES);
-                if (e != hipSuccess) attr_err = e;
-            }
-        });
-        CSRK_HIP(attr_err);
-        int cus = 0;
-        CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-        const unsigned lgrid = (unsigned)std::min<int64_t>(cus > 0 ? cus : 256, ceil_div(p->n_segs, MM_L_UNITS));
-        const size_t lds = (size_t)want_hot * k * 8;
-#define GOH(VT)                                                                                                        \
-    spmm_lseg_kernel<VT><<<lgrid, MM_L_THREADS, lds, s>>>(p->ci_hot.as<int32_t>(), m->d_values, dB, k, ldb, dC, ldc,     \
-                                                         p->seg.as<SegDesc>(), p->n_segs, p->part.as<double>(),        \
-                                                         p->hot_cols.as<int32_t>(), want_hot)
-        if (m->val_type == CSRK_VAL_F64) GOH(CSRK_VAL_F64);
-        else if (m->val_type == CSRK_VAL_F32) GOH(CSRK_VAL_F32);
-        else GOH(CSRK_VAL_NONE);
-#undef GOH
-    } else {
     const unsigned grid = (unsigned)ceil_div(p->n_segs * MM_G, 256);
 #define GO(VT, F4)                                                                                                     \
     spmm_seg_kernel<VT, F4><<<grid, 256, 0, s>>>(m->d_colinds, m->d_values, dB, k, ldb, dC, ldc, p->seg.as<SegDesc>(),   \
@@ -764,7 +800,6 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
         else GO(CSRK_VAL_NONE, false);
     }
 #undef GO
-    }
     CSRK_LAUNCH_CHECK();
     if (p->n_multi > 0) {
         spmm_fixup_kernel<<<(unsigned)ceil_div((int64_t)p->n_split * WAVE, 256), 256, 0, s>>>(

@@ -589,6 +589,16 @@ int stable_sort_payload_by_key(const int32_t *keys, const int32_t *payload, int6
                                                        payload_range, ptrs.as<int64_t>(), out_payload, nullptr, s);
 }
 
+// Stable sort of (key, int32 payload, float64 value) records by key in [0, key_range): the sorted payloads and values,
+// and the run start of every key in out_ptr[0 .. key_range] (the COO-ingest form of the radix passes).  Exposed to
+// spmm_dense.hip (the heavy rows' entries bucketed by (column tile, row group, wavefront)).
+int stable_sort_records_f64(const int32_t *keys, const int32_t *payload, const double *vals, int64_t n, int32_t key_range,
+                            int64_t payload_range, int64_t *out_ptr, int32_t *out_payload, double *out_vals, hipStream_t s)
+{
+    return sort_records<int64_t, CSRK_VAL_F64, false>(keys, payload, vals, (const int64_t *)nullptr, 0, n, key_range,
+                                                      payload_range, out_ptr, out_payload, out_vals, s);
+}
+
 // Transpose `a` into a new matrix.  Exposed to the other translation units (spgemm_abt,
 // order_columns).
 int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s)

@@ -694,47 +694,58 @@ def test_spmm_dense(k):
     assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
 
 
-@pytest.mark.parametrize('k,dtype', [(64, np.float64), (6, np.float64), (130, np.float32), (512, np.float64)])
-def test_spmm_dense_hot_rows_in_lds(k, dtype, monkeypatch):
+@pytest.mark.parametrize('k,dtype,groups', [(64, np.float64, 0), (6, np.float64, 2), (130, np.float32, 0), (200, None, 4)])
+def test_spmm_dense_heavy_rows_in_registers(k, dtype, groups, monkeypatch):
     """
-    CSRK_SPMM_HOT=1 (north_star's "dense B tile staged in LDS"): the light rows' most referenced B rows
-    are held in LDS by a persistent kernel.  Same sums in the same order as the default kernel: the panel must come out
-    bit for bit equal to it (and to the oracle within the usual bound), for panel widths that fill a 64-column chunk,
-    fall short of it, exceed it, and leave only 32 LDS rows.
+    The heavy-row form of the dense-panel SpMM (DESIGN.md section 7, north_star's "dense B tile staged in LDS";
+    spmm_hrows_kernel): B tiles through LDS, the rows' accumulators in dynamically indexed registers.  Forced on for a
+    small matrix (CSRK_SPMM_HEAVY=1), with one, two and four row groups, panel widths that fill a 64-column launch,
+    fall short of it and need several, f64 / f32 / absent values, columns sorted or not, a last tile that is cut by
+    the matrix' width, and heavy rows that leave whole tiles empty.  Checked against the light-row kernel alone
+    (CSRK_SPMM_HEAVY=0) and the oracle; run twice: the bits must repeat.
     """
     from oracle import oracle as O
     from csr_amd.kernels import hip as K
+    from csr_amd import CSR
     rng = np.random.default_rng(1000 + k)
-    n, ncols = 20000, 9000
-    lens = np.minimum((rng.pareto(1.0, n) * 4).astype(np.int64), 3000)
-    # a popular set of columns, so that LDS slots are worth having: Zipf-like column choice, distinct inside a row
-    pop = rng.permutation(ncols)
+    n, ncols = 6000, 9001 + k
+    lens = np.minimum((rng.pareto(1.0, n) * 4).astype(np.int64), 300)
+    heavy = rng.choice(n, 1300, replace=False)
+    lens[heavy] = rng.integers(256, 2500, size=len(heavy))
+    lens[heavy[0]] = ncols                                   # a full row
     rp = np.zeros(n + 1, np.int32)
     rp[1:] = np.cumsum(lens)
     ci = np.empty(int(rp[-1]), np.int32)
     for i in range(n):
         m = int(lens[i])
         if m:
-            draw = np.unique(np.minimum((np.exp(rng.uniform(0, np.log(ncols), size=2 * m + 8)) - 1).astype(np.int64), ncols - 1))
-            draw = draw[:m] if len(draw) >= m else np.concatenate([draw, np.setdiff1d(np.arange(ncols), draw)[:m - len(draw)]])
-            ci[rp[i]:rp[i + 1]] = np.sort(pop[draw])
-    from csr_amd import CSR
-    A = CSR(n, ncols, int(rp[-1]), rp, ci, rng.uniform(-1, 1, int(rp[-1])).astype(dtype), _cast=False)
+            lo = 0 if i % 3 or m > ncols - 2000 else 2000    # (some rows never touch the first tiles)
+            c = lo + rng.choice(ncols - lo, m, replace=False)
+            ci[rp[i]:rp[i + 1]] = np.sort(c) if i % 2 else c
+    vals = None if dtype is None else rng.uniform(-1, 1, int(rp[-1])).astype(dtype)
+    A = CSR(n, ncols, int(rp[-1]), rp, ci, vals, _cast=False)
     B = rng.uniform(-1, 1, (ncols, k))
+    if groups:
+        monkeypatch.setenv('CSRK_SPMM_HEAVY_GROUPS', str(groups))
     outs = {}
     for mode in ('0', '1'):
-        monkeypatch.setenv('CSRK_SPMM_HOT', mode)
+        monkeypatch.setenv('CSRK_SPMM_HEAVY', mode)
         h = K.to_handle(A)
         try:
             outs[mode] = K.mult_dense(h, B)
             again = K.mult_dense(h, B)
         finally:
             K.release_handle(h)
+            K.invalidate(A)                                  # (the next mode must build its own plan, not find this one cached)
         assert np.array_equal(outs[mode], again)
-    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, A.values, B)
-    bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
-    assert np.all(np.abs(outs['1'] - ref) <= 1e-12 * bound + 1e-300)
-    assert np.array_equal(outs['1'].view(np.int64), outs['0'].view(np.int64))
+    v64 = np.ones(A.nnz) if vals is None else vals.astype(np.float64)
+    ref = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, v64, B)
+    bound = O.spmm_dense(A.nrows, A.rowptrs, A.colinds, np.abs(v64), np.abs(B))
+    for mode in ('0', '1'):
+        assert np.all(np.abs(outs[mode] - ref) <= 1e-12 * bound + 1e-300), mode
+    light = lens < 256                                       # rows the heavy form never takes: same kernel, same bits
+    assert np.array_equal(outs['1'][light].view(np.int64), outs['0'][light].view(np.int64))
+    assert not np.array_equal(outs['1'].view(np.int64), outs['0'].view(np.int64)) or k < 2      # (the heavy form did run)
 
 
 # ---- COO ingest on the device ----------------------------------------------------------------------------
@@ -835,7 +846,7 @@ def test_unit_center_long_rows_vs_oracle(dtype):
 
 @pytest.mark.parametrize('k', [64, 20])
 def test_spmm_dense_heavy_rows_blocked(k, monkeypatch):
-    "heavy rows served from the SpMV plan's column-block-major panel (forced on for this small matrix)"
+    "heavy rows in the register-accumulator form (forced on for this small matrix), split light rows beside them"
     from oracle import oracle as O
     from csr_amd.kernels import hip as K
     monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
@@ -859,7 +870,7 @@ def test_spmm_dense_heavy_rows_blocked(k, monkeypatch):
 
 
 def test_spmm_survives_spmv_algo_change(monkeypatch):
-    "the SpMM plan borrows the SpMV plan's panel: changing the SpMV algorithm must not leave it dangling"
+    "the SpMM plan is independent of the SpMV plan: changing the SpMV algorithm between products changes nothing"
     from oracle import oracle as O
     from csr_amd.kernels import hip as K
     monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
