@@ -142,19 +142,6 @@ void drain_user_streams(Matrix *m);
 // Create an owning matrix with freshly allocated (uninitialised) device arrays.
 int new_matrix(int32_t nrows, int32_t ncols, int64_t nnz, int ptr64, int val_type, Matrix **out);
 
-// View of the SpMV plan's tier-0 panel (heavy rows re-sorted column-block-major, spmv.hip), shared with
-// the dense-panel SpMM.  Valid while the handle lives and its SpMV algorithm is not changed.
-struct Tier0View {
-    bool on = false, p64 = false;
-    int32_t n_rows = 0, n_blocks = 0, block_cols = 0, min_entries = 0;
-    int64_t pairs = 0, nnz = 0;
-    const void *rp = nullptr;          // int32/int64 [pairs + 1], pair index = block * n_rows + h
-    const int32_t *ci = nullptr;       // absolute column of every entry of M'
-    const double *vs = nullptr;
-    const int32_t *row_list = nullptr; // original row id of heavy row h
-};
-int spmv_tier0_view(Matrix *m, Tier0View *out);   // builds the SpMV plan (with the split) if needed
-
 // ---- shared device-side primitives (scan.hip) --------------------------------------------
 // Exclusive prefix sum of n counts into out[0..n] (out[n] = total); in-place allowed when
 // in == out (then out needs n+1 slots and in[n] is ignored).  T in {int32_t, int64_t}.

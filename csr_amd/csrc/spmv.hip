@@ -80,7 +80,7 @@ __device__ __forceinline__ double ordered_sum(const double *p, int s, int e)
 // One column-blocked panel: the entries of a set of long rows re-sorted block-major into a matrix
 // M' whose rows are (column block, long row) pairs; see "long rows, panel form" below.
 struct Panel {
-    bool on = false, p64 = false, window = false;
+    bool on = false, p64 = false;
     int32_t cb = 0, nb = 0, nrow = 0;            // block width (columns), blocks, long rows in this tier
     int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
     DevBuf row_list;                             // int32[nrow]: original row ids, ascending
@@ -107,14 +107,13 @@ struct AccPanel {
 };
 
 // A light stream (see "short rows: the light stream"): a private tiled copy of a set of rows ("runs") plus
-// the tables the one-wavefront-per-tile kernel needs.  Two instances per plan: the short rows of the matrix,
-// and tier 1 (runs = (column block, row) pairs, output = the pair partials).
+// the tables the one-wavefront-per-tile kernel needs.
 struct LightStream {
     bool on = false;
     int64_t n_tiles = 0;
     int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
     unsigned grid = 0;
-    DevBuf vals, idx, rowids, tile_base, carry_idx, carry_row, carry_val;
+    DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
     // dense rows (build_light_stream): EVERY row of the view has a run -- a row without entries holds one padding entry --
     // so run k is row k: no row-id table (`rowids` stays empty), no gaps to clear
     bool dense = false;
@@ -123,9 +122,6 @@ struct LightStream {
     int64_t n_cold = 0;
     int32_t n_stage_blk = 0, stage_w = 0;
     DevBuf xg, a_col, a_dst, blk_start;
-    // tile-major staging (build_cold_stage, default): the staged values of tile t are xg[tile_cold[t] .. tile_cold[t + 1]),
-    // and a cold entry's index word holds its offset inside that range; empty: positions are absolute (round-major form)
-    DevBuf tile_cold;
     // round-in-LDS staging (build_cold_stage, LS_RND): workgroup b walks rounds wg_round0[b] .. wg_round0[b + 1]; round r =
     // tiles round_tile0[r] .. round_tile0[r + 1] (at most `stage_tiles`), whose staged values xg[round_start[r] ..
     // round_start[r + 1]) the workgroup copies into LDS; a cold entry's index word holds its offset inside that range
@@ -158,22 +154,17 @@ struct SpmvPlan {
     int32_t n_hot_lds = 0;        // slots [0, n_hot_lds) hold the most referenced columns (kept in LDS by the light stream)
     int32_t hot_slots = 0;
     double hot_cover = 0.0;       // sampled fraction of the tile kernel's entries on packed columns
-    DevBuf ci_hot;      // int32[nnz]: colinds with the packed columns renumbered (tile kernel only: built when the
-                        // light stream is not)
-    DevBuf hot_slot;    // int32[ncols]: slot of a packed column, -1 otherwise (kept until the stream / ci_hot is built)
+    DevBuf hot_slot;    // int32[ncols]: slot of a packed column, -1 otherwise (kept until the light stream is built)
     DevBuf hot_cols;    // int32[n_hot]: column of each slot
     DevBuf xh;          // double[n_hot]
-    Panel tier[2];      // [0] heavy rows, 4096-column blocks, x window in LDS (pair form: built only when
-                        // CSRK_SPMV_TIER0=pairs or when the dense-panel SpMM asks for it); [1] mid rows,
-                        // 262144-column blocks, x window kept in L2 by block-major, XCD-aware scheduling
+    Panel tier1;        // mid rows: (column block, row) pairs over 262144-column blocks, the x window kept in L2 by
+                        // block-major, XCD-aware scheduling
     LightStream ls;                       // the rows that stay on the row-major path
-    LightStream t1s;                      // tier 1 as a stream of (column block, row) runs
     std::vector<int32_t> t1_rows;         // tier-1 rows (ascending) and their entries: build_tiers
     int64_t t1_nnz = 0;
-    std::vector<AccPanel *> acc;          // tier 0, accumulator form (default)
-    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths: source of either form
+    std::vector<AccPanel *> acc;          // tier 0: accumulator form, groups of <= ACC_MAXROWS rows
+    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths
     std::vector<int64_t> t0_lens;
-    int32_t view_min = 0;                 // row-length threshold of the pair-form panel handed to the SpMM
     // vector
     int64_t n_segs = 0;
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
@@ -188,18 +179,10 @@ struct SpmvPlan {
     int prof_calls = 0;
     int prof_mask = 0xf;          // channels that get event pairs (csrk_spmv_profile_channels)
     bool prof_this = false;       // the launch group in progress is being timed
-    // tier 1 beside tier 0 (see "the two tiers side by side"): the accumulator kernel runs on acc_wgs < #CUs workgroups
-    // and the pair kernel of tier 1 on a side stream takes the CUs it leaves free
-    bool t1_beside = false;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~SpmvPlan()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         for (AccPanel *a : acc) delete a;
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -231,17 +214,21 @@ int64_t spmv_plan_bytes(const SpmvPlan *p)
     {
         auto add = [&](const DevBuf &b) { plan_bytes += (int64_t)b.bytes; };
         for (const DevBuf *b : {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut,
-                                &p->heavy_row, &p->ci_hot, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
+                                &p->heavy_row, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
             add(*b);
-        for (const Panel &t : p->tier)
+        {
+            const Panel &t = p->tier1;
             for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx})
                 add(*b);
+        }
         for (const AccPanel *ap : p->acc)
             for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
-        for (const LightStream *l : {&p->ls, &p->t1s})
-            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_idx, &l->carry_row, &l->carry_val, &l->xg,
-                                    &l->a_col, &l->a_dst, &l->blk_start, &l->tile_cold, &l->round_start, &l->round_tile0, &l->wg_round0})
+        {
+            const LightStream *l = &p->ls;
+            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_row, &l->carry_val, &l->xg, &l->a_col,
+                                    &l->a_dst, &l->blk_start, &l->round_start, &l->round_tile0, &l->wg_round0})
                 add(*b);
+        }
     }
     return plan_bytes;
 }
@@ -358,20 +345,13 @@ constexpr int MERGE_PAIRS = MERGE_IPT / 2;
 
 // HEAVY: the path runs over the light view (rp = rp_light, nnz = nnz_light); a light entry index
 // jl maps to the actual entry jl + cut_cum[#cuts with cut_pos <= jl].
-//
-// HOT: hot-column pack.  `ci` is the plan's renumbered copy of colinds (a popular column reads
-// -1 - slot) and `xh` holds x[hot_cols[slot]], packed by hot_pack_kernel before this launch.  What
-// bounds this kernel on a power-law matrix is the x gathers that miss L2 (one 128-B line from the
-// Infinity Cache or HBM per 8-B value): with the columns in arbitrary order a
-// popular column shares its line with 15 unpopular ones, so the 4 MiB L2 holds ~30k popular columns;
-// packed, every cached line is 16 popular columns.
-template <class P, int VT, bool HEAVY, bool HOT>
+template <class P, int VT, bool HEAVY>
 __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
     int32_t nrows, int64_t nnz, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
     const int32_t *__restrict__ tile_cut, const int64_t *__restrict__ cut_pos,
-    const int64_t *__restrict__ cut_cum, int64_t nnz_total, const double *__restrict__ xh)
+    const int64_t *__restrict__ cut_cum, int64_t nnz_total)
 {
     // One LDS buffer: nn products (8 B each) followed by nr + 1 tile-relative row ends (4 B each);
     // nn + nr <= MERGE_ITEMS, so MERGE_ITEMS * 8 + 8 bytes always suffice (16.4 KB -> 8 tiles per CU).
@@ -459,12 +439,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
 #pragma unroll
     for (int u = 0; u < MERGE_PAIRS; u++) {
         const int k = 2 * (tid + u * MERGE_THREADS);
-        const double *a0 = x + c0[u], *a1 = x + c1[u];
-        if (HOT) {
-            a0 = c0[u] < 0 ? xh + ~c0[u] : a0;
-            a1 = c1[u] < 0 ? xh + ~c1[u] : a1;
-        }
-        const double t0 = p0[u] * *a0, t1 = p1[u] * *a1;
+        const double t0 = p0[u] * x[c0[u]], t1 = p1[u] * x[c1[u]];
         p0[u] = k < nn ? t0 : 0.0;
         p1[u] = k + 1 < nn ? t1 : 0.0;
         if ((u + 1) % MERGE_GATHER_PAIRS == 0 && u + 1 < MERGE_PAIRS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -681,23 +656,6 @@ __global__ void hot_slot_kernel(const int32_t *__restrict__ hot_cols, int32_t n_
     if (k < n_hot) slot[hot_cols[k]] = k;
 }
 
-__global__ void hot_remap_kernel(const int32_t *__restrict__ ci, int64_t nnz, const int32_t *__restrict__ slot_map,
-                                 int32_t *__restrict__ ci_hot)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    const int32_t c = ci[k], sl = slot_map[c];
-    ci_hot[k] = sl >= 0 ? ~sl : c;
-}
-
-// ---- long rows: cut out of the merge path ------------------------------------------------------
-// What limits SpMV on a power-law matrix is the x[col] gathers, not the 12 B/entry stream
-// (measured, DESIGN.md section 4: a gather served by L2 costs ~2.9 ps of chip time, one served by the
-// Infinity Cache ~14.5 ps, and every row with thousands of entries sweeps most of x).  Rows with at
-// least `cut` entries are therefore removed from the merge path -- the tile kernel runs on a light
-// view of the row pointers (rp_light + a cut table; colinds/values are not copied for it) -- and are
-// served by the column-blocked panels below.  Needs ascending columns inside those rows (checked at
-// plan time; otherwise no split).
 static int HEAVY_MIN = 2048;      // tier 0 threshold (CSRK_HEAVY_MIN)
 static int TIERB_MIN = 128;       // tier 1 threshold (CSRK_TIERB_MIN; 0 disables tier 1)
 
@@ -792,27 +750,16 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
     tile_cut[t] = lo;
 }
 
-// ---- long rows, panel form ---------------------------------------------------------------------
-// At plan time the long rows' entries are re-sorted column-block-major into a panel matrix M' whose
-// rows are (column block b, long row h) pairs; values are widened to float64.  Per call the
-// merge-tile algorithm runs over M' with tiles confined to one block; row sums of M' are the
-// per-(block, row) partials y'[b][h], reduced over b in block order by the panel_reduce kernels.
-// No float atomics: deterministic.
-//   tier 0 (rows >= 2048 entries, 46-64 % of a power-law matrix): blocks of 4096 columns; the
-//     workgroup copies the block's 32 KiB x window into LDS with coalesced 16-B loads (512 requests
-//     instead of 2048 gathers per tile) and multiplies from LDS.  A first version that only
-//     re-ordered the rows' pieces block-major (x window in L2) had an 88 % L2 hit rate and still ran
-//     at the chip's L1-miss request rate (~150-170 G 64-B requests/s): every gather is its own L2
-//     round trip, so the gathers themselves had to go.
-//   tier 1 (rows of 128..2047 entries): a (row, block) pair of 4096 columns would hold < 1 entry, so
-//     blocks are 262144 columns (2 MiB of x; 131072 until late in round 2) and x is gathered from global memory; tiles run
-//     block-major and block b is served only by workgroups with blockIdx % 8 == b % 8 (one XCD, so ONE
-//     L2 holds the window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.
-constexpr int PANEL_CB0 = 4096;
+// ---- mid rows, pair form (tier 1) ---------------------------------------------------------------
+// At plan time the rows' entries are re-sorted column-block-major into a panel matrix M' whose rows are (column block
+// b, row h) pairs; values are widened to float64.  Per call the merge-tile algorithm runs over M' with tiles confined
+// to one block; row sums of M' are the per-(block, row) partials y'[b][h], reduced over b in block order by the
+// epilogue.  No float atomics: deterministic.  Rows of 128 .. tier-0 threshold entries: a (row, block) pair of 4096
+// columns would hold < 1 entry, so blocks are 262144 columns (2 MiB of x) and x is gathered from global memory; tiles
+// run block-major and block b is served only by workgroups with blockIdx % 8 == b % 8 (one XCD, so ONE L2 holds the
+// window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.  (The longest rows had this form
+// too, with the x window in LDS, until the accumulator form below replaced it.)
 constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block, row) pairs of 131072 at the same kernel time, -9 us of partials)
-#ifndef PANEL_T0
-#define PANEL_T0 512      // threads per workgroup, tier 0: same LDS as 256 threads, twice the wavefronts per CU
-#endif
 #ifndef PANEL_T1
 #define PANEL_T1 256
 #endif
@@ -914,16 +861,13 @@ struct PanelGroup {
     int32_t nt;      // tiles handled by this workgroup (all in one column block)
     int32_t blk;
 };
-constexpr int PANEL_TPW = 8;     // tiles per workgroup: the x window is copied once per group
-
-template <class PP, int CB, bool WINDOW, int PT>
+template <class PP, int PT>
 __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
     double *__restrict__ carry_val, int64_t pnnz)
 {
-    __shared__ double s_x[WINDOW ? CB : 1];
     __shared__ double s_buf[MERGE_ITEMS + 1];
     __shared__ int32_t s_long[MERGE_MAXLONG];
     __shared__ int32_t s_nlong;
@@ -934,24 +878,6 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const int lane = tid & (WAVE - 1), wv = tid / WAVE;
     const PanelGroup grp = groups[blockIdx.x];
     if (grp.nt == 0) return;                      // padding group of an XCD stream
-    const int32_t w0 = WINDOW ? grp.blk * CB : 0; // without a window, columns index x directly
-
-    // the block's x window -> LDS, coalesced 16-B loads, all in flight before the first store
-    if (WINDOW) {
-        const int wlen = ncols - w0 < CB ? ncols - w0 : CB;
-        const f64x2_t *src = (const f64x2_t *)(x + w0);
-        constexpr int WL = WINDOW ? CB / 2 / PT : 1;
-        if (wlen == CB) {
-            f64x2_t v[WL];
-#pragma unroll
-            for (int u = 0; u < WL; u++) v[u] = src[tid + u * PT];
-#pragma unroll
-            for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * PT] = v[u];
-        } else {
-            for (int k = tid; k < wlen; k += PT) s_x[k] = x[w0 + k];
-        }
-    }
-
     // Software pipeline over the group's tiles: the entries (and row ends) of tile it+1 are loaded
     // into registers while tile it is reduced out of LDS, so one global-load latency is exposed per
     // group instead of two per tile.
@@ -968,10 +894,6 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         {                                                                                             \
             const int k = 2 * (tid + u * PT);                                              \
             load_pair_clamped<CSRK_VAL_F64>(pci, pvs, j0_ + k, j0_, nn_, pnnz - 2, c0[u], c1[u], p0[u], p1[u]); \
-            if (WINDOW) {                                                                             \
-                c0[u] = k < nn_ ? c0[u] : w0;                                                         \
-                c1[u] = k + 1 < nn_ ? c1[u] : w0;                                                     \
-            }                                                                                         \
         }                                                                                             \
         _Pragma("unroll") for (int u = 0; u < RPT; u++)                                               \
         {                                                                                             \
@@ -991,12 +913,12 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         const bool more = it + 1 < grp.nt;
         if (more) nx = tiles[t + 1];
 
-        __syncthreads();      // window visible (first pass); previous tile's LDS reads finished
+        __syncthreads();      // previous tile's LDS reads finished
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-            const double t0 = p0[u] * (WINDOW ? s_x[c0[u] - w0] : x[c0[u]]);
-            const double t1 = p1[u] * (WINDOW ? s_x[c1[u] - w0] : x[c1[u]]);
+            const double t0 = p0[u] * x[c0[u]];
+            const double t1 = p1[u] * x[c1[u]];
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
             p1[u] = k + 1 < nn ? t1 : 0.0;
         }
@@ -1602,44 +1524,24 @@ __global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const
     if (r < nrows && rpv[r + 1] > rpv[r]) rowids[ridx[r]] = (int32_t)r;
 }
 
-// A stream is laid out as up to 8 sub-streams (one for the short rows; one per XCD for tier 1), each a
-// whole number of tiles: sub-stream q holds the view entries [ent0[q], ent0[q+1]) in the logical slots
-// starting at slot0[q] (a multiple of ACC_TILE); slots past a sub-stream's entries are padding.
-struct LsSegs {
-    int32_t n;
-    int64_t slot0[9], ent0[9];
-};
-
-__device__ __forceinline__ int ls_seg_of(const LsSegs &sg, int64_t slot)
-{
-    int q = 0;
-#pragma unroll
-    for (int k = 1; k < 8; k++)
-        if (k < sg.n && slot >= sg.slot0[k]) q = k;
-    return q;
-}
-
-// One thread per logical slot: view entry L of view row r is the source entry src[r] + (L - rpv[r]) (a view
-// row is a whole row of the source or empty).  phys_tile (optional): where each logical tile is stored.
+// One thread per slot of the stream (n_ent entries, then padding to a whole tile): view entry L of view row r is the
+// source entry src[r] + (L - rpv[r]) (a view row is a whole row of the source or empty).
 template <class P, int VT>
 __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
                                                      const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                                     LsSegs sg, int64_t n_slots, const int32_t *__restrict__ phys_tile,
-                                                     const int32_t *__restrict__ slot_map, double *__restrict__ svals,
+                                                     int64_t n_ent, int64_t n_slots, const int32_t *__restrict__ slot_map, double *__restrict__ svals,
                                                      uint32_t *__restrict__ sidx, const P *__restrict__ rp_len)
 {
     // rp_len (dense rows): the view's own row pointers; rpv then gives every row at least one slot, and a row that is
     // empty in rp_len becomes one padding entry that opens (and is) its run
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
-    const int64_t lt = slot / ACC_TILE;
-    const int64_t t = phys_tile ? (int64_t)phys_tile[lt] : lt;
+    const int64_t t = slot / ACC_TILE;
     const int el = (int)(slot % ACC_TILE);
-    const int q = ls_seg_of(sg, slot);
-    const int64_t L = sg.ent0[q] + (slot - sg.slot0[q]);
+    const int64_t L = slot;
     double v = 0.0;
     uint32_t ix = LS_PAD;
-    if (L < sg.ent0[q + 1]) {
+    if (L < n_ent) {
         const int32_t r = ls_row_of(rpv, nrows, L);
         const int64_t first = (int64_t)rpv[r];
         if (rp_len && rp_len[r + 1] == rp_len[r]) {
@@ -1657,70 +1559,43 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
     sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
 }
 
-// per logical tile: run numbering base (stored at the tile's physical place) and the inverse placement
+// per tile: run numbering base
 template <class P>
-__global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
-                                   LsSegs sg, int64_t n_tiles, const int32_t *__restrict__ phys_tile,
-                                   int32_t *__restrict__ tile_base, int32_t *__restrict__ carry_idx)
+__global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx, int64_t n_tiles,
+                                   int32_t *__restrict__ tile_base)
 {
-    const int64_t lt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lt >= n_tiles) return;
-    const int64_t slot = lt * ACC_TILE;
-    const int q = ls_seg_of(sg, slot);
-    const int64_t e0 = sg.ent0[q] + (slot - sg.slot0[q]);      // < ent0[q + 1]: a sub-stream has no empty tile
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t e0 = t * ACC_TILE;      // (< the entry count: the stream has no empty tile)
     const int32_t r = ls_row_of(rpv, nrows, e0);
-    const int64_t t = phys_tile ? (int64_t)phys_tile[lt] : lt;
     tile_base[t] = ridx[r] + ((int64_t)rpv[r] == e0 ? 0 : 1);
-    if (carry_idx) carry_idx[t] = (int32_t)lt;
 }
 
 // LDS: [0, LS_HOT_LDS) the x values of the most popular packed columns (slots below n_lds are read from
 // here instead of gathered), then one staging buffer of ACC_TILE + 2 run sums per wavefront.
-// Diagnostic build only (-DCSRK_LS_STAMPS, tools/build_variant.sh): per-wavefront cycle totals of the phases of the
-// stream kernel's tile loop, stamped with s_memtime and read back by csrk_debug_ls_stamps.  The stamps go to a buffer of
-// their own and no output is computed from them; the shipped library contains none of this.
-#ifdef CSRK_LS_STAMPS
-constexpr int LS_NSTAMP = 8;
-__device__ unsigned long long g_ls_stamps[4096 * LS_NSTAMP];
-#define LS_STAMP(I)                                                       \
-    {                                                                     \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-        stamp_acc[I] += now_ - stamp_last;                                \
-        stamp_last = now_;                                                \
-    }
-#else
-#define LS_STAMP(I)
-#endif
-
-// XGT (tile-major cold staging): `x` is xg and `tile_cold[t]` the start of tile t's staged values in it; the wavefront
-// copies that range (at most 512 values, on average ~a quarter of the tile) into its LDS staging buffer with coalesced
-// 512-B loads and a cold entry reads LDS at the offset its index word holds -- one L1 line fill per 16 staged values
-// instead of one per value (a gather lane that misses L1 costs its CU ~4 clocks of line fill wherever the line comes
-// from).  The buffer is the run-sum staging buffer s_out: the gathers of a tile are over before
-// its run sums are written, and a wavefront's LDS operations complete in order.
-// MODE: LS_PLAIN; LS_XGT (above);
+// MODE: LS_PLAIN = the unpacked columns' x values are gathered from x (nothing was staged);
 // LS_RND = round-in-LDS staging: the workgroup walks ROUNDS of `stage_tiles` consecutive tiles (wavefront w takes tiles
-// w, w + 8, ... of the round); `x` is xg and tile_cold[r] the start of round r's staged values in it, which the workgroup
+// w, w + 8, ... of the round); `x` is xg and round_start[r] the start of round r's staged values in it, which the workgroup
 // copies into LDS with coalesced loads (requested one round ahead, into registers) -- a cold entry's index word holds its
 // offset there.  The copy pass can then use rounds of 64 tiles (its store transactions are per (round, column block)
 // bucket: 0.049 ms against 0.065 at 8 tiles) without the stream side paying for it in L1 lines (0.257 ms at 64 tiles when
 // the round's range is read by gathers).  Two workgroup barriers per round.
 // DENSE: run k is row k (LightStream::dense): row ids are not loaded and there are no gaps between runs to clear.
-constexpr int LS_PLAIN = 0, LS_XGT = 1, LS_RND = 2;
+constexpr int LS_PLAIN = 0, LS_RND = 2;
 template <int MODE, bool DENSE = false>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
-    const int32_t *__restrict__ tile_base, const int32_t *__restrict__ carry_idx, const double *__restrict__ x,
+    const int32_t *__restrict__ tile_base, const double *__restrict__ x,
     const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
     double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
-    const int32_t *__restrict__ tile_cold, const int32_t *__restrict__ round_tile0, const int32_t *__restrict__ wg_round0)
+    const int32_t *__restrict__ round_start, const int32_t *__restrict__ round_tile0, const int32_t *__restrict__ wg_round0)
 {
     // No FMA contraction in this kernel: the reference rounds every product before adding it.  (HIP's rounding
     // intrinsics for multiply and add are plain * and + inside inline functions compiled with
     // -ffp-contract=fast and fuse after inlining -- measured: 2041 instead of 75 rows of BASELINE configs[0]
     // differed in the last bits; the pragma governs the operators written in this body.)
 #pragma clang fp contract(off)
-    constexpr bool XGT = MODE == LS_XGT, RND = MODE == LS_RND;
+    constexpr bool RND = MODE == LS_RND;
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1747,12 +1622,11 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     f64x2_t v[4], vn[4];
     u32x4_t ix[2], ixn[2];
     int32_t tb = 0, tbn = 0;
-    int32_t cb = 0, cn = 0, cbn = 0, cnn = 0;      // XGT: this tile's range of xg (start, length), and the next tile's
     constexpr int RQ = LS_RND_CAP / 2 / LS_THREADS;      // RND: 16-B loads per thread that cover a round's staged values
     f64x2_t rv[RND ? RQ : 1];
     auto round_request = [&](int64_t R_) {      // the staged values of round R_ -> registers (pairs past its count re-read its first)
-        const int32_t r0 = tile_cold[R_];
-        const int32_t rn = tile_cold[R_ + 1] - r0;
+        const int32_t r0 = round_start[R_];
+        const int32_t rn = round_start[R_ + 1] - r0;
 #pragma unroll
         for (int q = 0; q < RQ; q++) {
             const int k = 2 * (q * LS_THREADS + (int)threadIdx.x);
@@ -1763,10 +1637,6 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     };
     if (RND && R_begin < R_end) round_request(R_begin);
     int64_t t = wave0;
-#ifdef CSRK_LS_STAMPS
-    unsigned long long stamp_acc[LS_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-#endif
     if (R_begin < R_end && t < round_t1(R_begin)) {
         const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
         const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
@@ -1775,10 +1645,6 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
         for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
         tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
-        if (XGT) {
-            cb = __builtin_amdgcn_readfirstlane(tile_cold[t]);
-            cn = __builtin_amdgcn_readfirstlane(tile_cold[t + 1]) - cb;
-        }
     }
     for (int64_t R = R_begin; R < R_end; R += R_step) {
     if (RND) {
@@ -1807,27 +1673,9 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         // the next tile's stream loads -- HBM latency -- are requested after them and stay in flight across the whole
         // tile.  (Requested first, as they used to be, every tile waited for the next tile's HBM loads before its first
         // multiply.)
-        // XGT: the tile's staged x values, coalesced: lane k of load q takes the value pair 2 (64 q + k), so four 16-B
-        // loads cover the 512 values a tile can have at most (pairs past the tile's count re-read its first pair: one
-        // line, no traffic; an odd count's last pair reads one value into the next tile's range or the array's padding)
-        f64x2_t xr[4];
         double gv[ACC_K], lv[ACC_K];
         bool inl[ACC_K];
-        if (XGT) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int k = 2 * (q * WAVE + lane);
-                xr[q] = *(const F64x2 *)(x + cb + (k < cn ? k : 0));
-            }
-            // packed columns beyond the LDS slots: gathered from the pack
-#pragma unroll
-            for (int j = 0; j < ACC_K; j++) {
-                const uint32_t c = e[j] & LS_COL_MASK;
-                const bool hot = (e[j] & LS_HOT_BIT) != 0;
-                gv[j] = 0.0;
-                if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
-            }
-        } else if (RND) {
+        if (RND) {
             // packed columns beyond the LDS slots: gathered from the pack; everything else is in LDS
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) {
@@ -1872,13 +1720,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
 #pragma unroll
             for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
             tbn = tile_base[tn];
-            if (XGT) {
-                cbn = tile_cold[tn];
-                cnn = tile_cold[tn + 1] - cbn;
-            }
         }
         asm volatile("" ::: "memory");
-        LS_STAMP(0)
         // row starts: bit j of st = entry j opens a row (index words only: this runs while the tile's x values arrive)
         uint32_t st = 0;
 #pragma unroll
@@ -1886,21 +1729,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         const int cnt = __popc(st);
         const int S = wave_exscan_i32(cnt, lane);          // row starts in the lanes below
         const int total = wave_last_i32(S + cnt);            // row starts in the tile
-        LS_STAMP(1)
-        if (XGT) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) ((f64x2_t *)s_out)[q * WAVE + lane] = xr[q];
-#pragma unroll
-            for (int j = 0; j < ACC_K; j++) {
-                const uint32_t c = e[j] & LS_COL_MASK;
-                const bool hot = (e[j] & LS_HOT_BIT) != 0;
-                const bool lds_hot = hot && (int32_t)c < n_lds;
-                const bool cold = !hot && c != LS_PAD;
-                inl[j] = lds_hot || cold;                       // served from LDS: the hot slots or the staged range
-                const double *src = cold ? s_out + c : s_hot + (lds_hot ? c : 0);
-                lv[j] = *src;
-            }
-        } else if (RND) {
+        if (RND) {
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) {
                 const uint32_t c = e[j] & LS_COL_MASK;
@@ -1919,11 +1748,6 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         for (int j = 0; j < ACC_K; j++) {
             pr[j] = a[j] * (inl[j] ? lv[j] : gv[j]);
         }
-#ifdef CSRK_LS_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7]));
-#endif
-        LS_STAMP(2)
         // Run sums go to the wavefront's staging buffer: slot 0 = the tile's leading run (the part of a row
         // begun in an earlier tile; 0.0 if the tile opens a row), slot k = the run opened by the tile's k-th
         // row start.  Lane-local pass: runs that start and end inside the lane.
@@ -1971,7 +1795,6 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         }
         if (has_start) s_out[S] = hok ? Hq : hs + X;             // the head run ends in this lane
         if (lane == WAVE - 1) s_out[S + cnt] = okq ? Tq : T;     // the tile's last run (continued by the next tile's slot 0)
-        LS_STAMP(3)
         // out: slot k -> the row of run tile_base - 1 + k; consecutive lanes write ascending (mostly
         // consecutive) rows.  LDS operations of one wavefront complete in order: no barrier needed.
         // Rows without a run -- empty rows, rows served by the tiers (their reduce kernels overwrite y later
@@ -1995,9 +1818,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 const double val = s_out[k];
                 if (k == 0) {
                     const bool opens = (st & 1u) != 0;           // lane 0: the tile's first entry opens a row
-                    const int64_t ct = carry_idx ? (int64_t)carry_idx[t] : t;     // the tile's place in run order
-                    carry_val[ct] = val;
-                    carry_row[ct] = opens ? -1 : r;              // r = rowids[tb - 1] (clamped when tb == 0: then it opens)
+                    carry_val[t] = val;
+                    carry_row[t] = opens ? -1 : r;              // r = rowids[tb - 1] (clamped when tb == 0: then it opens)
                 } else {
                     __builtin_nontemporal_store(val, y + r);
                     if (!DENSE) {
@@ -2032,28 +1854,13 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         if (!DENSE && total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
             for (int64_t q = (int64_t)rowids[n_runs - 1] + 1 + lane; q < nrows; q += WAVE) y[q] = 0.0;
         }
-        LS_STAMP(4)
-#ifdef CSRK_LS_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // [5] = what the stores (and the prefetch) still needed
-        LS_STAMP(5)
-        stamp_acc[7] += 1;
-#endif
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = vn[q];
 #pragma unroll
         for (int q = 0; q < 2; q++) ix[q] = ixn[q];
         tb = __builtin_amdgcn_readfirstlane(tbn);
-        if (XGT) {
-            cb = __builtin_amdgcn_readfirstlane(cbn);
-            cn = __builtin_amdgcn_readfirstlane(cnn);
-        }
     }
     }
-#ifdef CSRK_LS_STAMPS
-    const int64_t wave_id = (int64_t)blockIdx.x * NW + wv;
-    if (lane == 0 && wave_id < 4096)
-        for (int i = 0; i < LS_NSTAMP; i++) g_ls_stamps[wave_id * LS_NSTAMP + i] = stamp_acc[i];
-#endif
 }
 
 // One wavefront per tile: the first tile of each run of equal carry_row adds the whole run,
@@ -2175,7 +1982,7 @@ constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (s
 // with blockIdx % 8 == b % 8.
 template <class P, int VT>
 static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
-                       bool window, int tpw, bool xcd_streams, hipStream_t s)
+                       int tpw, bool xcd_streams, hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t n = (int32_t)rows.size();
@@ -2273,7 +2080,6 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
     pn->on = true;
-    pn->window = window;
     pn->cb = cb;
     pn->nb = nb;
     pn->nrow = n;
@@ -2287,7 +2093,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
 // column-block-major (value, packed index) stream plus the persistent workgroups' segment lists.
 template <class P, int VT>
 static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const int64_t *lens, int32_t n, int64_t nnz_rows,
-                           hipStream_t s, int64_t wgs = 0)
+                           hipStream_t s)
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
@@ -2334,8 +2140,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     // segments
     int cus = 0;
     CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    int64_t n_wg = wgs > 0 ? wgs : (cus > 0 ? cus : 256);
-    if (const char *e = getenv("CSRK_ACC_WGS")) n_wg = atoll(e) > 0 ? atoll(e) : n_wg;
+    int64_t n_wg = cus > 0 ? cus : 256;
     if (n_wg > n_tiles) n_wg = n_tiles;
     if (n_wg < 1) n_wg = 1;
     std::vector<int64_t> wg_t0((size_t)n_wg + 1);
@@ -2405,6 +2210,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     if (env && env[0] == '0') return CSRK_OK;
     HEAVY_MIN = 2048;
     TIERB_MIN = 128;
+    // (test hooks, not tuning switches: a small matrix gets more "heavy" rows than one accumulator group holds, or no tier 1)
     if (const char *e = getenv("CSRK_HEAVY_MIN")) HEAVY_MIN = atoi(e) > 64 ? atoi(e) : 64;
     if (const char *e = getenv("CSRK_TIERB_MIN")) TIERB_MIN = atoi(e) >= 0 ? atoi(e) : 0;
     const bool tier1 = allow_tier1 && TIERB_MIN > 0 && TIERB_MIN < HEAVY_MIN;
@@ -2454,14 +2260,10 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     CSRK_HIP(hipStreamSynchronize(s));
     if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
 
-    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows) unless CSRK_SPMV_TIER0=pairs
-    const char *t0env = getenv("CSRK_SPMV_TIER0");
-    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
-    // The accumulator form costs 1.8 ps per entry against 4.8 for tier 1 (measured, headline matrix), and
+    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows).  The accumulator form costs 1.8 ps per entry against 4.8 for tier 1 (measured, headline matrix), and
     // one group holds up to ACC_MAXROWS rows at no extra window traffic: when fewer rows than that reach
     // HEAVY_MIN, tier 0 is extended downwards to the ACC_MAXROWS longest rows (not below ACC_FLOOR).
-    const int base_heavy_min = HEAVY_MIN;
-    if (acc_form && tier1 && !getenv("CSRK_HEAVY_MIN")) {
+    if (tier1 && !getenv("CSRK_HEAVY_MIN")) {
         int64_t n_min = 0;
         for (int32_t c = 0; c < n_cut; c++) n_min += lens[c] >= HEAVY_MIN;
         if (n_min < ACC_MAXROWS && n_cut > n_min) {
@@ -2473,9 +2275,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
             int64_t n_ge = 0;
             for (int32_t c = 0; c < n_cut; c++) n_ge += lens[c] >= thr;
             if (n_ge > ACC_MAXROWS) thr++;
-            int acc_floor = ACC_FLOOR;
-            if (const char *e = getenv("CSRK_ACC_FLOOR")) acc_floor = atoi(e) > 0 ? atoi(e) : acc_floor;
-            thr = thr < acc_floor ? acc_floor : thr;
+            thr = thr < ACC_FLOOR ? ACC_FLOOR : thr;
             if (thr < HEAVY_MIN) HEAVY_MIN = (int)thr;
         }
     }
@@ -2493,9 +2293,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
         }
     }
     const int64_t pair_cap = 256ll << 20;
-    const int64_t pairs0 = (int64_t)r0.size() * ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB0);
     const int64_t pairs1 = (int64_t)r1.size() * ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB1);
-    if (pairs0 > pair_cap) return CSRK_OK;                       // pair table too large: keep one path
     if (pairs1 > pair_cap && tier1) return build_heavy_split<P>(m, p, s, false);
 
     p->n_heavy = n_cut;
@@ -2504,7 +2302,6 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->t0_lens = len0;
     p->t1_rows = r1;
     p->t1_nnz = nnz1;
-    p->view_min = acc_form ? (base_heavy_min > p->heavy_min ? base_heavy_min : p->heavy_min) : p->heavy_min;
     return CSRK_OK;
 }
 
@@ -2513,62 +2310,21 @@ template <class P>
 static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
 {
     if (!p->n_heavy) return CSRK_OK;
-    const char *t0env = getenv("CSRK_SPMV_TIER0");
-    const bool acc_form = !(t0env && !strcmp(t0env, "pairs"));
     const std::vector<int32_t> &r0 = p->t0_rows, &r1 = p->t1_rows;
     const std::vector<int64_t> &len0 = p->t0_lens;
-    int64_t nnz0 = 0;
-    for (int64_t l : len0) nnz0 += l;
     const int64_t nnz1 = p->t1_nnz;
-    // The two tiers side by side (OPT-IN: CSRK_SPMV_T1_BESIDE=1, or =W to force W).  The accumulator kernel is bound by HBM:
-    // with fewer workgroups than CUs it loses little (headline matrix: 256 workgroups 0.220 ms, 224: 0.218, 192: 0.232,
-    // 160: 0.265, 128: 0.316), while the pair kernel of tier 1 waits on L2 gathers and leaves HBM idle (0.096 ms for 19.5 M
-    // entries at 3.6 TB/s).  So the accumulator kernel gets W = 25/32 of the CUs as persistent workgroups -- each fills its
-    // CU's LDS, so nothing else lands there -- and the pair kernel, launched on a side stream of the plan's own, starts on
-    // the other CUs at the same time and takes the rest as they come free.  Measured (20-step runs as the driver launches
-    // them, ten boxes): 0.515-0.523 ms against 0.531-0.537 on seven of them, no gain on three (0.532-0.534: the same on
-    // each box run after run); W = 160 gave 0.500-0.506 on some boxes and 0.552-0.556 on others.  Nothing available makes
-    // the split exact (stream priorities, a head start for the accumulator kernel: no change; CU-masked streams slow
-    // every kernel down), and with two queues busy the event pairs around the accumulator kernel stop meaning its
-    // duration (0.43 ms reported inside a 0.533-ms step).  Hence off by default.  Results do not depend on the overlap;
-    // they do depend on W (the accumulator partials are per workgroup), which is fixed per plan.
-    int64_t acc_wgs = 0;
-    {
-        const char *e = getenv("CSRK_SPMV_T1_BESIDE");
-        const char *t1env = getenv("CSRK_SPMV_TIER1");
-        const bool t1_stream = t1env && !strcmp(t1env, "stream");
-        int cus = 0;
-        CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-        if (e && e[0] != '0' && acc_form && !t1_stream && !r0.empty() && !r1.empty() && r0.size() <= (size_t)ACC_MAXROWS &&
-            cus >= 64) {
-            // worth two more stream operations per product only when tier 1 is a real share of the tiers' work
-            if ((double)nnz1 * 4.9 >= 0.08 * (double)nnz0 * 1.58) acc_wgs = (cus * 25 / 32) & ~7;
-            if (e && atoi(e) >= 8 && atoi(e) < cus) acc_wgs = atoi(e) & ~7;      // (CSRK_SPMV_T1_BESIDE=W forces W)
-        }
-        if (acc_wgs) {
-            if (!p->side) CSRK_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-            if (!p->ev_fork) CSRK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            if (!p->ev_join) CSRK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-            p->t1_beside = true;
-        }
-    }
-    int tpw0 = 8, tpw1 = 1;
-    if (const char *e = getenv("CSRK_PANEL_TPW")) tpw0 = atoi(e) > 0 ? atoi(e) : tpw0;
-    if (const char *e = getenv("CSRK_PANEL_TPW1")) tpw1 = atoi(e) > 0 ? atoi(e) : tpw1;
 #define BUILD(VT)                                                                                                  \
     do {                                                                                                           \
-        if (!r0.empty() && !acc_form)                                                                              \
-            CSRK_TRY((build_panel<P, VT>(m, &p->tier[0], r0, nnz0, PANEL_CB0, true, tpw0, false, s)));              \
-        for (size_t g0 = 0; acc_form && g0 < r0.size(); g0 += ACC_MAXROWS) {                                       \
+        for (size_t g0 = 0; g0 < r0.size(); g0 += ACC_MAXROWS) {                                                   \
             const size_t g1 = g0 + ACC_MAXROWS < r0.size() ? g0 + ACC_MAXROWS : r0.size();                         \
             int64_t gn = 0;                                                                                        \
             for (size_t c = g0; c < g1; c++) gn += len0[c];                                                        \
             AccPanel *ap = new (std::nothrow) AccPanel();                                                          \
             CSRK_REQUIRE(ap, "out of host memory");                                                                \
             p->acc.push_back(ap);                                                                                  \
-            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s, acc_wgs))); \
+            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
         }                                                                                                          \
-        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier[1], r1, nnz1, PANEL_CB1, false, tpw1, true, s))); \
+        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier1, r1, nnz1, PANEL_CB1, 1, true, s)));            \
     } while (0)
     if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
     else if (m->val_type == CSRK_VAL_F32) BUILD(CSRK_VAL_F32);
@@ -2594,7 +2350,6 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
                                   // 256k 0.308, 512k 0.302, 1M 0.297, 2M 0.297 ms, but the per-call pack costs more than that gains past 512k)
                                   // earlier sweep, tile kernel, 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
                                   // 256k 0.430, 1M 0.439, 4M 0.460 ms for the tile kernel; none 0.481)
-    if (const char *e = getenv("CSRK_HOT_SLOTS")) HOT_SLOTS = atoll(e) > 0 ? atoll(e) : HOT_SLOTS;
     p->hot_slots = (int32_t)HOT_SLOTS;
     // x that fits in L2 whole needs no packing
     if (!force && (m->nnz < (1 << 20) || (int64_t)m->ncols * 8 <= (4ll << 20))) return CSRK_OK;
@@ -2729,19 +2484,18 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
-// Build the arrays of one light stream from a view: view row r (r < nrows_view) is the source entries
-// src[r] .. src[r] + (rpv[r+1] - rpv[r]) of (ci, vs); `sg` places the view's entries in sub-streams, `phys`
-// (optional) places the logical tiles in memory.
+// Build the arrays of the light stream from a view: view row r (r < nrows_view) is the source entries
+// src[r] .. src[r] + (rpv[r+1] - rpv[r]) of (ci, vs); n_ent entries in n_tiles tiles.
 template <class P, int VT>
 static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, int32_t nrows_view, const int32_t *ci,
-                        const void *vs, const LsSegs &sg, int64_t n_tiles, const std::vector<int32_t> *phys, int32_t n_out,
-                        const int32_t *slot_map, hipStream_t s, const P *rp_len = nullptr)
+                        const void *vs, int64_t n_ent, int64_t n_tiles, int32_t n_out, const int32_t *slot_map, hipStream_t s,
+                        const P *rp_len = nullptr)
 {
     // rp_len (dense rows): rpv gives every row of the view at least one slot; a row that is empty in rp_len is one padding
     // entry.  Run k is then row k, and no row-id table is built.
     ls->on = false;
     ls->dense = rp_len != nullptr;
-    DevBuf ridx, dphys;
+    DevBuf ridx;
     CSRK_TRY(ridx.alloc((size_t)(nrows_view + 2) * 4));
     const unsigned gr = (unsigned)ceil_div((int64_t)nrows_view + 1, 256);
     ls_rowflag_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>());
@@ -2756,23 +2510,14 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
         ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
         CSRK_LAUNCH_CHECK();
     }
-    const int32_t *d_phys = nullptr;
-    if (phys) {
-        CSRK_TRY(dphys.alloc((size_t)n_tiles * 4));
-        CSRK_HIP(hipMemcpyAsync(dphys.p, phys->data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
-        CSRK_TRY(ls->carry_idx.alloc((size_t)n_tiles * 4));
-        d_phys = dphys.as<int32_t>();
-    }
     CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
     ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        src, rpv, nrows_view, ci, vs, sg, n_tiles * ACC_TILE, d_phys, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(),
-        rp_len);
+        src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
     ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-        rpv, nrows_view, ridx.as<int32_t>(), sg, n_tiles, d_phys, ls->tile_base.as<int32_t>(),
-        phys ? ls->carry_idx.as<int32_t>() : (int32_t *)nullptr);
+        rpv, nrows_view, ridx.as<int32_t>(), n_tiles, ls->tile_base.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(ls->carry_val.alloc((size_t)n_tiles * 8));
@@ -2781,17 +2526,12 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_XGT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(160 * 1024)));
-    if (const char *e = getenv("CSRK_LS_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;
     const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
     ls->grid = (unsigned)(wgs < need ? wgs : need);
     ls->n_tiles = n_tiles;
@@ -2881,66 +2621,6 @@ __global__ void ls_round_start_kernel(const int32_t *__restrict__ base_rb, int32
 {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r <= nround_ls) round_start[r] = base_rb[(int64_t)r * nblk];
-}
-
-// Tile-major staging.  The positions above put the staged values of one workgroup ROUND (16 tiles) side by side, ordered
-// by column block: cheap for the copy pass, but a wavefront's ~113 cold entries then lie scattered over the round's 14 KB
-// and each of its gather lanes pulls its own 128-B line into L1 (9 * 10^6 line fills per SpMV at ~4 CU clocks each).
-// Here the staged values of one TILE are contiguous instead -- xg[tile_cold[t] .. tile_cold[t + 1]) -- so the stream
-// kernel fetches them with coalesced loads (spmv_lstream_kernel<true>), and inside a tile they are ordered by the XCD
-// that copies them (octant = column block / blocks per XCD, the copy pass's own assignment), so that what one XCD's
-// workgroups write into a tile's range is one contiguous piece and still merges into whole lines in that XCD's L2.
-// One wavefront per tile: rank[w] = offset of index word w's value inside its tile's range (octant-major, inside an
-// octant in physical word order: deterministic), tile_cnt[t] = staged values of the tile.
-__global__ __launch_bounds__(256) void ls_cold_rank_kernel(const uint32_t *__restrict__ sidx, int64_t n_tiles, int32_t W,
-                                                          int32_t blk_per_oct, uint16_t *__restrict__ rank,
-                                                          int32_t *__restrict__ tile_cnt)
-{
-    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (t >= n_tiles) return;
-    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
-    int oct[ACC_K], r[ACC_K];
-#pragma unroll
-    for (int u = 0; u < ACC_K; u++) {
-        const uint32_t ix = sidx[t * ACC_TILE + u * WAVE + lane];
-        int o = (int)((ix & LS_COL_MASK) / (uint32_t)W) / blk_per_oct;
-        oct[u] = ls_is_cold(ix) ? (o < 7 ? o : 7) : 8;
-        r[u] = 0;
-    }
-    int start = 0;
-    for (int o = 0; o < 8; o++) {
-#pragma unroll
-        for (int u = 0; u < ACC_K; u++) {
-            const unsigned long long m = __ballot(oct[u] == o);
-            if (oct[u] == o) r[u] = start + __popcll(m & below);
-            start += __popcll(m);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < ACC_K; u++) rank[t * ACC_TILE + u * WAVE + lane] = (uint16_t)r[u];
-    if (lane == 0) tile_cnt[t] = start;
-}
-
-// tile-major form of ls_cold_place_kernel: position = the tile's start + the rank; the index word keeps the rank
-__global__ __launch_bounds__(256) void ls_cold_place_tile_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
-                                                                int32_t W, const int32_t *__restrict__ tile_round,
-                                                                const int32_t *__restrict__ tile_cold,
-                                                                const uint16_t *__restrict__ rank,
-                                                                const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
-                                                                uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint32_t ix = sidx[w];
-    if (!ls_is_cold(ix)) return;
-    const int64_t r = tile_round[w / ACC_TILE];
-    const uint32_t c = ix & LS_COL_MASK;
-    const int32_t b = (int32_t)(c / (uint32_t)W);
-    const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
-    a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);
-    a_dst[pa] = tile_cold[w / ACC_TILE] + (int32_t)rank[w];
-    sidx[w] = (ix & LS_START_BIT) | (uint32_t)rank[w];
 }
 
 // xg[a_dst[k]] = x[a_col[k]] for the entries of one column block: the block's window of x is copied into LDS with
@@ -3052,9 +2732,6 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     ls->stage_tiles = 0;
     const char *env = getenv("CSRK_LS_STAGE");
     if (env && env[0] == '0') return CSRK_OK;
-    const char *xgt_env = getenv("CSRK_LS_XGT"), *rnd_env = getenv("CSRK_LS_RND");
-    const bool xgt = xgt_env && xgt_env[0] == '1';
-    bool rnd = !xgt && !(rnd_env && rnd_env[0] == '0');
     const int64_t n_words = ls->n_tiles * ACC_TILE;
     // a number of column blocks that fills the chip a whole number of times (two workgroups per CU), each window
     // at most LS_STAGE_WMAX columns
@@ -3083,29 +2760,25 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     int stage_tiles = LS_STAGE_TILES;
     int64_t nround_ls = 0, nround = 0, nb = 0, n_cold = 0;      // n_cold = where the virtual round starts
     // counts per (round, block) bucket for rounds of `nt` tiles; the old count is an entry's place inside its bucket
-    // Rounds of at most `nt` tiles.  balanced: every workgroup of the stream's persistent grid gets an equal share of the
-    // tiles, cut into equal rounds (whole tiles per wavefront); else rounds of `nt` tiles from tile 0 on.
+    // Rounds of at most `nt` tiles: every workgroup of the stream's persistent grid gets an equal share of the tiles, cut
+    // into equal rounds (whole tiles per wavefront).
     std::vector<int32_t> h_rt0, h_wr0;
     constexpr int NW_ = LS_THREADS / WAVE;
-    auto count_pass = [&](int nt, bool balanced, int64_t *max_round) -> int {
+    auto count_pass = [&](int nt, int64_t *max_round) -> int {
         stage_tiles = nt;
         h_rt0.clear();
         h_wr0.clear();
-        if (balanced) {
-            const int64_t G = ls->grid;
-            for (int64_t w = 0; w < G; w++) {
-                const int64_t tb = ls->n_tiles * w / G, te = ls->n_tiles * (w + 1) / G;
-                h_wr0.push_back((int32_t)h_rt0.size());
-                if (te > tb) {
-                    const int64_t k = ceil_div(te - tb, nt);
-                    const int64_t per = ceil_div(ceil_div(te - tb, k), NW_) * NW_;
-                    for (int64_t t = tb; t < te; t += per) h_rt0.push_back((int32_t)t);
-                }
-            }
+        const int64_t G = ls->grid;
+        for (int64_t w = 0; w < G; w++) {
+            const int64_t tb = ls->n_tiles * w / G, te = ls->n_tiles * (w + 1) / G;
             h_wr0.push_back((int32_t)h_rt0.size());
-        } else {
-            for (int64_t t = 0; t < ls->n_tiles; t += nt) h_rt0.push_back((int32_t)t);
+            if (te > tb) {
+                const int64_t k = ceil_div(te - tb, nt);
+                const int64_t per = ceil_div(ceil_div(te - tb, k), NW_) * NW_;
+                for (int64_t t = tb; t < te; t += per) h_rt0.push_back((int32_t)t);
+            }
         }
+        h_wr0.push_back((int32_t)h_rt0.size());
         nround_ls = (int64_t)h_rt0.size();
         h_rt0.push_back((int32_t)ls->n_tiles);
         nround = nround_ls + 1;      // + the virtual round of the packed columns
@@ -3134,24 +2807,24 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         for (int64_t r = 0; r < nround_ls; r++) *max_round = std::max(*max_round, rs[(size_t)r + 1] - rs[(size_t)r]);
         return CSRK_OK;
     };
+    // the largest rounds whose staged values fit the LDS round buffer (a round of one tile per wavefront always does)
     int64_t max_round = 0;
-    if (rnd) {
+    {
         constexpr int NW = LS_THREADS / WAVE;      // a round is a whole number of tiles per wavefront
-        int nt0 = LS_RND_MAXTILES / NW * NW;
-        if (const char *e = getenv("CSRK_LS_RND_TILES")) nt0 = atoi(e) >= NW ? atoi(e) / NW * NW : nt0;
-        rnd = false;
-        for (int nt = nt0; nt >= NW;) {
-            CSRK_TRY(count_pass(nt, true, &max_round));
+        static_assert(NW * ACC_TILE <= LS_RND_CAP, "the smallest round must fit the LDS round buffer");
+        bool fits = false;
+        for (int nt = LS_RND_MAXTILES / NW * NW; nt >= NW;) {
+            CSRK_TRY(count_pass(nt, &max_round));
             if (max_round <= LS_RND_CAP) {
-                rnd = true;
+                fits = true;
                 break;
             }
             // the fullest round scales with the round's size: jump to the size that would just fit, then step down
             int next = (int)((double)nt * LS_RND_CAP / (double)max_round) / NW * NW;
             nt = next < nt - NW ? next : nt - NW;
         }
+        if (!fits) return CSRK_OK;
     }
-    if (!rnd) CSRK_TRY(count_pass(LS_STAGE_TILES, false, &max_round));
     if (nround > INT32_MAX) return CSRK_OK;
     CSRK_HIP(hipMemsetAsync(cnt.as<int32_t>() + nround_ls * nblk, 0, (size_t)(nblk + 1) * 4, s));
     ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
@@ -3169,43 +2842,18 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     CSRK_TRY(ls->xg.alloc((size_t)(n_all + WAVE) * 8));      // (+ padding: the stream kernel's last pair of an odd count)
     CSRK_TRY(ls->a_col.alloc((size_t)n_all * 2));
     CSRK_TRY(ls->a_dst.alloc((size_t)n_all * 4));
-    // Measured on the headline matrix (tools/sweep_inproc.py): the tile-major form takes the stream kernel from 0.214 to
-    // 0.178 ms (its cold gathers were a fifth of its L1 line fills) but the copy pass from 0.064 to 0.125 ms -- every value
-    // it writes is then a store transaction of its own (~13 ps each chip-wide; the round-major form averages 0.55 per
-    // value) -- so it stays opt-in (CSRK_LS_XGT=1) until the copy is done in two coalesced passes.
-    if (xgt) {
-        // tile-major positions (see ls_cold_rank_kernel); the copy list keeps its (block, round) order
-        DevBuf rank;
-        CSRK_TRY(rank.alloc((size_t)n_words * 2));
-        CSRK_TRY(ls->tile_cold.alloc((size_t)(ls->n_tiles + 2) * 4));
-        ls_cold_rank_kernel<<<(unsigned)ceil_div(ls->n_tiles * WAVE, 256), 256, 0, s>>>(
-            ls->idx.as<uint32_t>(), ls->n_tiles, (int32_t)W, (int32_t)ceil_div(nblk, 8), rank.as<uint16_t>(),
-            ls->tile_cold.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_TRY(exclusive_scan_i32(ls->tile_cold.as<int32_t>(), ls->tile_cold.as<int32_t>(), ls->n_tiles, s));
-        ls_cold_place_tile_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)W,
-                                                    tile_round.as<int32_t>(), ls->tile_cold.as<int32_t>(), rank.as<uint16_t>(), cntT.as<int32_t>(),
-                                                    off.as<int32_t>(), ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipStreamSynchronize(s));      // `rank` is freed here
-    } else {
-        if (rnd) {
-            CSRK_TRY(ls->round_start.alloc((size_t)(nround_ls + 1) * 4));
-            ls_round_start_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround_ls, (int32_t)nblk,
-                                                                                       ls->round_start.as<int32_t>());
-            CSRK_LAUNCH_CHECK();
-        }
-        if (rnd) {
-            CSRK_TRY(ls->round_tile0.alloc(h_rt0.size() * 4));
-            CSRK_TRY(ls->wg_round0.alloc(h_wr0.size() * 4));
-            CSRK_HIP(hipMemcpyAsync(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
-            CSRK_HIP(hipMemcpyAsync(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, hipMemcpyHostToDevice, s));
-        }
-        ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W,
-                                               tile_round.as<int32_t>(), rnd ? 1 : 0, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
-                                               ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-    }
+    CSRK_TRY(ls->round_start.alloc((size_t)(nround_ls + 1) * 4));
+    ls_round_start_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround_ls, (int32_t)nblk,
+                                                                               ls->round_start.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(ls->round_tile0.alloc(h_rt0.size() * 4));
+    CSRK_TRY(ls->wg_round0.alloc(h_wr0.size() * 4));
+    CSRK_HIP(hipMemcpyAsync(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
+    CSRK_HIP(hipMemcpyAsync(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, hipMemcpyHostToDevice, s));
+    ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W,
+                                           tile_round.as<int32_t>(), 1, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
+                                           ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
     ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
                                                                        cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
                                                                        ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
@@ -3255,7 +2903,6 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     const P *rp_dense = nullptr;
     int64_t n_view_d = n_view, n_tiles_d = n_tiles;
     {
-        const char *de = getenv("CSRK_LS_DENSE");
         DevBuf nz;
         CSRK_TRY(nz.alloc((size_t)(m->nrows + 2) * 4));
         ls_rowflag_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, m->nrows, nz.as<int32_t>());
@@ -3266,7 +2913,7 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
         CSRK_HIP(hipStreamSynchronize(s));
         const int64_t n_pad = (int64_t)m->nrows - n_nonempty;
         const bool fits = sizeof(P) == 8 || n_view + n_pad <= (int64_t)INT32_MAX;
-        if (!(de && de[0] == '0') && fits && (n_pad * 8 <= n_view || (de && de[0] == '1'))) {
+        if (fits && n_pad * 8 <= n_view) {
             CSRK_TRY(rpd_buf.alloc((size_t)(m->nrows + 1) * sizeof(P)));
             ls_dense_ptr_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, nz.as<int32_t>(), m->nrows,
                                                                                                 rpd_buf.as<P>());
@@ -3277,13 +2924,8 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
         }
         CSRK_HIP(hipStreamSynchronize(s));      // nz is released here
     }
-    LsSegs sg;
-    sg.n = 1;
-    for (int k = 0; k < 9; k++) sg.slot0[k] = n_tiles_d * ACC_TILE, sg.ent0[k] = n_view_d;
-    sg.slot0[0] = 0;
-    sg.ent0[0] = 0;
-    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rp_dense ? rp_dense : rpv, m->nrows, m->d_colinds, m->d_values, sg, n_tiles_d,
-                                  nullptr, m->nrows, slot_map, s, rp_dense ? rpv : (const P *)nullptr)));
+    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rp_dense ? rp_dense : rpv, m->nrows, m->d_colinds, m->d_values, n_view_d, n_tiles_d,
+                                  m->nrows, slot_map, s, rp_dense ? rpv : (const P *)nullptr)));
     if (p->ls.on && p->n_hot) {
         CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
         // (round-in-LDS form: the round's staged values take the place of the hot window's tail)
@@ -3292,110 +2934,6 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     return CSRK_OK;
 }
 
-// Tier 1 as a stream: the (column block, row) pairs of the pair panel become the runs of a light stream whose
-// output is the pair partials.  The column blocks are dealt to 8 sub-streams (block b -> b % 8) and the
-// sub-streams' tiles interleaved in groups of 16, so that -- one workgroup of 16 wavefronts per CU, workgroup
-// w on XCD w % 8 -- the tiles of block b are gathered by one XCD and ONE L2 holds its 1 MiB x window (a speed
-// assumption only, as in the pair kernel it replaces: one wavefront per tile, no workgroup barriers, 12 B per
-// entry + 4 B per pair instead of the merge-path tile kernel's bookkeeping).
-__global__ void t1_view_kernel(const void *__restrict__ prp, int p64, const int32_t *__restrict__ blk_perm, int32_t n_heavy,
-                               int64_t pairs, int64_t *__restrict__ src, int64_t *__restrict__ lens)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= pairs) return;
-    const int64_t pr = (int64_t)blk_perm[r / n_heavy] * n_heavy + r % n_heavy;
-    const int64_t a = p64 ? ((const int64_t *)prp)[pr] : (int64_t)((const int32_t *)prp)[pr];
-    const int64_t b = p64 ? ((const int64_t *)prp)[pr + 1] : (int64_t)((const int32_t *)prp)[pr + 1];
-    src[r] = a;
-    lens[r] = b - a;
-}
-
-static int build_tier1_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
-{
-    Panel *pn = &p->tier[1];
-    p->t1s.on = false;
-    // Measured on the headline matrix: 0.152 ms as a stream against 0.101 ms for the pair kernel (both far from
-    // the HBM rate: every gather lane that misses L1 pulls a 128-B line into the CU, ~4 clocks each, and the
-    // pair kernel's entry-per-lane order makes fewer distinct lines per instruction) -- so the pair kernel stays
-    // the default and the stream form is kept for experiments: CSRK_SPMV_TIER1=stream.
-    const char *env = getenv("CSRK_SPMV_TIER1");
-    if (!pn->on || !(env && !strcmp(env, "stream")) || (int64_t)m->ncols > (int64_t)LS_COL_MASK) return CSRK_OK;
-    if (pn->rows > INT32_MAX - 2 || pn->nnz < 1) return CSRK_OK;
-    const int32_t nb = pn->nb, H = pn->nrow;
-    const int64_t pairs = pn->rows;
-    const int n_sub = nb >= 2 * HEAVY_STREAMS ? HEAVY_STREAMS : 1;
-    std::vector<int32_t> perm;
-    std::vector<int64_t> sub_blk0((size_t)n_sub + 1, 0);      // first permuted block of each sub-stream
-    for (int q = 0; q < n_sub; q++) {
-        sub_blk0[(size_t)q] = (int64_t)perm.size();
-        for (int32_t b = q; b < nb; b += n_sub) perm.push_back(b);
-    }
-    sub_blk0[(size_t)n_sub] = nb;
-    DevBuf dperm, src, rpv;
-    CSRK_TRY(dperm.alloc((size_t)nb * 4));
-    CSRK_TRY(src.alloc((size_t)(pairs + 1) * 8));
-    CSRK_TRY(rpv.alloc((size_t)(pairs + 2) * 8));
-    CSRK_HIP(hipMemcpyAsync(dperm.p, perm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
-    t1_view_kernel<<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(pn->rp.p, pn->p64 ? 1 : 0, dperm.as<int32_t>(), H, pairs,
-                                                                src.as<int64_t>(), rpv.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(rpv.as<int64_t>(), rpv.as<int64_t>(), pairs, s));
-    // entries before each sub-stream
-    std::vector<int64_t> e0((size_t)n_sub + 1);
-    for (int q = 0; q <= n_sub; q++)
-        CSRK_HIP(hipMemcpyAsync(&e0[(size_t)q], rpv.as<int64_t>() + sub_blk0[(size_t)q] * H, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    LsSegs sg;
-    std::vector<int64_t> sub_tiles;      // tiles of the non-empty sub-streams, in order
-    int64_t slot = 0;
-    sg.n = 0;
-    for (int q = 0; q < n_sub; q++) {
-        const int64_t len = e0[(size_t)q + 1] - e0[(size_t)q];
-        if (len == 0) continue;
-        sg.slot0[sg.n] = slot;
-        sg.ent0[sg.n] = e0[(size_t)q];
-        sg.n++;
-        sub_tiles.push_back(ceil_div(len, ACC_TILE));
-        slot += ceil_div(len, ACC_TILE) * ACC_TILE;
-    }
-    if (sg.n == 0) return CSRK_OK;
-    for (int k = sg.n; k < 9; k++) sg.slot0[k] = slot, sg.ent0[k] = e0[(size_t)n_sub];
-    // (empty sub-streams contribute no entries, so ent0[k + 1] is where sub-stream k's entries end)
-    const int64_t n_tiles = slot / ACC_TILE;
-    if (n_tiles > INT32_MAX) return CSRK_OK;
-    size_t mfree = 0, mtotal = 0;
-    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if ((size_t)n_tiles * ACC_TILE * 12 + (size_t)pairs * 8 + (64u << 20) > mfree) return CSRK_OK;
-    // tiles of the sub-streams interleaved in groups of 16
-    std::vector<int32_t> phys((size_t)n_tiles);
-    {
-        std::vector<int64_t> cur((size_t)sg.n), end((size_t)sg.n);
-        for (int k = 0; k < sg.n; k++) {
-            cur[(size_t)k] = sg.slot0[k] / ACC_TILE;
-            end[(size_t)k] = cur[(size_t)k] + sub_tiles[(size_t)k];
-        }
-        int64_t pos = 0;
-        while (pos < n_tiles)
-            for (int k = 0; k < sg.n; k++)
-                for (int u = 0; u < LS_THREADS / WAVE && cur[(size_t)k] < end[(size_t)k]; u++) phys[(size_t)cur[(size_t)k]++] = (int32_t)pos++;
-    }
-    CSRK_TRY((build_stream<int64_t, CSRK_VAL_F64>(m, &p->t1s, src.as<int64_t>(), rpv.as<int64_t>(), (int32_t)pairs,
-                                                   pn->ci.as<int32_t>(), pn->vs.p, sg, n_tiles, &phys, (int32_t)pairs,
-                                                   p->n_hot ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr, s)));
-    if (p->t1s.on) {
-        // the pair kernel's own arrays are no longer needed (the partials y', the row list and the geometry are)
-        pn->rp.release();
-        pn->ci.release();
-        pn->vs.release();
-        pn->tile.release();
-        pn->group.release();
-        pn->carry_row.release();
-        pn->carry_val.release();
-    }
-    return CSRK_OK;
-}
-
-// CSRK_PLAN_TRACE=1: wall-clock time of the plan's build stages on stderr (each stage is synchronised first)
 struct PlanTrace {
     bool on;
     double t0;
@@ -3456,17 +2994,14 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
             tr.lap("hot-column census + pack");
             CSRK_TRY(build_tiers<P>(m, p, s));
             tr.lap("tiers");
-            CSRK_TRY(build_tier1_stream(m, p, s));
             if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
             else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
             else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
             tr.lap("light stream + cold staging");
-            if (p->n_hot && !p->ls.on) {        // the tile kernel stays in charge: it reads a renumbered colinds copy
-                CSRK_TRY(p->ci_hot.alloc((size_t)m->nnz * 4));
-                hot_remap_kernel<<<(unsigned)ceil_div(m->nnz, 256), 256, 0, s>>>(m->d_colinds, m->nnz, p->hot_slot.as<int32_t>(),
-                                                                                p->ci_hot.as<int32_t>());
-                CSRK_LAUNCH_CHECK();
-                CSRK_HIP(hipStreamSynchronize(s));
+            if (p->n_hot && !p->ls.on) {        // no stream (no memory for it, CSRK_SPMV_STREAM=0): the tile kernel reads x itself
+                p->n_hot = 0;
+                p->hot_cols.release();
+                p->xh.release();
             }
             p->hot_slot.release();
         }
@@ -3599,8 +3134,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         };
         // cold staging (ls_stage_kernel) fills xg and the pack; it runs first, so that the x it has just read is still in
         // the Infinity Cache when the accumulator kernel fetches its windows
-        static const bool stage_first = [] { const char *e = getenv("CSRK_LS_STAGE_FIRST"); return !(e && e[0] == '0'); }();
-        auto launch_stage = [&]() -> int {
+        if (do_light && p->ls.on && p->ls.n_cold) {
             KernelTimer ks(p, s, 3);
             const unsigned gs = (unsigned)(ceil_div(p->ls.n_stage_blk, 8) * 8);
             ls_stage_kernel<<<gs, LS_STAGE_THREADS, (size_t)p->ls.stage_w * 8, s>>>(
@@ -3608,19 +3142,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 p->ls.blk_start.as<int32_t>(), p->ls.n_stage_blk, p->ls.xg.as<double>());
             ks.stop();
             CSRK_LAUNCH_CHECK();
-            return CSRK_OK;
-        };
-        if (do_light && p->ls.on && p->ls.n_cold && stage_first) CSRK_TRY(launch_stage());
+        }
         if (do_light && p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
             hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
                                                                             p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
-        }
-        // tier 1 beside tier 0: the pair kernel goes to the side stream, ordered after everything submitted to `s` so far
-        const bool beside = p->t1_beside && do_heavy && p->n_heavy && !p->acc.empty() && p->tier[1].on && !p->t1s.on;
-        if (beside) {
-            CSRK_HIP(hipEventRecord(p->ev_fork, s));
-            CSRK_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
         }
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
@@ -3632,73 +3158,41 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             }
             kh.stop();
         }
-        for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
-            Panel *pn = &p->tier[q];
-            if (!pn->on || (q == 0 && !p->acc.empty())) continue;
-            if (q == 1 && p->t1s.on) {      // tier 1 as a stream of (block, row) runs -> pair partials
-                constexpr size_t t1_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-                LightStream &t = p->t1s;
-                KernelTimer kh(p, s, 2);
-                spmv_lstream_kernel<LS_PLAIN><<<t.grid, LS_THREADS, t1_lds, s>>>(
-                    t.vals.as<double>(), t.idx.as<uint32_t>(), t.rowids.as<int32_t>(), t.tile_base.as<int32_t>(),
-                    t.carry_idx.as<int32_t>(), d_x,
-                    (p->ls.on && p->ls.n_cold) ? p->ls.xg.as<double>() + p->ls.n_cold : p->xh.as<double>(),
-                    p->n_hot ? p->n_hot_lds : 0, t.n_tiles, t.n_runs, t.n_out,
-                    pn->y.as<double>(), t.carry_row.as<int32_t>(), t.carry_val.as<double>(), (const int32_t *)nullptr,
-                    (const int32_t *)nullptr, (const int32_t *)nullptr);
-                kh.stop();
-                CSRK_LAUNCH_CHECK();
-                // (the stream form's carries go into the pair partials before the reduce reads them: a launch of their own)
-                spmv_merge_fixup_short_kernel<<<(unsigned)ceil_div(t.n_tiles, 256), 256, 0, s>>>(
-                    t.carry_row.as<int32_t>(), t.carry_val.as<double>(), t.n_tiles, pn->y.as<double>());
-                CSRK_LAUNCH_CHECK();
-                continue;
-            }
-            hipStream_t s_main = s;
-            if (q == 1 && beside) s = p->side;
-            KernelTimer kh(p, s, 1 + q);
+        if (do_heavy && p->n_heavy && p->tier1.on) {            // tier 1, pair form
+            Panel *pn = &p->tier1;
+            KernelTimer kh(p, s, 2);
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
         pn->carry_val.as<double>(), pn->nnz
             const unsigned grid = (unsigned)pn->groups;
-            if (q == 0) {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, s>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB0, true, PANEL_T0><<<grid, PANEL_T0, 0, s>>>(PANEL_ARGS(int32_t));
-            } else {
-                if (pn->p64) spmv_panel_kernel<int64_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
-                else spmv_panel_kernel<int32_t, PANEL_CB1, false, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
-            }
+            if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
+            else spmv_panel_kernel<int32_t, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
-            if (q == 1 && beside) {
-                CSRK_HIP(hipEventRecord(p->ev_join, p->side));
-                s = s_main;
-            }
             // (the pair kernel's carries are added by the tier's reduce: Panel::crp)
         }
         if (do_light) {
 #define MERGE_ARGS_LIGHT(CI)                                                                                        \
     p->rp_light.as<P>(), CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, p->nnz_light,                \
         p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->tile_cut.as<int32_t>(), p->cut_pos.as<int64_t>(),  \
-        p->cut_cum.as<int64_t>(), m->nnz, p->xh.as<double>()
+        p->cut_cum.as<int64_t>(), m->nnz
 #define MERGE_ARGS_FULL(CI)                                                                                         \
     rp, CI, m->d_values, d_x, d_y, p->tile_row.as<int32_t>(), m->nrows, m->nnz, p->carry_row.as<int32_t>(),          \
-        p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz, p->xh.as<double>()
+        p->carry_val.as<double>(), nullptr, nullptr, nullptr, m->nnz
             const unsigned grid = (unsigned)p->n_tiles;
             if (p->ls.on) {
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                 const double *x_cold = d_x, *x_pack = p->xh.as<double>();
                 if (p->ls.n_cold) {      // cold staging: the unpacked columns' x values, in the stream's order
-                    if (!stage_first) CSRK_TRY(launch_stage());
                     x_cold = p->ls.xg.as<double>();
                     x_pack = x_cold + p->ls.n_cold;
                 }
 #define LS_ARGS                                                                                                       \
     p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),      \
-        (const int32_t *)nullptr, x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
+        x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
         p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>()
                 constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                 const int32_t *nil = nullptr;
@@ -3707,8 +3201,6 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         if (p->ls.n_cold && p->ls.round_start.p)                                                                       \
             spmv_lstream_kernel<LS_RND, D><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                                    \
                 LS_ARGS, p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(), p->ls.wg_round0.as<int32_t>()); \
-        else if (p->ls.n_cold && p->ls.tile_cold.p)                                                                    \
-            spmv_lstream_kernel<LS_XGT, D><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, p->ls.tile_cold.as<int32_t>(), nil, nil); \
         else                                                                                                           \
             spmv_lstream_kernel<LS_PLAIN, D><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, nil, nil, nil);           \
     } while (0)
@@ -3727,15 +3219,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 }
             } else {
             KernelTimer kt(p, s);
-            if (p->n_hot) {
-                if (p->n_heavy)
-                    spmv_merge_kernel<P, VT, true, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(p->ci_hot.as<int32_t>()));
-                else
-                    spmv_merge_kernel<P, VT, false, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(p->ci_hot.as<int32_t>()));
-            } else if (p->n_heavy)
-                spmv_merge_kernel<P, VT, true, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
+            if (p->n_heavy)
+                spmv_merge_kernel<P, VT, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
             else
-                spmv_merge_kernel<P, VT, false, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
+                spmv_merge_kernel<P, VT, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
 #undef MERGE_ARGS_LIGHT
 #undef MERGE_ARGS_FULL
             kt.stop();
@@ -3749,18 +3236,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_LAUNCH_CHECK();
             }
         }
-        if (beside) CSRK_HIP(hipStreamWaitEvent(s, p->ev_join, 0));      // the epilogue's reduces read tier 1's pair partials
         if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
                 CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 4, nullptr, nullptr, nullptr));
-        for (int q = 0; q < 2 && p->n_heavy && do_heavy; q++) {
-            Panel *pn = &p->tier[q];
-            if (!pn->on || (q == 0 && !p->acc.empty())) continue;
-            // y[row] = sum over column blocks of the (block, row) partials, in block order
-            const bool stream_form = q == 1 && p->t1s.on;      // (its carries are in the partials already)
+        if (do_heavy && p->n_heavy && p->tier1.on) {
+            // y[row] = sum over column blocks of the (block, row) partials, in block order, then the row's listed carries
+            Panel *pn = &p->tier1;
             CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb, pn->nb > 64 ? 16 : 2,
-                             stream_form ? nullptr : pn->crp.as<int32_t>(), stream_form ? nullptr : pn->cidx.as<int32_t>(),
-                             stream_form ? nullptr : pn->carry_val.as<double>()));
+                             pn->crp.as<int32_t>(), pn->cidx.as<int32_t>(), pn->carry_val.as<double>()));
         }
         CSRK_TRY(flush_epi());      // the light stream's carries and the ordered reduces of the tiers, one launch
         break;
@@ -3819,59 +3302,6 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     }
 #undef GO
     return CSRK_ERR_INVALID;   // not reached
-}
-
-int spmv_tier0_view(Matrix *m, Tier0View *out)
-{
-    *out = Tier0View();
-    SpmvPlan *p = nullptr;
-    CSRK_TRY(get_plan(m, nullptr, &p));              // a query: builds the split eagerly
-    if (p->algo != CSRK_SPMV_MERGE || !p->n_heavy) return CSRK_OK;
-    if (!p->tier[0].on && !p->t0_rows.empty()) {
-        // SpMV itself runs tier 0 in accumulator form; the dense-panel SpMM wants the pair form
-        // (of the rows that reach the pair form's own threshold: the accumulator form may have extended
-        // tier 0 to shorter rows, which would only add thin pairs there)
-        std::lock_guard<std::mutex> lk(m->mu);
-        std::vector<int32_t> vr;
-        int64_t vn = 0;
-        for (size_t c = 0; c < p->t0_rows.size(); c++)
-            if (p->t0_lens[c] >= p->view_min) {
-                vr.push_back(p->t0_rows[c]);
-                vn += p->t0_lens[c];
-            }
-        if (!p->tier[0].on && !vr.empty()) {
-            int rc;
-#define BUILD0(PT_, VT)                                                                                            \
-    rc = build_panel<PT_, VT>(m, &p->tier[0], vr, vn, PANEL_CB0, true, PANEL_TPW, false, nullptr)
-            if (m->ptr64) {
-                if (m->val_type == CSRK_VAL_F64) BUILD0(int64_t, CSRK_VAL_F64);
-                else if (m->val_type == CSRK_VAL_F32) BUILD0(int64_t, CSRK_VAL_F32);
-                else BUILD0(int64_t, CSRK_VAL_NONE);
-            } else {
-                if (m->val_type == CSRK_VAL_F64) BUILD0(int32_t, CSRK_VAL_F64);
-                else if (m->val_type == CSRK_VAL_F32) BUILD0(int32_t, CSRK_VAL_F32);
-                else BUILD0(int32_t, CSRK_VAL_NONE);
-            }
-#undef BUILD0
-            CSRK_TRY(rc);
-            CSRK_HIP(hipDeviceSynchronize());
-        }
-    }
-    if (!p->tier[0].on) return CSRK_OK;
-    const Panel &t = p->tier[0];
-    out->on = true;
-    out->p64 = t.p64;
-    out->n_rows = t.nrow;
-    out->n_blocks = t.nb;
-    out->block_cols = t.cb;
-    out->min_entries = p->acc.empty() ? p->heavy_min : p->view_min;
-    out->pairs = t.rows;
-    out->nnz = t.nnz;
-    out->rp = t.rp.p;
-    out->ci = t.ci.as<int32_t>();
-    out->vs = t.vs.as<double>();
-    out->row_list = t.row_list.as<int32_t>();
-    return CSRK_OK;
 }
 
 }  // namespace csrk
@@ -4114,9 +3544,8 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     CSRK_REQUIRE(out && n >= 0, "out is NULL");
     SpmvPlan *p = nullptr;
     CSRK_TRY(get_plan(m, nullptr, &p));
-    const Panel &t0 = p->tier[0], &t1 = p->tier[1];
-    // tier 0: [4] tiles, [5] column blocks, [7] block width, [9] (block,row) pairs in pair form / rows in
-    // accumulator form, [10] entries, [18] form (0 pairs, 1 accumulator)
+    const Panel &t1 = p->tier1;
+    // tier 0: [4] tiles, [5] column blocks, [7] block width, [9] rows, [10] entries, [18] 1 (accumulator form)
     int64_t a_tiles = 0, a_rows = 0, a_nnz = 0, a_nb = 0;
     for (const AccPanel *ap : p->acc) {
         a_tiles += ap->tiles;
@@ -4126,30 +3555,20 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     }
     const bool af = !p->acc.empty();
     const int64_t plan_bytes = spmv_plan_bytes(p);      // [25]
-    // [26] tiles per staging round when the round is held in LDS (else 0); [27] workgroups of the accumulator kernel;
-    // [28] 1 when tier 1's pair kernel runs beside it on the plan's side stream
+    // [26] tiles per staging round (0: nothing staged); [27] workgroups of the accumulator kernel; [28] 0 (was: tier 1 on a side stream)
     const int64_t v[29] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
-                           af ? a_tiles : t0.tiles, af ? a_nb : t0.nb, p->heavy_min, af ? ACC_CB : t0.cb, p->n_heavy ? 2 : 0,
-                           af ? a_rows : t0.rows, af ? a_nnz : t0.nnz,
+                           a_tiles, a_nb, p->heavy_min, af ? ACC_CB : 0, p->n_heavy ? 2 : 0, a_rows, a_nnz,
                            t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
                            p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
                            p->ls.round_start.p ? p->ls.stage_tiles : 0,
-                           af ? (int64_t)p->acc[0]->n_wg : 0, (p->t1_beside && t1.on && !p->t1s.on) ? 1 : 0};
+                           af ? (int64_t)p->acc[0]->n_wg : 0, 0};
     for (int i = 0; i < n && i < 29; i++) out[i] = v[i];
     return CSRK_OK;
 }
 
-#ifdef CSRK_LS_STAMPS
-CSRK_API int csrk_debug_ls_stamps(unsigned long long *out, int n)
-{
-    CSRK_HIP(hipDeviceSynchronize());
-    CSRK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_stamps), (size_t)n * 8));
-    return CSRK_OK;
-}
-#endif
 
 int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *tile_items)
 {

@@ -351,65 +351,3 @@ def test_cold_staging_and_stream_forms_are_bit_neutral(monkeypatch):
         finally:
             check(lib.csrk_free(h))
     assert torch.equal(out['1'], out['0'])
-
-
-def test_tiers_side_by_side_opt_in(monkeypatch):
-    """
-    CSRK_SPMV_T1_BESIDE=1: tier 1's pair kernel on the plan's side stream beside the accumulator
-    kernel, which then runs on 25/32 of the CUs.  The products are bitwise reproducible run after run, equal to the
-    default plan's to rounding (the accumulator partials are cut differently: 200 workgroups instead of 256), the two-part
-    product still adds up, and a caller's own stream is honoured (fork and join around the side stream).
-    """
-    import torch
-    from csr_amd import synth
-    from csr_amd._lib import lib, check
-    dev = 'cuda'
-    n, nnz = 3_000_000, 60_000_000
-    m = synth.powerlaw_csr(n, n, nnz, device=dev)
-    x = synth.dense_vector(n, device=dev, stream=3)
-    mabs = dict(m)
-    mabs['values'] = m['values'].abs()
-    hb = _handle(mabs, n, n)
-    bound = torch.empty(n, dtype=torch.float64, device=dev)
-    xa = x.abs().contiguous()
-    _spmv(hb, xa, bound)
-    torch.cuda.synchronize()
-    check(lib.csrk_free(hb))
-    out = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('CSRK_SPMV_T1_BESIDE', mode)
-        h = _handle(m, n, n)
-        try:
-            y = torch.empty(n, dtype=torch.float64, device=dev)
-            for _ in range(3):
-                _spmv(h, x, y)
-            torch.cuda.synchronize()
-            st = (C.c_int64 * 29)()
-            check(lib.csrk_spmv_plan_stats(h, st, 29))
-            assert st[2] > 0 and st[13] > 0 and st[18] == 1          # rows cut out, tier 1 entries, accumulator form
-            worth = st[13] * 4.9 >= 0.08 * st[10] * 1.58                 # (the plan's own criterion: csrc/spmv.hip, build_tiers)
-            assert int(st[28]) == (int(mode) if worth else 0)
-            if mode == '1' and not worth:
-                pytest.skip('tier 1 too small on this matrix for the side-by-side form')
-            if mode == '1':
-                assert 0 < st[27] < torch.cuda.get_device_properties(0).multi_processor_count
-            ref = y.clone()
-            for _ in range(20):
-                _spmv(h, x, y)
-                assert torch.equal(y, ref)
-            side = torch.cuda.Stream()
-            with torch.cuda.stream(side):
-                y2 = torch.zeros(n, dtype=torch.float64, device=dev)
-                check(lib.csrk_spmv_device(h, x.data_ptr(), y2.data_ptr(), side.cuda_stream))
-            side.synchronize()
-            assert torch.equal(y2, ref)
-            yp = torch.full((n,), 3.0, dtype=torch.float64, device=dev)
-            check(lib.csrk_spmv_device_part(h, x.data_ptr(), yp.data_ptr(), None, 1))
-            check(lib.csrk_spmv_device_part(h, x.data_ptr(), yp.data_ptr(), None, 2))
-            torch.cuda.synchronize()
-            assert torch.equal(yp, ref)
-            out[mode] = ref
-        finally:
-            check(lib.csrk_free(h))
-    assert bool(((out['1'] - out['0']).abs() <= 1e-12 * bound + 1e-300).all())
-    assert float((out['1'] != out['0']).double().mean()) < 0.01       # only the accumulator tier's rows can differ

@@ -18,42 +18,24 @@ pytestmark = pytest.mark.gpu
 ALGOS = ['merge', 'vector', 'scalar']
 
 
-@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'forced_split_pairs', 'hot', 'forced_split_hot',
-                                      'forced_split_hot_nostream'])
+@pytest.fixture(autouse=True, params=['auto', 'forced_split', 'hot', 'forced_split_hot', 'forced_split_nostream'])
 def split_mode(request, monkeypatch):
     """
-    Every test runs six times (the last one: split + pack with the light stream off, i.e. the merge-path
-    tile kernel in its cut-table + packed-column form): with the library's own choice (small test matrices have an x that fits
-    in L2, so the long-row split and the hot-column pack stay off), with the split forced on (the panel
-    tiers are exercised on every shape; tier 0 in its default accumulator form), with the split forced on
-    and tier 0 in its (block, row)-pair form, with the hot-column pack forced on (renumbered colinds +
-    packed x in the tile kernel), and with split and pack both.
+    Every test runs five times: with the library's own choice (small test matrices have an x that fits in L2, so the
+    long-row split and the hot-column pack stay off: the merge-path tile kernel alone), with the split forced on (both
+    tiers on every shape), with the hot-column pack forced on (light stream with LDS / packed / staged x), with split and
+    pack both (the form the headline matrix runs in), and with the split forced on but the light stream off (what a
+    handle gets when the stream's copy of the matrix does not fit in memory: the tile kernel in its cut-table form
+    beside the tiers).
     """
+    for k in ('CSRK_SPMV_HEAVY_SPLIT', 'CSRK_SPMV_STREAM', 'CSRK_SPMV_HOT'):
+        monkeypatch.delenv(k, raising=False)
     if 'forced_split' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HEAVY_SPLIT', '1')
-    else:
-        monkeypatch.delenv('CSRK_SPMV_HEAVY_SPLIT', raising=False)
-    if 'nostream' in request.param:      # the merge-path tile kernel instead of the light stream
+    if 'nostream' in request.param:
         monkeypatch.setenv('CSRK_SPMV_STREAM', '0')
-    else:
-        monkeypatch.delenv('CSRK_SPMV_STREAM', raising=False)
-    if 'pairs' in request.param:      # tier 0 in its (block, row)-pair form (merge-path panel kernel), like tier 1
-        monkeypatch.setenv('CSRK_SPMV_TIER0', 'pairs')
-        monkeypatch.delenv('CSRK_SPMV_TIER1', raising=False)
-    else:
-        monkeypatch.delenv('CSRK_SPMV_TIER0', raising=False)
-        if request.param == 'forced_split_hot':      # ... and once with tier 1 as a stream of (block, row) runs
-            monkeypatch.setenv('CSRK_SPMV_TIER1', 'stream')
-        else:
-            monkeypatch.delenv('CSRK_SPMV_TIER1', raising=False)
-    if 'nostream' in request.param:      # ... and with tier 0 not extended below 512 entries: acc tier 0 beside a pair-kernel tier 1
-        monkeypatch.setenv('CSRK_ACC_FLOOR', '512')
-    else:
-        monkeypatch.delenv('CSRK_ACC_FLOOR', raising=False)
     if 'hot' in request.param:
         monkeypatch.setenv('CSRK_SPMV_HOT', '1')
-    else:
-        monkeypatch.delenv('CSRK_SPMV_HOT', raising=False)
     return request.param
 
 
@@ -327,10 +309,8 @@ def test_plan_stats_and_cache_trim(split_mode):
         st = (C.c_int64 * 20)()
         check(lib.csrk_spmv_plan_stats(h.H, st, 20))
         assert st[2] == 2                      # two rows cut out of the tile path
-        # tier-0 / tier-1 entries: the accumulator tier takes every cut row down to 128 entries while it has room
-        # (ACC_FLOOR; 512 in the 'nostream' mode), the pair form only rows of 2048 and more
-        t1 = 500 if ('pairs' in split_mode or 'nostream' in split_mode) else 0
-        assert st[10] == 4500 - t1 and st[13] == t1
+        # tier-0 / tier-1 entries: the accumulator tier takes every cut row down to 128 entries while it has room (ACC_FLOOR)
+        assert st[10] == 4500 and st[13] == 0
         assert st[3] == m.nnz - 4500
         if 'hot' in split_mode:
             # columns referenced at least twice by the tile path's rows are packed
