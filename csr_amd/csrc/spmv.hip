@@ -31,180 +31,12 @@
 // All kernels accumulate in float64 whatever the storage dtype, like the reference
 // (float32 values are widened on load; structure-only matrices multiply by 1.0,
 // csr/csr.py:254-262).
-#include "common.h"
-#include "wave.h"
+#include "spmv_plan.h"
 
 #include <algorithm>
 #include <ctime>
-#include <vector>
 
 namespace csrk {
-
-// ---- value loads ------------------------------------------------------------------------
-template <int VT> struct ValLoad;
-template <> struct ValLoad<CSRK_VAL_F64> {
-    static __device__ __forceinline__ double at(const void *v, int64_t k) { return ((const double *)v)[k]; }
-};
-template <> struct ValLoad<CSRK_VAL_F32> {
-    static __device__ __forceinline__ double at(const void *v, int64_t k) { return (double)((const float *)v)[k]; }
-};
-template <> struct ValLoad<CSRK_VAL_NONE> {
-    static __device__ __forceinline__ double at(const void *, int64_t) { return 1.0; }
-};
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;
-}
-
-// Sum p[s..e) strictly left to right (the reference's order), four LDS loads in flight at a time: a
-// plain `for (k) acc += p[k]` is a load -> wait -> add chain of ~100 cycles per entry.
-__device__ __forceinline__ double ordered_sum(const double *p, int s, int e)
-{
-    double acc = 0.0;
-    int k = s;
-    for (; k + 4 <= e; k += 4) {
-        const double a = p[k], b = p[k + 1], c = p[k + 2], d = p[k + 3];
-        acc += a;
-        acc += b;
-        acc += c;
-        acc += d;
-    }
-    for (; k < e; k++) acc += p[k];
-    return acc;
-}
-
-// ---- plan ---------------------------------------------------------------------------------
-// One column-blocked panel: the entries of a set of long rows re-sorted block-major into a matrix
-// M' whose rows are (column block, long row) pairs; see "long rows, panel form" below.
-struct Panel {
-    bool on = false, p64 = false;
-    int32_t cb = 0, nb = 0, nrow = 0;            // block width (columns), blocks, long rows in this tier
-    int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
-    DevBuf row_list;                             // int32[nrow]: original row ids, ascending
-    DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y;
-    // the tiles' carries, listed per long row (static: a tile's carry belongs to the pair its last row end falls in):
-    // carries of long row h = carry_val[cidx[crp[h] .. crp[h + 1])], in tile order -- added by the tier's ordered reduce
-    DevBuf crp, cidx;
-};
-
-// one segment of an accumulator-form workgroup's tile range (see "long rows, accumulator form")
-struct AccSeg {
-    int64_t tile0;    // first tile of the segment (logical: block-major order)
-    int64_t ptile0;   // ... and where it is stored; the segment's tile t is stored at ptile0 + t * n_wg
-    int32_t ntiles;   // <= ACC_SEG_TILES, all in one column block
-    int32_t blk;
-};
-
-// Tier 0 in accumulator form: one group of <= ACC_MAXROWS heavy rows (see "long rows, accumulator form")
-struct AccPanel {
-    int32_t nrow = 0, nb = 0, n_wg = 0;
-    int64_t tiles = 0, nnz = 0, n_segs = 0;
-    size_t lds = 0;
-    DevBuf row_list, vals, idx, tile_row0, segs, wg_seg, partial;      // idx: 16-bit words (column, row step)
-};
-
-// A light stream (see "short rows: the light stream"): a private tiled copy of a set of rows ("runs") plus
-// the tables the one-wavefront-per-tile kernel needs.
-struct LightStream {
-    bool on = false;
-    int64_t n_tiles = 0;
-    int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
-    unsigned grid = 0;
-    DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
-    // dense rows (build_light_stream): EVERY row of the view has a run -- a row without entries holds one padding entry --
-    // so run k is row k: no row-id table (`rowids` stays empty), no gaps to clear
-    bool dense = false;
-    // cold staging (build_cold_stage): the x values of the stream's unpacked columns, copied per call into the
-    // order the stream reads them
-    int64_t n_cold = 0;
-    int32_t n_stage_blk = 0, stage_w = 0;
-    DevBuf xg, a_col, a_dst, blk_start;
-    // round-in-LDS staging (build_cold_stage, LS_RND): workgroup b walks rounds wg_round0[b] .. wg_round0[b + 1]; round r =
-    // tiles round_tile0[r] .. round_tile0[r + 1] (at most `stage_tiles`), whose staged values xg[round_start[r] ..
-    // round_start[r + 1]) the workgroup copies into LDS; a cold entry's index word holds its offset inside that range
-    int32_t stage_tiles = 0;
-    DevBuf round_start, round_tile0, wg_round0;
-};
-
-struct SpmvPlan {
-    int algo = CSRK_SPMV_MERGE;
-    // merge
-    int tile_items = 0;
-    int64_t n_tiles = 0;
-    DevBuf tile_row;    // int32[n_tiles + 1]: rows completed before each tile boundary
-    DevBuf carry_row;   // int32[n_tiles]
-    DevBuf carry_val;   // double[n_tiles]
-    // merge, long-row split: rows >= the cut threshold are taken out of the merge path (light view)
-    // and served by one or two column-blocked panels
-    bool split_considered = false; // false: built without looking at the long-row split (first call)
-    int32_t n_heavy = 0;          // rows cut out
-    int32_t heavy_min = 0;        // tier 0 holds the cut rows with at least this many entries
-    int64_t nnz_light = 0;
-    DevBuf rp_light;    // P[nrows + 1]: row pointers with the cut rows collapsed to length 0
-    DevBuf cut_pos;     // int64[n_heavy]: light-index position of each cut row
-    DevBuf cut_cum;     // int64[n_heavy + 1]: cut entries before each cut row (shift table)
-    DevBuf tile_cut;    // int32[n_tiles + 1]: cuts at or before each tile start
-    DevBuf heavy_row;   // int32[n_heavy]
-    // merge, hot-column pack: the HOT_SLOTS most referenced columns are renumbered to -1 - slot in a
-    // copy of colinds; their x values are packed into xh before every tile-kernel launch
-    int32_t n_hot = 0;            // 0: no pack
-    int32_t n_hot_lds = 0;        // slots [0, n_hot_lds) hold the most referenced columns (kept in LDS by the light stream)
-    int32_t hot_slots = 0;
-    double hot_cover = 0.0;       // sampled fraction of the tile kernel's entries on packed columns
-    DevBuf hot_slot;    // int32[ncols]: slot of a packed column, -1 otherwise (kept until the light stream is built)
-    DevBuf hot_cols;    // int32[n_hot]: column of each slot
-    DevBuf xh;          // double[n_hot]
-    Panel tier1;        // mid rows: (column block, row) pairs over 262144-column blocks, the x window kept in L2 by
-                        // block-major, XCD-aware scheduling
-    LightStream ls;                       // the rows that stay on the row-major path
-    std::vector<int32_t> t1_rows;         // tier-1 rows (ascending) and their entries: build_tiers
-    int64_t t1_nnz = 0;
-    std::vector<AccPanel *> acc;          // tier 0: accumulator form, groups of <= ACC_MAXROWS rows
-    std::vector<int32_t> t0_rows;         // tier-0 rows (ascending) and their lengths
-    std::vector<int64_t> t0_lens;
-    // vector
-    int64_t n_segs = 0;
-    DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
-    DevBuf seg_row;     // int32[n_segs]
-    DevBuf seg_part;    // double[n_segs]
-    // kernel timing (csrk_spmv_profile_begin/end)
-    std::vector<hipEvent_t> ev;   // start/stop pairs
-    std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1/2 = panel tier 0/1
-    int ev_used = 0;
-    bool profiling = false;
-    int prof_every = 1;           // profile every n-th launch group only (an event pair costs ~3 us on the stream)
-    int prof_calls = 0;
-    int prof_mask = 0xf;          // channels that get event pairs (csrk_spmv_profile_channels)
-    bool prof_this = false;       // the launch group in progress is being timed
-    ~SpmvPlan()
-    {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        for (AccPanel *a : acc) delete a;
-    }
-};
-
-struct KernelTimer {   // records an event pair around one launch when the plan is profiling
-    SpmvPlan *p;
-    hipStream_t s;
-    int slot = -1;
-    KernelTimer(SpmvPlan *p_, hipStream_t s_, int chan = 0) : p(p_), s(s_)
-    {
-        if (p->profiling && p->prof_this && ((p->prof_mask >> chan) & 1) && p->ev_used + 2 <= (int)p->ev.size()) {
-            slot = p->ev_used;
-            p->ev_used += 2;
-            p->ev_chan[slot / 2] = chan;
-            (void)hipEventRecord(p->ev[slot], s);
-        }
-    }
-    void stop()
-    {
-        if (slot >= 0) (void)hipEventRecord(p->ev[slot + 1], s);
-    }
-};
-
 void free_spmv_plan(SpmvPlan *p) { delete p; }
 
 // device memory the plan holds (private streams, tables, scratch)
@@ -233,46 +65,6 @@ int64_t spmv_plan_bytes(const SpmvPlan *p)
     return plan_bytes;
 }
 
-
-constexpr int MERGE_THREADS = 256;
-constexpr int MERGE_IPT = 8;
-constexpr int MERGE_ITEMS = MERGE_THREADS * MERGE_IPT;   // 2048 path items per tile
-constexpr int MERGE_LONG = 64;                           // rows this long get a whole wave
-constexpr int MERGE_MAXLONG = MERGE_ITEMS / MERGE_LONG + 2;
-
-// tile_row[t] = number of row ends consumed before merge-path diagonal d = min(t*ITEMS, nrows+nnz).
-// Row end r (= rp[r+1]) is consumed once all its nnz are: it lies before diagonal d iff
-// rp[r+1] + r + 1 <= d.
-template <class P>
-__global__ void merge_plan_kernel(const P *__restrict__ rp, int32_t nrows, int64_t nnz, int items,
-                                  int64_t n_tiles, int32_t *__restrict__ tile_row)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    int64_t total = (int64_t)nrows + nnz;
-    int64_t d = t * items;
-    if (d > total) d = total;
-    int64_t lo = d - nnz > 0 ? d - nnz : 0;
-    int64_t hi = d < nrows ? d : nrows;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)rp[mid + 1] <= d - mid - 1)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    tile_row[t] = (int32_t)lo;
-}
-
-// 4-byte-aligned pair types: tile starts fall on arbitrary nnz indices, and gfx950 global loads
-// only need dword alignment, so two consecutive colinds / values are fetched with one
-// dwordx2 / dwordx4 load per lane (512 B / 1 KiB per wave-instruction).
-typedef int32_t i32x2_t __attribute__((ext_vector_type(2)));
-typedef double f64x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef i32x2_t I32x2 __attribute__((aligned(4)));
-typedef f64x2_t F64x2 __attribute__((aligned(4)));
-typedef f32x2_t F32x2 __attribute__((aligned(4)));
 
 template <int VT>
 __device__ __forceinline__ void load_val_pair(const void *vs, int64_t k, bool two, double &v0, double &v1)
@@ -521,58 +313,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     }
 }
 
-// ---- hot-column cache: plan-time kernels ------------------------------------------------------------
-// Column reference counts over the rows the tile kernel serves, from every `row_stride`-th row and at
-// most 128 entries of it (a sample is enough to rank popularity); total[0] = entries counted.
-// Popular columns collect millions of these increments: as global atomics they serialise (14 ms for the 4*10^7
-// sampled entries of the headline matrix).  Each persistent workgroup therefore counts into an LDS hash table
-// first (a column that finds a slot within HOT_PROBE probes stays there; the others go straight to memory) and
-// flushes its <= HOT_TABLE distinct columns once at the end.
-constexpr int HOT_TABLE = 8192, HOT_PROBE = 4;
-template <class P>
-__global__ __launch_bounds__(256) void hot_count_kernel(const P *__restrict__ rp, const P *__restrict__ rp_light,
-                                                       const int32_t *__restrict__ ci, int32_t nrows, int64_t row_stride,
-                                                       int32_t *__restrict__ cnt, unsigned long long *__restrict__ total)
-{
-    __shared__ int32_t s_key[HOT_TABLE];
-    __shared__ int32_t s_cnt[HOT_TABLE];
-    for (int k = threadIdx.x; k < HOT_TABLE; k += 256) {
-        s_key[k] = -1;
-        s_cnt[k] = 0;
-    }
-    __syncthreads();
-    const int64_t n_sampled = (nrows + row_stride - 1) / row_stride;
-    unsigned long long n = 0;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_sampled; q += (int64_t)gridDim.x * 256) {
-        const int64_t r = q * row_stride;
-        if (rp_light && rp_light[r + 1] == rp_light[r]) continue;      // a row cut out to the tiers
-        const int64_t s = rp[r];
-        int64_t e = rp[r + 1];
-        e = e - s > 128 ? s + 128 : e;
-        for (int64_t k = s; k < e; k++) {
-            const int32_t c = ci[k];
-            uint32_t slot = ((uint32_t)c * 2654435761u) >> 19;      // 13 bits
-            bool done = false;
-#pragma unroll
-            for (int pr = 0; pr < HOT_PROBE && !done; pr++) {
-                const int32_t old = atomicCAS(&s_key[slot], -1, c);
-                if (old == -1 || old == c) {
-                    atomicAdd(&s_cnt[slot], 1);
-                    done = true;
-                }
-                slot = (slot + 1) & (HOT_TABLE - 1);
-            }
-            if (!done) atomicAdd(&cnt[c], 1);
-        }
-        n += (unsigned long long)(e - s);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < HOT_TABLE; k += 256)
-        if (s_key[k] >= 0) atomicAdd(&cnt[s_key[k]], s_cnt[k]);
-    for (int off = WAVE / 2; off; off >>= 1) n += __shfl_down(n, off, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && n) atomicAdd(total, n);
-}
-
 __global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__restrict__ hot_cols, int32_t n_hot,
                                 double *__restrict__ xh)
 {
@@ -580,287 +320,6 @@ __global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__r
     if (i < n_hot) xh[i] = x[hot_cols[i]];
 }
 
-// out[0] = #columns with count >= thr, out[1] = sum of their counts
-__global__ __launch_bounds__(256) void hot_census_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr,
-                                                        unsigned long long *__restrict__ out)
-{
-    unsigned long long n = 0, sum = 0;
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * 256) {
-        const int32_t v = cnt[c];
-        if (v >= thr) {
-            n++;
-            sum += (unsigned long long)v;
-        }
-    }
-    for (int off = WAVE / 2; off; off >>= 1) {
-        n += __shfl_down(n, off, WAVE);
-        sum += __shfl_down(sum, off, WAVE);
-    }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && n) {
-        atomicAdd(&out[0], n);
-        atomicAdd(&out[1], sum);
-    }
-}
-
-// The whole census in one pass: hist[v] = {#columns with count == v, sum of their counts} for v < HOT_HIST (counts at or
-// above it share the last bin), so that the host finds the threshold for any slot budget from ONE copy instead of a
-// binary search of ~27 launches and round trips (2.5 ms of the headline matrix's plan).  Small counts -- nearly all
-// columns -- go through an LDS histogram.
-constexpr int HOT_HIST = 65536, HOT_HIST_LDS = 2048;
-__global__ __launch_bounds__(256) void hot_hist_kernel(const int32_t *__restrict__ cnt, int32_t ncols,
-                                                      unsigned long long *__restrict__ hist_n,
-                                                      unsigned long long *__restrict__ hist_sum)
-{
-    __shared__ unsigned int s_n[HOT_HIST_LDS];
-    for (int k = threadIdx.x; k < HOT_HIST_LDS; k += 256) s_n[k] = 0u;
-    __syncthreads();
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * 256) {
-        const int32_t v = cnt[c];
-        if (v < HOT_HIST_LDS) {
-            atomicAdd(&s_n[v], 1u);
-        } else {
-            const int b = v < HOT_HIST ? v : HOT_HIST;
-            atomicAdd(&hist_n[b], 1ull);
-            atomicAdd(&hist_sum[b], (unsigned long long)v);
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < HOT_HIST_LDS; k += 256)
-        if (s_n[k]) {
-            atomicAdd(&hist_n[k], (unsigned long long)s_n[k]);
-            atomicAdd(&hist_sum[k], (unsigned long long)s_n[k] * (unsigned long long)k);
-        }
-}
-
-__global__ void hot_flag_kernel(const int32_t *__restrict__ cnt, int32_t ncols, int32_t thr, int32_t *__restrict__ flag)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= ncols) flag[c] = (c < ncols && cnt[c] >= thr) ? 1 : 0;
-}
-
-// pos[c] = exclusive scan of the flags: the packed columns in column order, with their counts
-__global__ void hot_list_kernel(const int32_t *__restrict__ cnt, const int32_t *__restrict__ pos, int32_t ncols,
-                                int32_t thr, int32_t *__restrict__ hot_cols, int32_t *__restrict__ hot_cnt)
-{
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncols && cnt[c] >= thr) {
-        hot_cols[pos[c]] = (int32_t)c;
-        hot_cnt[pos[c]] = cnt[c];
-    }
-}
-
-// slot[hot_cols[k]] = k (hot_cols in its final, popularity order)
-__global__ void hot_slot_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t *__restrict__ slot)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_hot) slot[hot_cols[k]] = k;
-}
-
-static int HEAVY_MIN = 2048;      // tier 0 threshold (CSRK_HEAVY_MIN)
-static int TIERB_MIN = 128;       // tier 1 threshold (CSRK_TIERB_MIN; 0 disables tier 1)
-
-template <class P>
-__global__ void heavy_flag_kernel(const P *__restrict__ rp, int32_t nrows, int32_t *__restrict__ flag,
-                                  int64_t *__restrict__ hlen, int cut_min)
-{
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nrows) return;
-    int64_t len = r < nrows ? (int64_t)rp[r + 1] - (int64_t)rp[r] : 0;
-    bool h = len >= cut_min;
-    flag[r] = h ? 1 : 0;
-    hlen[r] = h ? len : 0;
-}
-
-template <class P>
-__global__ void heavy_view_kernel(const P *__restrict__ rp, int32_t nrows, const int32_t *__restrict__ hidx,
-                                  const int64_t *__restrict__ hbefore, P *__restrict__ rp_light,
-                                  int32_t *__restrict__ heavy_row, int64_t *__restrict__ cut_pos,
-                                  int64_t *__restrict__ cut_cum, int64_t *__restrict__ cut_len, int32_t n_heavy)
-{
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nrows) return;
-    const int64_t light = (int64_t)rp[r] - hbefore[r];
-    rp_light[r] = (P)light;
-    if (r < nrows && hidx[r + 1] != hidx[r]) {     // row r is cut out
-        const int32_t c = hidx[r];
-        heavy_row[c] = (int32_t)r;
-        cut_pos[c] = light;
-        cut_cum[c] = hbefore[r];
-        cut_len[c] = (int64_t)rp[r + 1] - (int64_t)rp[r];
-    }
-    if (r == nrows) cut_cum[n_heavy] = hbefore[nrows];
-}
-
-template <class P>
-__global__ void heavy_sorted_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t *__restrict__ bad)
-{
-    const int c = blockIdx.x;
-    if (c >= n_heavy) return;
-    const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    // (a 10^6-entry row is one workgroup's: 1024 threads with four comparisons in flight each; 256 threads one at a time
-    // made this check 1.8 ms of the headline matrix's plan)
-    bool b = false;
-    const int64_t step = (int64_t)blockDim.x * 4;
-    for (int64_t k0 = s + threadIdx.x; k0 + 1 < e; k0 += step) {
-        int32_t a[4], n[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t k = k0 + (int64_t)u * blockDim.x;
-            const bool in = k + 1 < e;
-            a[u] = in ? ci[k] : 0;
-            n[u] = in ? ci[k + 1] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) b |= a[u] > n[u];
-    }
-    if (b) atomicOr(bad, 1);
-}
-
-__device__ __forceinline__ int64_t lower_bound_col(const int32_t *__restrict__ ci, int64_t lo, int64_t hi, int64_t col)
-{
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)ci[mid] < col)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// cuts at or before each tile start: tile_cut[t] = #{c : cut_pos[c] <= j0(t)}
-__global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64_t n_tiles, int items, int64_t total,
-                                     const int64_t *__restrict__ cut_pos, int32_t n_heavy, int32_t *__restrict__ tile_cut)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    int64_t d = t * items;
-    if (d > total) d = total;
-    const int64_t j0 = d - tile_row[t];
-    int32_t lo = 0, hi = n_heavy;
-    while (lo < hi) {
-        int32_t mid = (lo + hi) >> 1;
-        if (cut_pos[mid] <= j0)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    tile_cut[t] = lo;
-}
-
-// ---- mid rows, pair form (tier 1) ---------------------------------------------------------------
-// At plan time the rows' entries are re-sorted column-block-major into a panel matrix M' whose rows are (column block
-// b, row h) pairs; values are widened to float64.  Per call the merge-tile algorithm runs over M' with tiles confined
-// to one block; row sums of M' are the per-(block, row) partials y'[b][h], reduced over b in block order by the
-// epilogue.  No float atomics: deterministic.  Rows of 128 .. tier-0 threshold entries: a (row, block) pair of 4096
-// columns would hold < 1 entry, so blocks are 262144 columns (2 MiB of x) and x is gathered from global memory; tiles
-// run block-major and block b is served only by workgroups with blockIdx % 8 == b % 8 (one XCD, so ONE L2 holds the
-// window -- a speed assumption only), which turns Infinity-Cache gathers into L2 hits.  (The longest rows had this form
-// too, with the x window in LDS, until the accumulator form below replaced it.)
-constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block, row) pairs of 131072 at the same kernel time, -9 us of partials)
-#ifndef PANEL_T1
-#define PANEL_T1 256
-#endif
-
-template <class P>
-__global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                   const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                   int32_t cb, int64_t *__restrict__ cnt)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);      // index = b * H + c
-    const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
-    const int64_t hi = lower_bound_col(ci, lo, e, (int64_t)(b + 1) * cb);
-    cnt[i] = hi - lo;
-}
-
-template <class P, int VT, class PP>
-__global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                  const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
-                                  int32_t cb, const int64_t *__restrict__ off, PP *__restrict__ prp,
-                                  int32_t *__restrict__ pci, double *__restrict__ pvs)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t pairs = (int64_t)n_heavy * n_blocks;
-    if (i > pairs) return;
-    prp[i] = (PP)off[i];
-    if (i == pairs) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
-    const int32_t r = heavy_row[c];
-    const int64_t s = rp[r], e = rp[r + 1];
-    const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
-    const int64_t n = off[i + 1] - off[i];
-    int64_t o = off[i];
-    for (int64_t k = lo; k < lo + n; k++, o++) {
-        pci[o] = ci[k];
-        pvs[o] = ValLoad<VT>::at(vs, k);
-    }
-}
-
-struct PanelTile {
-    int64_t j0;      // first entry of the tile in M'
-    int32_t i0, i1;  // rows of M' completed before the tile start / end
-    int32_t nn;      // entries in the tile
-    int32_t blk;     // column block
-};
-
-// one thread per tile: merge-path coordinates inside the tile's block
-template <class PP>
-__global__ void panel_plan_kernel(const PP *__restrict__ prp, int32_t n_heavy, int32_t n_blocks,
-                                  const int64_t *__restrict__ blk_tile0, int64_t n_tiles, int items,
-                                  PanelTile *__restrict__ tiles)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    int32_t lo = 0, hi = n_blocks;                 // block with blk_tile0[b] <= t < blk_tile0[b+1]
-    while (hi - lo > 1) {
-        int32_t mid = (lo + hi) >> 1;
-        if (blk_tile0[mid] <= t)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const int32_t b = lo;
-    const int64_t r0 = (int64_t)b * n_heavy;                    // first row of the block in M'
-    const int64_t e0 = (int64_t)prp[r0], e1 = (int64_t)prp[r0 + n_heavy];
-    const int64_t total = (int64_t)n_heavy + (e1 - e0);
-    const int64_t lt = t - blk_tile0[b];
-    int64_t coord[2];
-    for (int q = 0; q < 2; q++) {
-        int64_t d = (lt + q) * items;
-        if (d > total) d = total;
-        int64_t a = d - (e1 - e0) > 0 ? d - (e1 - e0) : 0, z = d < n_heavy ? d : n_heavy;
-        while (a < z) {
-            int64_t mid = (a + z) >> 1;
-            if ((int64_t)prp[r0 + mid + 1] - e0 <= d - mid - 1)
-                a = mid + 1;
-            else
-                z = mid;
-        }
-        coord[q] = a;                                           // rows of the block consumed before d
-    }
-    int64_t d0 = lt * items, d1 = (lt + 1) * items;
-    if (d0 > total) d0 = total;
-    if (d1 > total) d1 = total;
-    PanelTile pt;
-    pt.i0 = (int32_t)(r0 + coord[0]);
-    pt.i1 = (int32_t)(r0 + coord[1]);
-    pt.j0 = e0 + (d0 - coord[0]);
-    pt.nn = (int32_t)((d1 - coord[1]) - (d0 - coord[0]));
-    pt.blk = b;
-    tiles[t] = pt;
-}
-
-struct PanelGroup {
-    int64_t t0;      // first tile
-    int32_t nt;      // tiles handled by this workgroup (all in one column block)
-    int32_t blk;
-};
 template <class PP, int PT>
 __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
@@ -998,210 +457,6 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     }
 #undef PANEL_LOAD_TILE
 }
-
-__global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
-                                       int64_t *__restrict__ out)
-{
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= n_blocks) out[b] = off[(int64_t)b * n_heavy];
-}
-
-// ---- long rows, accumulator form (tier 0, default) ---------------------------------------------------
-// The pair form above spends a quarter of the tier-0 traffic on bookkeeping: a row pointer and a partial
-// per (column block, row) pair (avg. 7.8 entries), the partials re-read by the reduce, plus four
-// workgroup barriers per 2048-item tile.  The heavy rows are FEW (thousands), so one accumulator per heavy
-// row fits in LDS next to the x window: 8192 rows * 8 B = 64 KiB + 32 KiB.  The accumulator form is a pure
-// stream:
-//   * Heavy rows are taken in groups of <= ACC_MAXROWS.  A group's entries are stored column-block-major
-//     (block = ACC_CB columns), inside a block by heavy row, as (float64 value, packed uint32
-//     {column - block start : 13 bits, heavy-row index : 13 bits}) = 12 B per entry, nothing else.
-//   * A block's entries are padded to whole TILES of 512 = 64 lanes x 8 entries; a tile is stored lane-
-//     interleaved so that one wavefront reads it with 16-B-per-lane coalesced loads and every lane
-//     receives 8 CONSECUTIVE entries (a run of one row is then mostly inside one lane).
-//   * A persistent workgroup (one per CU, 16 wavefronts) owns a contiguous range of tiles, cut into
-//     SEGMENTS (tiles of one column block, <= 256).  Per segment: the block's x window -> LDS; each
-//     wavefront walks tiles: lane-local ordered sums per row, a segmented scan over the lanes (__shfl_up)
-//     joins the runs that cross lanes, and the finished row sums are added to the LDS accumulators.
-//   * Determinism: within a segment a row's run is owned by the tile it starts in; the leading run of a
-//     tile (which may belong to the previous tile's last row) is parked in a per-tile head slot instead and
-//     the heads are folded in, in tile order, by one wavefront after the segment's barrier.  So every
-//     accumulator sees its addends in a fixed order whichever wavefront took which tile: results are
-//     bitwise reproducible, although ds_add_f64 is used for the adds.
-//   * At the end the workgroup stores its accumulators (H * 8 B) and acc_reduce_multi_kernel sums the
-//     workgroups' partials in workgroup order into y.
-// HBM traffic: 12 B per entry + one 32 KiB window per segment + n_wg * H * 8 B of partials (14 MB on the
-// headline matrix) -- against 12 B + 20 B per pair + windows for the pair form.
-constexpr int ACC_CB = 4096;
-constexpr int ACC_K = 8;                      // consecutive entries per lane
-constexpr int ACC_TILE = WAVE * ACC_K;        // 512
-constexpr int ACC_MAXROWS = 15936;            // heavy rows per group: 124.5 KiB of accumulators + 32 KiB window + 3 KiB of head slots <= 160 KiB
-constexpr int ACC_FLOOR = 128;                // tier 0 is never extended to rows shorter than this (512 before the 10-B stream: a rank of an 8-way split ran 0.129 ms, 0.119 with 128)
-constexpr int ACC_SEG_TILES = 256;            // head slots per segment
-constexpr int ACC_THREADS = 1024;
-// index word of the accumulator stream, 16 bits: column - block start in the low 13 (ACC_CB = the zero slot of the
-// window, for padding), and in the high 3 the STEP from the previous entry's heavy-row index to this one's (rows
-// ascend inside a block; 0 = same row).  A tile's first entry has step 0 and its row in tile_row0[]; a step over 7
-// is bridged by padding entries (0.0 * zero slot) of step 7.  10 B per entry instead of 12: the kernel runs at the
-// fabric's rate, so bytes are its time (16-bit columns + a row id per run, fetched by a dependent load, had not paid).
-constexpr int ACC_ROW_SHIFT = 13;
-constexpr uint32_t ACC_COL_MASK = (1u << ACC_ROW_SHIFT) - 1;
-constexpr int ACC_MAXSTEP = 7;
-
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-// physical slot of logical entry e (0..511) of a tile: lane = e / 8, j = e % 8
-__host__ __device__ __forceinline__ int acc_val_slot(int e)
-{
-    const int lane = e >> 3, j = e & 7;
-    return (j >> 1) * (2 * WAVE) + lane * 2 + (j & 1);        // four 16-B loads per lane
-}
-__host__ __device__ __forceinline__ int acc_idx_slot(int e)
-{
-    const int lane = e >> 3, j = e & 7;
-    return (j >> 2) * (4 * WAVE) + lane * 4 + (j & 3);        // two 16-B loads per lane
-}
-
-// Where each column block starts inside each heavy row, from ONE pass over the rows' (ascending) columns:
-// pstart[b * H + c] = entries of heavy row c in blocks < b, for b = 0 .. n_blocks (the last = the row's length).
-// One wavefront per 4096-entry piece of a row; an entry whose block differs from its predecessor's opens that
-// block and every empty block skipped in between.  (A binary search per (block, row) pair -- 3.7 * 10^7 pairs on
-// the headline matrix, twice -- was 14 ms of the plan.)
-constexpr int ACC_PIECE = 4096;
-template <class P>
-__global__ __launch_bounds__(256) void acc_pairstart_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                           const int32_t *__restrict__ heavy_row, int32_t n_heavy,
-                                                           int32_t n_blocks, int32_t cb, const int32_t *__restrict__ task_row,
-                                                           const int32_t *__restrict__ task_piece, int64_t n_tasks,
-                                                           int32_t *__restrict__ pstart)
-{
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (q >= n_tasks) return;
-    const int32_t c = task_row[q];
-    const int64_t s = rp[heavy_row[c]], e = rp[heavy_row[c] + 1];
-    const int64_t k0 = s + (int64_t)task_piece[q] * ACC_PIECE;
-    const int64_t k1 = k0 + ACC_PIECE < e ? k0 + ACC_PIECE : e;
-    for (int64_t k = k0 + lane; k < k1; k += WAVE) {
-        const int32_t b = ci[k] / cb;
-        const int32_t bp = k > s ? ci[k - 1] / cb : -1;
-        for (int32_t bb = bp + 1; bb <= b; bb++) pstart[(int64_t)bb * n_heavy + c] = (int32_t)(k - s);
-        if (k == e - 1)
-            for (int32_t bb = b + 1; bb <= n_blocks; bb++) pstart[(int64_t)bb * n_heavy + c] = (int32_t)(e - s);
-    }
-}
-
-__global__ void acc_paircount_kernel(const int32_t *__restrict__ pstart, int64_t pairs, int32_t n_heavy,
-                                     int64_t *__restrict__ cnt)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pairs) cnt[i] = (int64_t)pstart[i + n_heavy] - (int64_t)pstart[i];
-}
-
-// One wavefront per column block: gap[b * H + c] = distance from heavy row c to the previous heavy row with entries in
-// block b (0 for the block's first one and for absent pairs), and the padding entries a gap over ACC_MAXSTEP needs
-// are added to the pair's count.
-__global__ __launch_bounds__(256) void acc_gap_kernel(int64_t *__restrict__ cnt, int32_t n_heavy, int32_t n_blocks,
-                                                     int32_t *__restrict__ gap)
-{
-    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (b >= n_blocks) return;
-    int32_t last = -1;
-    for (int32_t c0 = 0; c0 < n_heavy; c0 += WAVE) {
-        const int32_t c = c0 + lane;
-        const bool present = c < n_heavy && cnt[b * n_heavy + c] > 0;
-        const unsigned long long mask = __ballot(present);
-        const unsigned long long below = lane ? (mask & (~0ull >> (WAVE - lane))) : 0ull;
-        const int32_t prev = below ? c0 + 63 - __clzll((long long)below) : last;
-        if (c < n_heavy) {
-            const int32_t g = present && prev >= 0 ? c - prev : 0;
-            gap[b * n_heavy + c] = g;
-            if (g > ACC_MAXSTEP) cnt[b * n_heavy + c] += (g - 1) / ACC_MAXSTEP;
-        }
-        if (mask) last = c0 + 63 - __clzll((long long)mask);
-    }
-}
-
-// Where logical tile t is stored.  Workgroup w owns the logical tiles [wg_t0[w], wg_t0[w + 1]); its k-th tile is stored
-// at k * n_wg + w, i.e. the workgroups' streams are interleaved tile by tile: the persistent workgroups advance at
-// about the same pace, so at any moment they read one contiguous ~1 MB window of the array, spread over all HBM
-// channels.  (Contiguous per-workgroup ranges put 256 concurrent streams at a fixed stride: when that stride
-// resonates with the channel interleave the kernel loses up to 38 % -- 0.129 -> 0.177 ms measured on a 2-way partition's
-// shard at 580 tiles per workgroup, 0.218 -> 0.224 on the headline matrix; any other workgroup count restored the rate.)
-__device__ __forceinline__ int64_t acc_phys_tile(int64_t t, const int64_t *__restrict__ wg_t0, int32_t n_wg)
-{
-    int32_t lo = 0, hi = n_wg - 1;      // the workgroup with wg_t0[w] <= t < wg_t0[w + 1]
-    while (lo < hi) {
-        const int32_t mid = lo + ((hi - lo + 1) >> 1);
-        if (wg_t0[mid] <= t)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    return (t - wg_t0[lo]) * n_wg + lo;
-}
-
-// one thread per (block, heavy row) pair: copies the pair's entries into the tiled stream (after the padding
-// entries that bridge a long step)
-template <class P, int VT>
-__global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks, int32_t cb,
-                                const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
-                                const int32_t *__restrict__ pstart, const int32_t *__restrict__ gap,
-                                double *__restrict__ pvals, uint16_t *__restrict__ pidx, int32_t *__restrict__ tile_row0,
-                                const int64_t *__restrict__ wg_t0, int32_t n_wg)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
-    const int64_t n_all = off[i + 1] - off[i];
-    if (n_all == 0) return;
-    const int32_t g = gap[i];
-    const int32_t npad = g > ACC_MAXSTEP ? (g - 1) / ACC_MAXSTEP : 0;
-    const int64_t n = n_all - npad;
-    const int32_t r = heavy_row[c];
-    const int64_t lo = (int64_t)rp[r] + pstart[i];
-    int64_t L = blk_tile0[b] * ACC_TILE + (off[i] - off[(int64_t)b * n_heavy]);      // logical position
-    int64_t t_of = -1, pt = 0;                                 // the logical tile last looked up and where it is stored
-    for (int32_t k = 1; k <= npad; k++, L++) {                 // padding entry k stands on heavy row c - g + 7k
-        const int64_t t = L / ACC_TILE;
-        const int el = (int)(L % ACC_TILE);
-        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
-        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
-        if (el == 0) tile_row0[t] = c - g + ACC_MAXSTEP * k;
-    }
-    int32_t step = g - ACC_MAXSTEP * npad;                     // first entry: from the previous row (or padding) to c
-    for (int64_t k = lo; k < lo + n; k++, L++) {
-        const int64_t t = L / ACC_TILE;
-        const int el = (int)(L % ACC_TILE);
-        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
-        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? (uint32_t)step : 0u) << ACC_ROW_SHIFT));
-        if (el == 0) tile_row0[t] = c;
-        step = 0;
-    }
-}
-
-// one workgroup per block: pads the block's last tile with (0.0, column slot ACC_CB (a zero in LDS), step 0 = the
-// block's last heavy row) -- a padding entry adds 0.0 * 0.0 to an accumulator
-__global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
-                                                     const int64_t *__restrict__ blk_tile0, double *__restrict__ pvals,
-                                                     uint16_t *__restrict__ pidx, const int64_t *__restrict__ wg_t0, int32_t n_wg)
-{
-    const int32_t b = blockIdx.x;
-    if (b >= n_blocks) return;
-    const int64_t cnt = off[(int64_t)(b + 1) * n_heavy] - off[(int64_t)b * n_heavy];
-    const int64_t L0 = blk_tile0[b] * ACC_TILE + cnt, L1 = blk_tile0[b + 1] * ACC_TILE;
-    for (int64_t L = L0 + threadIdx.x; L < L1; L += blockDim.x) {      // (the tail of the block's last tile: one tile)
-        const int64_t pt = acc_phys_tile(L / ACC_TILE, wg_t0, n_wg);
-        const int el = (int)(L % ACC_TILE);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
-        pidx[pt * ACC_TILE + el] = (uint16_t)ACC_CB;
-    }
-}
-
-// (wave_exscan_i32 / wave_segscan: wave.h)
 
 template <int CB, int PT>
 __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__ pvals, const uint16_t *__restrict__ pidx,
@@ -1437,140 +692,6 @@ __global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs
 }
 
 // ---- short rows: the light stream ---------------------------------------------------------------------
-// The merge-path tile kernel spends ~600 vector instructions per wavefront-tile on index arithmetic (clamped
-// 64-bit addresses, merge coordinates, the cut table) and four dependent memory round trips per 2048-item
-// tile; with every x gather served from L1 it still took 0.25-0.28 ms on the headline matrix against
-// 0.09 ms for its 0.61 GB at streaming rate (measured: SQ counters, gather ablation).  The light stream is
-// the same idea as the accumulator form, for the rows that stay on the row-major path: at plan time their
-// entries are copied into a private stream of (float64 value, uint32 index) tiles of 512 = 64 lanes x 8
-// consecutive entries, lane-interleaved for 16-B coalesced loads, with
-//     index bit 31  hot column (low bits = slot in the packed xh), else low bits = column
-//     index bit 30  first entry of its row
-// plus rowids[k] = k-th non-empty row of the view and tile_base[t] (run numbering, below).  One wavefront
-// per tile, no LDS, no workgroup barrier:
-//   * every lane sums its 8 entries run by run in storage order; a run that starts and ends inside the lane
-//     is stored to y at once;
-//   * a segmented scan over the lanes joins runs that cross lanes (fixed tree order: deterministic);
-//   * the tile's leading run, when it continues a row of the previous tile, goes to carry[] and the
-//     existing fix-up kernel adds it to y in tile order.
-// Rows without a run (no entries, or served by the tiers) are cleared by the run that follows them.
-// Run numbering: run(e) = tile_base[t] - 1 + #{row starts in the tile up to and including e}, with
-// tile_base[t] = index of the row holding the tile's first entry among the non-empty rows, + 1 if that entry
-// is not the row's first.  Needs ncols < 2^30 (two flag bits); otherwise the tile kernel stays in charge.
-// One persistent workgroup per CU: 8 wavefronts and the 15360 most referenced packed columns in LDS (120 KiB + 8 staging
-// buffers = 152 KiB).  Measured on the headline matrix (stream kernel alone; threads / LDS slots): 1024 / 8192 -> 0.204 ms,
-// 512 / 8192 -> 0.195, 640 / 14336 -> 0.200, 512 / 15360 -> 0.190, 448 / 15872 -> 0.196, 384 / 16384 -> 0.200, 256 / 17408 ->
-// 0.230: the kernel queues on the CU's vector memory path, and eight wavefronts keep it as busy
-// as sixteen while leaving LDS for twice the columns.
-#ifndef CSRK_LS_THREADS
-#define CSRK_LS_THREADS 512
-#endif
-constexpr int LS_THREADS = CSRK_LS_THREADS;
-#ifndef CSRK_LS_HOT_LDS
-#define CSRK_LS_HOT_LDS 15360
-#endif
-constexpr int LS_HOT_LDS = CSRK_LS_HOT_LDS;
-// round-in-LDS form of the stream kernel (LS_RND): LDS = LS_RND_HOT hot slots + the LS_RND_CAP staged values of the
-// workgroup's current round + the run-sum buffers
-#ifndef CSRK_LS_RND_CAP
-#define CSRK_LS_RND_CAP 8192
-#endif
-constexpr int LS_RND_CAP = CSRK_LS_RND_CAP, LS_RND_MAXTILES = 128;
-constexpr int LS_RND_HOT = (160 * 1024 - (CSRK_LS_THREADS / 64) * (512 + 2) * 8) / 8 - LS_RND_CAP;      // 8176 with the defaults
-constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead per tile (2 / 3 / 4: 0.557 / 0.553 / 0.553 ms)
-#ifndef CSRK_LS_SEQ
-#define CSRK_LS_SEQ 3
-#endif
-constexpr int LS_SEQ = CSRK_LS_SEQ;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
-constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
-constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
-
-// smallest r in [0, nrows) with rpv[r + 1] > L (the row holding view entry L); L < rpv[nrows]
-template <class P>
-__device__ __forceinline__ int32_t ls_row_of(const P *__restrict__ rpv, int32_t nrows, int64_t L)
-{
-    int32_t lo = 0, hi = nrows - 1;
-    while (lo < hi) {
-        const int32_t mid = lo + ((hi - lo) >> 1);
-        if ((int64_t)rpv[mid + 1] > L)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    return lo;
-}
-
-template <class P>
-__global__ void ls_rowflag_kernel(const P *__restrict__ rpv, int32_t nrows, int32_t *__restrict__ flag)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= nrows) flag[r] = (r < nrows && rpv[r + 1] > rpv[r]) ? 1 : 0;
-}
-
-// dense rows: rpd[r] = rpv[r] + (empty rows before r) -- every empty row of the view gets one slot; nz = exclusive scan of
-// the non-empty flags (so r - nz[r] = empty rows before r)
-template <class P>
-__global__ void ls_dense_ptr_kernel(const P *__restrict__ rpv, const int32_t *__restrict__ nz, int32_t nrows, P *__restrict__ rpd)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= nrows) rpd[r] = (P)((int64_t)rpv[r] + (r - (int64_t)nz[r]));
-}
-
-template <class P>
-__global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx,
-                                 int32_t *__restrict__ rowids)
-{
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nrows && rpv[r + 1] > rpv[r]) rowids[ridx[r]] = (int32_t)r;
-}
-
-// One thread per slot of the stream (n_ent entries, then padding to a whole tile): view entry L of view row r is the
-// source entry src[r] + (L - rpv[r]) (a view row is a whole row of the source or empty).
-template <class P, int VT>
-__global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
-                                                     const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                                     int64_t n_ent, int64_t n_slots, const int32_t *__restrict__ slot_map, double *__restrict__ svals,
-                                                     uint32_t *__restrict__ sidx, const P *__restrict__ rp_len)
-{
-    // rp_len (dense rows): the view's own row pointers; rpv then gives every row at least one slot, and a row that is
-    // empty in rp_len becomes one padding entry that opens (and is) its run
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    const int64_t t = slot / ACC_TILE;
-    const int el = (int)(slot % ACC_TILE);
-    const int64_t L = slot;
-    double v = 0.0;
-    uint32_t ix = LS_PAD;
-    if (L < n_ent) {
-        const int32_t r = ls_row_of(rpv, nrows, L);
-        const int64_t first = (int64_t)rpv[r];
-        if (rp_len && rp_len[r + 1] == rp_len[r]) {
-            ix = LS_PAD | LS_START_BIT;
-        } else {
-            const int64_t a = (int64_t)src[r] + (L - first);
-            v = ValLoad<VT>::at(vs, a);
-            const int32_t c = ci[a];
-            const int32_t sl = slot_map ? slot_map[c] : -1;         // slot of a packed column
-            ix = sl >= 0 ? (LS_HOT_BIT | (uint32_t)sl) : (uint32_t)c;
-            if (L == first) ix |= LS_START_BIT;
-        }
-    }
-    svals[t * ACC_TILE + acc_val_slot(el)] = v;
-    sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
-}
-
-// per tile: run numbering base
-template <class P>
-__global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx, int64_t n_tiles,
-                                   int32_t *__restrict__ tile_base)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int64_t e0 = t * ACC_TILE;      // (< the entry count: the stream has no empty tile)
-    const int32_t r = ls_row_of(rpv, nrows, e0);
-    tile_base[t] = ridx[r] + ((int64_t)rpv[r] == e0 ? 0 : 1);
-}
-
 // LDS: [0, LS_HOT_LDS) the x values of the most popular packed columns (slots below n_lds are read from
 // here instead of gathered), then one staging buffer of ACC_TILE + 2 run sums per wavefront.
 // MODE: LS_PLAIN = the unpacked columns' x values are gathered from x (nothing was staged);
@@ -1904,24 +1025,6 @@ __global__ __launch_bounds__(256) void spmv_merge_fixup_short_kernel(const int32
 }
 
 // ---- vector: one wavefront per row segment ------------------------------------------------
-constexpr int VEC_SEG = 4096;
-
-template <class P>
-__global__ void vec_count_kernel(const P *__restrict__ rp, int32_t nrows, int64_t *__restrict__ cnt)
-{
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    int64_t len = (int64_t)rp[r + 1] - (int64_t)rp[r];
-    cnt[r] = len <= VEC_SEG ? 1 : (len + VEC_SEG - 1) / VEC_SEG;
-}
-
-__global__ void vec_fill_kernel(const int64_t *__restrict__ seg_off, int32_t nrows, int32_t *__restrict__ seg_row)
-{
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    for (int64_t q = seg_off[r]; q < seg_off[r + 1]; q++) seg_row[q] = (int32_t)r;
-}
-
 template <class P, int VT>
 __global__ __launch_bounds__(256) void spmv_vector_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                                          const void *__restrict__ vs, const double *__restrict__ x,
@@ -1974,655 +1077,6 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
     y[r] = acc;
 }
 
-// ---- host side ----------------------------------------------------------------------------------
-constexpr int HEAVY_STREAMS = 8;   // XCDs: blockIdx % 8 labels the XCD group (speed assumption only)
-
-// Build one panel tier: M' (column-block-major copy of the listed rows, float64 values), its tiles and
-// the workgroup list.  `xcd_streams`: order the groups so that column block b is served by workgroups
-// with blockIdx % 8 == b % 8.
-template <class P, int VT>
-static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
-                       int tpw, bool xcd_streams, hipStream_t s)
-{
-    const P *rp = (const P *)m->d_rowptrs;
-    const int32_t n = (int32_t)rows.size();
-    const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, cb);
-    const int64_t pairs = (int64_t)n * nb;
-    CSRK_TRY(pn->row_list.alloc((size_t)n * 4));
-    CSRK_HIP(hipMemcpyAsync(pn->row_list.p, rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    DevBuf off, bends;
-    CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
-    const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
-    panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
-    pn->p64 = nnz_rows > INT32_MAX;
-    CSRK_TRY(pn->rp.alloc((size_t)(pairs + 1) * (pn->p64 ? 8 : 4)));
-    CSRK_TRY(pn->ci.alloc((size_t)nnz_rows * 4));
-    CSRK_TRY(pn->vs.alloc((size_t)nnz_rows * 8));
-    if (pn->p64)
-        panel_fill_kernel<P, VT, int64_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
-                                                          cb, off.as<int64_t>(), pn->rp.as<int64_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
-    else
-        panel_fill_kernel<P, VT, int32_t><<<g, 256, 0, s>>>(rp, m->d_colinds, m->d_values, pn->row_list.as<int32_t>(), n, nb,
-                                                          cb, off.as<int64_t>(), pn->rp.as<int32_t>(),
-                                                          pn->ci.as<int32_t>(), pn->vs.as<double>());
-    CSRK_LAUNCH_CHECK();
-    // tiles per block (host: nb is at most a few thousand)
-    CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
-    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
-    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    t0[0] = 0;
-    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n + be[b + 1] - be[b], MERGE_ITEMS);
-    const int64_t n_tiles = t0[nb];
-    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
-    CSRK_TRY(pn->tile.alloc((size_t)n_tiles * sizeof(PanelTile)));
-    if (pn->p64)
-        panel_plan_kernel<int64_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-            pn->rp.as<int64_t>(), n, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, pn->tile.as<PanelTile>());
-    else
-        panel_plan_kernel<int32_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-            pn->rp.as<int32_t>(), n, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, pn->tile.as<PanelTile>());
-    CSRK_LAUNCH_CHECK();
-
-    // workgroup list: `tpw` consecutive tiles of one block per workgroup
-    std::vector<PanelGroup> groups;
-    auto block_groups = [&](int32_t b, std::vector<PanelGroup> &out) {
-        for (int64_t t = t0[b]; t < t0[b + 1]; t += tpw) {
-            PanelGroup gq;
-            gq.t0 = t;
-            gq.nt = (int32_t)(t0[b + 1] - t < tpw ? t0[b + 1] - t : tpw);
-            gq.blk = b;
-            out.push_back(gq);
-        }
-    };
-    if (!xcd_streams || nb < 2 * HEAVY_STREAMS) {      // too few blocks to keep all 8 XCDs busy per stream
-        for (int32_t b = 0; b < nb; b++) block_groups(b, groups);
-    } else {
-        std::vector<PanelGroup> st[HEAVY_STREAMS];
-        size_t longest = 0;
-        for (int32_t b = 0; b < nb; b++) block_groups(b, st[b % HEAVY_STREAMS]);
-        for (int q = 0; q < HEAVY_STREAMS; q++) longest = st[q].size() > longest ? st[q].size() : longest;
-        PanelGroup pad;
-        pad.t0 = 0;
-        pad.nt = 0;
-        pad.blk = 0;
-        groups.reserve(longest * HEAVY_STREAMS);
-        for (size_t i = 0; i < longest; i++)
-            for (int q = 0; q < HEAVY_STREAMS; q++) groups.push_back(i < st[q].size() ? st[q][i] : pad);
-    }
-    // the tiles' carries per long row (a tile's carry belongs to the pair holding its last, unfinished row end: static)
-    {
-        std::vector<PanelTile> ht((size_t)n_tiles);
-        CSRK_HIP(hipMemcpy(ht.data(), pn->tile.p, (size_t)n_tiles * sizeof(PanelTile), hipMemcpyDeviceToHost));
-        std::vector<int32_t> crp((size_t)n + 1, 0), cidx;
-        for (int64_t t = 0; t < n_tiles; t++)
-            if ((int64_t)ht[(size_t)t].i1 < pairs) crp[(size_t)(ht[(size_t)t].i1 % n) + 1]++;
-        for (int32_t h = 0; h < n; h++) crp[(size_t)h + 1] += crp[(size_t)h];
-        cidx.resize((size_t)crp[(size_t)n] + 1);
-        std::vector<int32_t> cur(crp.begin(), crp.end() - 1);
-        for (int64_t t = 0; t < n_tiles; t++)      // ascending tiles: each row's list comes out in tile order
-            if ((int64_t)ht[(size_t)t].i1 < pairs) cidx[(size_t)cur[(size_t)(ht[(size_t)t].i1 % n)]++] = (int32_t)t;
-        CSRK_TRY(pn->crp.alloc(crp.size() * 4));
-        CSRK_TRY(pn->cidx.alloc(cidx.size() * 4));
-        CSRK_HIP(hipMemcpy(pn->crp.p, crp.data(), crp.size() * 4, hipMemcpyHostToDevice));
-        CSRK_HIP(hipMemcpy(pn->cidx.p, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice));
-    }
-    pn->groups = (int64_t)groups.size();
-    CSRK_TRY(pn->group.alloc(groups.size() * sizeof(PanelGroup)));
-    CSRK_HIP(hipMemcpyAsync(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
-    CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
-    CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
-    CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
-    CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
-    pn->on = true;
-    pn->cb = cb;
-    pn->nb = nb;
-    pn->nrow = n;
-    pn->rows = pairs;
-    pn->tiles = n_tiles;
-    pn->nnz = nnz_rows;
-    return CSRK_OK;
-}
-
-// Build one accumulator-form group: the listed heavy rows (<= ACC_MAXROWS, ascending) as a tiled,
-// column-block-major (value, packed index) stream plus the persistent workgroups' segment lists.
-template <class P, int VT>
-static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const int64_t *lens, int32_t n, int64_t nnz_rows,
-                           hipStream_t s)
-{
-    const P *rp = (const P *)m->d_rowptrs;
-    const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
-    const int64_t pairs = (int64_t)n * nb;
-    CSRK_TRY(ap->row_list.alloc((size_t)n * 4));
-    CSRK_HIP(hipMemcpyAsync(ap->row_list.p, rows, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    DevBuf off, bends, pstart, d_trow, d_tpiece;
-    CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
-    // block starts inside every row (one pass over the rows' entries), then the pair counts
-    std::vector<int32_t> trow, tpiece;
-    for (int32_t c = 0; c < n; c++)
-        for (int64_t pc = 0; pc * ACC_PIECE < lens[c]; pc++) {
-            trow.push_back(c);
-            tpiece.push_back((int32_t)pc);
-        }
-    const int64_t n_tasks = (int64_t)trow.size();
-    CSRK_TRY(pstart.alloc((size_t)(pairs + n) * 4));
-    CSRK_TRY(d_trow.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
-    CSRK_TRY(d_tpiece.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
-    CSRK_HIP(hipMemcpyAsync(d_trow.p, trow.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(d_tpiece.p, tpiece.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
-    acc_pairstart_kernel<P><<<(unsigned)ceil_div(n_tasks * WAVE, 256), 256, 0, s>>>(
-        rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, d_trow.as<int32_t>(), d_tpiece.as<int32_t>(), n_tasks,
-        pstart.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    acc_paircount_kernel<<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(pstart.as<int32_t>(), pairs, n, off.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    DevBuf gap;
-    CSRK_TRY(gap.alloc((size_t)pairs * 4));
-    acc_gap_kernel<<<(unsigned)ceil_div((int64_t)nb * WAVE, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, gap.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
-    CSRK_TRY(bends.alloc((size_t)(nb + 1) * 8));
-    panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
-    CSRK_LAUNCH_CHECK();
-    std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
-    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    t0[0] = 0;
-    for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div(be[b + 1] - be[b], ACC_TILE);
-    const int64_t n_tiles = t0[nb];
-    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
-    // persistent workgroups: one per CU, equal shares of the tiles (stored interleaved: acc_phys_tile), cut into one-block
-    // segments
-    int cus = 0;
-    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    int64_t n_wg = cus > 0 ? cus : 256;
-    if (n_wg > n_tiles) n_wg = n_tiles;
-    if (n_wg < 1) n_wg = 1;
-    std::vector<int64_t> wg_t0((size_t)n_wg + 1);
-    int64_t share_max = 0;
-    for (int64_t w = 0; w <= n_wg; w++) wg_t0[(size_t)w] = n_tiles * w / n_wg;
-    for (int64_t w = 0; w < n_wg; w++) share_max = std::max(share_max, wg_t0[(size_t)w + 1] - wg_t0[(size_t)w]);
-    const int64_t n_phys = share_max * n_wg;      // stored tiles (the last sweep has holes where a share is one tile shorter)
-    DevBuf d_wg_t0;
-    CSRK_TRY(d_wg_t0.alloc((size_t)(n_wg + 1) * 8));
-    CSRK_HIP(hipMemcpyAsync(d_wg_t0.p, wg_t0.data(), (size_t)(n_wg + 1) * 8, hipMemcpyHostToDevice, s));
-    CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * 8));
-    CSRK_TRY(ap->idx.alloc((size_t)n_phys * ACC_TILE * 2));
-    CSRK_TRY(ap->tile_row0.alloc((size_t)(n_tiles ? n_tiles : 1) * 4));
-    acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
-        rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
-        pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(),
-        d_wg_t0.as<int64_t>(), (int32_t)n_wg);
-    CSRK_LAUNCH_CHECK();
-    acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
-                                               ap->idx.as<uint16_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg);
-    CSRK_LAUNCH_CHECK();
-    std::vector<AccSeg> segs;
-    std::vector<int32_t> wg_seg((size_t)n_wg + 1);
-    int32_t b = 0;
-    for (int64_t w = 0; w < n_wg; w++) {
-        wg_seg[(size_t)w] = (int32_t)segs.size();
-        int64_t t = wg_t0[(size_t)w];
-        const int64_t t_end = wg_t0[(size_t)w + 1];
-        while (t < t_end) {
-            while (t0[b + 1] <= t) b++;
-            int64_t e = t_end < t0[b + 1] ? t_end : t0[b + 1];
-            if (e - t > ACC_SEG_TILES) e = t + ACC_SEG_TILES;
-            AccSeg sg;
-            sg.tile0 = t;
-            sg.ptile0 = (t - wg_t0[(size_t)w]) * n_wg + w;
-            sg.ntiles = (int32_t)(e - t);
-            sg.blk = b;
-            segs.push_back(sg);
-            t = e;
-        }
-    }
-    wg_seg[(size_t)n_wg] = (int32_t)segs.size();
-    CSRK_TRY(ap->segs.alloc(segs.size() * sizeof(AccSeg)));
-    CSRK_TRY(ap->wg_seg.alloc(wg_seg.size() * 4));
-    CSRK_HIP(hipMemcpyAsync(ap->segs.p, segs.data(), segs.size() * sizeof(AccSeg), hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(ap->wg_seg.p, wg_seg.data(), wg_seg.size() * 4, hipMemcpyHostToDevice, s));
-    CSRK_TRY(ap->partial.alloc((size_t)n_wg * n * 8));
-    ap->lds = (size_t)(ACC_CB + 2) * 8 + (size_t)((n + 1) & ~1) * 8 + (size_t)ACC_SEG_TILES * 12;
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-    CSRK_HIP(hipStreamSynchronize(s));     // `segs`, `wg_seg`, `t0` are host temporaries of async copies
-    ap->nrow = n;
-    ap->nb = nb;
-    ap->n_wg = (int32_t)n_wg;
-    ap->tiles = n_tiles;
-    ap->nnz = nnz_rows;
-    ap->n_segs = (int64_t)segs.size();
-    return CSRK_OK;
-}
-
-// Cut the long rows out of the merge path and build their panel tiers.
-template <class P>
-static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_tier1 = true)
-{
-    p->n_heavy = 0;
-    const char *env = getenv("CSRK_SPMV_HEAVY_SPLIT");
-    if (env && env[0] == '0') return CSRK_OK;
-    HEAVY_MIN = 2048;
-    TIERB_MIN = 128;
-    // (test hooks, not tuning switches: a small matrix gets more "heavy" rows than one accumulator group holds, or no tier 1)
-    if (const char *e = getenv("CSRK_HEAVY_MIN")) HEAVY_MIN = atoi(e) > 64 ? atoi(e) : 64;
-    if (const char *e = getenv("CSRK_TIERB_MIN")) TIERB_MIN = atoi(e) >= 0 ? atoi(e) : 0;
-    const bool tier1 = allow_tier1 && TIERB_MIN > 0 && TIERB_MIN < HEAVY_MIN;
-    const int cut_min = tier1 ? TIERB_MIN : HEAVY_MIN;
-    if (m->nrows == 0 || m->nnz < cut_min) return CSRK_OK;
-    // The split pays for itself only when x does not fit in an XCD's 4 MiB L2: otherwise every gather
-    // is an L2 hit already and the panels only add (block, row) overhead (MovieLens-25M shape, x = 472 KB:
-    // 0.146 ms on the single merge path against 0.176-0.53 ms split; measured).  CSRK_SPMV_HEAVY_SPLIT=1 forces it.
-    if ((int64_t)m->ncols * 8 <= (4ll << 20) && !(env && env[0] == '1')) return CSRK_OK;
-    const P *rp = (const P *)m->d_rowptrs;
-    const int32_t nr = m->nrows;
-    const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);
-    DevBuf flag, hlen, bad, clen;
-    CSRK_TRY(flag.alloc((size_t)(nr + 2) * 4));
-    CSRK_TRY(hlen.alloc((size_t)(nr + 2) * 8));
-    heavy_flag_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), cut_min);
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(flag.as<int32_t>(), flag.as<int32_t>(), nr, s));      // -> cut-row index
-    CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> cut entries before
-    int32_t n_cut = 0;
-    int64_t nnz_cut = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_cut, flag.as<int32_t>() + nr, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(&nnz_cut, hlen.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    if (n_cut == 0) return CSRK_OK;
-
-    CSRK_TRY(p->rp_light.alloc((size_t)(nr + 1) * sizeof(P)));
-    CSRK_TRY(p->heavy_row.alloc((size_t)n_cut * 4));
-    CSRK_TRY(p->cut_pos.alloc((size_t)n_cut * 8));
-    CSRK_TRY(p->cut_cum.alloc((size_t)(n_cut + 1) * 8));
-    CSRK_TRY(clen.alloc((size_t)n_cut * 8));
-    heavy_view_kernel<P><<<g1, 256, 0, s>>>(rp, nr, flag.as<int32_t>(), hlen.as<int64_t>(), p->rp_light.as<P>(),
-                                          p->heavy_row.as<int32_t>(), p->cut_pos.as<int64_t>(),
-                                          p->cut_cum.as<int64_t>(), clen.as<int64_t>(), n_cut);
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(bad.alloc(4));
-    CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, s));
-    heavy_sorted_kernel<P><<<(unsigned)n_cut, 1024, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_cut,
-                                                         bad.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    int32_t is_bad = 0;
-    std::vector<int32_t> rows((size_t)n_cut);
-    std::vector<int64_t> lens((size_t)n_cut);
-    CSRK_HIP(hipMemcpyAsync(&is_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(rows.data(), p->heavy_row.p, (size_t)n_cut * 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(lens.data(), clen.p, (size_t)n_cut * 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
-
-    // tier 0: accumulator form (groups of <= ACC_MAXROWS rows).  The accumulator form costs 1.8 ps per entry against 4.8 for tier 1 (measured, headline matrix), and
-    // one group holds up to ACC_MAXROWS rows at no extra window traffic: when fewer rows than that reach
-    // HEAVY_MIN, tier 0 is extended downwards to the ACC_MAXROWS longest rows (not below ACC_FLOOR).
-    if (tier1 && !getenv("CSRK_HEAVY_MIN")) {
-        int64_t n_min = 0;
-        for (int32_t c = 0; c < n_cut; c++) n_min += lens[c] >= HEAVY_MIN;
-        if (n_min < ACC_MAXROWS && n_cut > n_min) {
-            std::vector<int64_t> sl(lens);
-            const size_t kth = (size_t)(n_cut < ACC_MAXROWS ? n_cut : ACC_MAXROWS) - 1;
-            std::nth_element(sl.begin(), sl.begin() + kth, sl.end(), [](int64_t a, int64_t b) { return a > b; });
-            int64_t thr = sl[kth];
-            // rows tied with the kth must not push the group over its capacity
-            int64_t n_ge = 0;
-            for (int32_t c = 0; c < n_cut; c++) n_ge += lens[c] >= thr;
-            if (n_ge > ACC_MAXROWS) thr++;
-            thr = thr < ACC_FLOOR ? ACC_FLOOR : thr;
-            if (thr < HEAVY_MIN) HEAVY_MIN = (int)thr;
-        }
-    }
-    p->heavy_min = HEAVY_MIN;
-    std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
-    std::vector<int64_t> len0;
-    int64_t nnz1 = 0;
-    for (int32_t c = 0; c < n_cut; c++) {
-        if (lens[c] >= HEAVY_MIN) {
-            r0.push_back(rows[c]);
-            len0.push_back(lens[c]);
-        } else {
-            r1.push_back(rows[c]);
-            nnz1 += lens[c];
-        }
-    }
-    const int64_t pair_cap = 256ll << 20;
-    const int64_t pairs1 = (int64_t)r1.size() * ceil_div(m->ncols > 0 ? m->ncols : 1, PANEL_CB1);
-    if (pairs1 > pair_cap && tier1) return build_heavy_split<P>(m, p, s, false);
-
-    p->n_heavy = n_cut;
-    p->nnz_light = m->nnz - nnz_cut;
-    p->t0_rows = r0;
-    p->t0_lens = len0;
-    p->t1_rows = r1;
-    p->t1_nnz = nnz1;
-    return CSRK_OK;
-}
-
-// Build the tiers of the rows build_heavy_split cut out.
-template <class P>
-static int build_tiers(Matrix *m, SpmvPlan *p, hipStream_t s)
-{
-    if (!p->n_heavy) return CSRK_OK;
-    const std::vector<int32_t> &r0 = p->t0_rows, &r1 = p->t1_rows;
-    const std::vector<int64_t> &len0 = p->t0_lens;
-    const int64_t nnz1 = p->t1_nnz;
-#define BUILD(VT)                                                                                                  \
-    do {                                                                                                           \
-        for (size_t g0 = 0; g0 < r0.size(); g0 += ACC_MAXROWS) {                                                   \
-            const size_t g1 = g0 + ACC_MAXROWS < r0.size() ? g0 + ACC_MAXROWS : r0.size();                         \
-            int64_t gn = 0;                                                                                        \
-            for (size_t c = g0; c < g1; c++) gn += len0[c];                                                        \
-            AccPanel *ap = new (std::nothrow) AccPanel();                                                          \
-            CSRK_REQUIRE(ap, "out of host memory");                                                                \
-            p->acc.push_back(ap);                                                                                  \
-            CSRK_TRY((build_acc_panel<P, VT>(m, ap, r0.data() + g0, len0.data() + g0, (int32_t)(g1 - g0), gn, s)));  \
-        }                                                                                                          \
-        if (!r1.empty()) CSRK_TRY((build_panel<P, VT>(m, &p->tier1, r1, nnz1, PANEL_CB1, 1, true, s)));            \
-    } while (0)
-    if (m->val_type == CSRK_VAL_F64) BUILD(CSRK_VAL_F64);
-    else if (m->val_type == CSRK_VAL_F32) BUILD(CSRK_VAL_F32);
-    else BUILD(CSRK_VAL_NONE);
-#undef BUILD
-    return CSRK_OK;
-}
-
-// Pick the (at most HOT_SLOTS) most referenced columns and renumber them in a copy of colinds.  Built
-// with the lazy plan (second launch on a handle).  Skipped when x is small enough to live in L1/L2
-// next to the streams anyway, when the matrix is small, or when the cached columns would carry less
-// than a fifth of the entries (no popularity skew: nothing to gain, and the persistent grid has fewer
-// wavefronts in flight than the plain one).  CSRK_SPMV_HOT=0 disables, =1 forces.
-template <class P>
-static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
-{
-    p->n_hot = 0;
-    const char *env = getenv("CSRK_SPMV_HOT");
-    if (env && env[0] == '0') return CSRK_OK;
-    const bool force = env && env[0] == '1';
-    if (m->nnz < 2 || m->ncols < 1) return CSRK_OK;
-    int64_t HOT_SLOTS = 524288;   // 4 MiB of packed x, most popular first (light stream, LDS for the first 8192: 64k 0.340,
-                                  // 256k 0.308, 512k 0.302, 1M 0.297, 2M 0.297 ms, but the per-call pack costs more than that gains past 512k)
-                                  // earlier sweep, tile kernel, 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
-                                  // 256k 0.430, 1M 0.439, 4M 0.460 ms for the tile kernel; none 0.481)
-    p->hot_slots = (int32_t)HOT_SLOTS;
-    // x that fits in L2 whole needs no packing
-    if (!force && (m->nnz < (1 << 20) || (int64_t)m->ncols * 8 <= (4ll << 20))) return CSRK_OK;
-    const int32_t nc = m->ncols;
-    DevBuf cnt, slot, census;
-    CSRK_TRY(cnt.alloc((size_t)(nc + 1) * 4));
-    CSRK_TRY(slot.alloc((size_t)(nc + 2) * 4));
-    CSRK_TRY(census.alloc(16));
-    CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * 4, s));
-    CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
-    const int64_t row_stride = p->nnz_light > (1ll << 25) ? p->nnz_light >> 25 : 1;
-    const int64_t hc_need = ceil_div(ceil_div(m->nrows, row_stride), 256);
-    hot_count_kernel<P><<<(unsigned)(hc_need < 2048 ? hc_need : 2048), 256, 0, s>>>(
-        (const P *)m->d_rowptrs, p->n_heavy ? p->rp_light.as<P>() : (const P *)nullptr, m->d_colinds, m->nrows,
-        row_stride, cnt.as<int32_t>(), census.as<unsigned long long>());
-    CSRK_LAUNCH_CHECK();
-    unsigned long long n_samples_u = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_samples_u, census.p, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    const int64_t n_samples = (int64_t)n_samples_u;
-    if (n_samples == 0) return CSRK_OK;
-    // smallest threshold (>= 2 references in the sample) that leaves at most HOT_SLOTS columns
-    auto census_at = [&](int32_t thr, unsigned long long out[2]) -> int {
-        CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
-        hot_census_kernel<<<1024, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, census.as<unsigned long long>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(out, census.p, 16, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        return CSRK_OK;
-    };
-    unsigned long long c[2];
-    int64_t lo = 2, hi = n_samples + 1;     // invariant: census(hi).n <= HOT_SLOTS
-    // one histogram pass decides it unless more than HOT_SLOTS columns sit in the shared top bin (then: the search below)
-    bool decided = false;
-    {
-        DevBuf hist;
-        CSRK_TRY(hist.alloc((size_t)2 * (HOT_HIST + 1) * 8));
-        CSRK_HIP(hipMemsetAsync(hist.p, 0, (size_t)2 * (HOT_HIST + 1) * 8, s));
-        hot_hist_kernel<<<1024, 256, 0, s>>>(cnt.as<int32_t>(), nc, hist.as<unsigned long long>(),
-                                             hist.as<unsigned long long>() + (HOT_HIST + 1));
-        CSRK_LAUNCH_CHECK();
-        std::vector<unsigned long long> hh((size_t)2 * (HOT_HIST + 1));
-        CSRK_HIP(hipMemcpyAsync(hh.data(), hist.p, hh.size() * 8, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        const unsigned long long *hn = hh.data(), *hs = hh.data() + (HOT_HIST + 1);
-        if (hn[HOT_HIST] <= (unsigned long long)HOT_SLOTS) {
-            unsigned long long n_ge = 0, s_ge = 0;      // columns / references with count >= v
-            int64_t thr0 = HOT_HIST;                     // smallest threshold >= 2 that leaves at most HOT_SLOTS columns
-            n_ge = hn[HOT_HIST];
-            s_ge = hs[HOT_HIST];
-            for (int64_t v = HOT_HIST - 1; v >= 2; v--) {
-                if (n_ge + hn[v] > (unsigned long long)HOT_SLOTS) break;
-                n_ge += hn[v];
-                s_ge += hs[v];
-                thr0 = v;
-            }
-            lo = thr0;
-            c[0] = n_ge;
-            c[1] = s_ge;
-            decided = true;
-        }
-    }
-    if (!decided) CSRK_TRY(census_at((int32_t)lo, c));
-    if (!decided && c[0] > (unsigned long long)HOT_SLOTS) {
-        while (lo + 1 < hi) {
-            const int64_t mid = lo + (hi - lo) / 2;
-            CSRK_TRY(census_at((int32_t)(mid > INT32_MAX ? INT32_MAX : mid), c));
-            if (c[0] <= (unsigned long long)HOT_SLOTS)
-                hi = mid;
-            else
-                lo = mid;
-        }
-        CSRK_TRY(census_at((int32_t)(hi > INT32_MAX ? INT32_MAX : hi), c));
-        lo = hi;
-    }
-    const int32_t thr = (int32_t)(lo > INT32_MAX ? INT32_MAX : lo);
-    const int32_t n_hot = (int32_t)c[0];
-    p->hot_cover = n_samples ? (double)c[1] / (double)n_samples : 0.0;
-    if (n_hot == 0 || (!force && p->hot_cover < 0.2)) return CSRK_OK;
-
-    // Slots in order of popularity (count descending, column ascending among equals): the first
-    // LS_HOT_LDS slots are the ones the light stream keeps in LDS, and the packed lines that follow
-    // are referenced less and less often, so what L2 fails to retain is the pack's tail.
-    const unsigned gc = (unsigned)ceil_div((int64_t)nc + 1, 256);
-    hot_flag_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, slot.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(slot.as<int32_t>(), slot.as<int32_t>(), nc, s));
-    CSRK_TRY(p->hot_cols.alloc((size_t)n_hot * 4));
-    DevBuf hcnt;
-    CSRK_TRY(hcnt.alloc((size_t)n_hot * 4));
-    hot_list_kernel<<<gc, 256, 0, s>>>(cnt.as<int32_t>(), slot.as<int32_t>(), nc, thr, p->hot_cols.as<int32_t>(),
-                                      hcnt.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    {
-        std::vector<int32_t> hc((size_t)n_hot), hn((size_t)n_hot), ord((size_t)n_hot), sorted((size_t)n_hot);
-        CSRK_HIP(hipMemcpyAsync(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipMemcpyAsync(hn.data(), hcnt.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        // stable, count descending: two 16-bit LSD radix passes over the complemented count (a comparison sort of
-        // 4 * 10^5 indices through a lambda took tens of ms of the plan)
-        {
-            std::vector<int32_t> tmp((size_t)n_hot);
-            std::vector<uint32_t> bucket(65537);
-            for (int32_t i = 0; i < n_hot; i++) ord[(size_t)i] = i;
-            for (int pass = 0; pass < 2; pass++) {
-                const int sh = 16 * pass;
-                std::fill(bucket.begin(), bucket.end(), 0u);
-                for (int32_t i = 0; i < n_hot; i++) bucket[((~(uint32_t)hn[(size_t)i] >> sh) & 0xffffu) + 1]++;
-                for (size_t b = 0; b < 65536; b++) bucket[b + 1] += bucket[b];
-                for (int32_t i = 0; i < n_hot; i++) {
-                    const int32_t o = ord[(size_t)i];
-                    tmp[bucket[(~(uint32_t)hn[(size_t)o] >> sh) & 0xffffu]++] = o;
-                }
-                ord.swap(tmp);
-            }
-        }
-        for (int32_t i = 0; i < n_hot; i++) sorted[(size_t)i] = hc[(size_t)ord[(size_t)i]];
-        CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, s));
-        CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
-    }
-    // column -> slot map (-1: not packed); the light stream's fill reads it, as does the renumbered colinds copy
-    // the tile kernel needs when no stream is built
-    CSRK_TRY(p->hot_slot.alloc((size_t)nc * 4));
-    CSRK_HIP(hipMemsetAsync(p->hot_slot.p, 0xff, (size_t)nc * 4, s));
-    hot_slot_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(p->hot_cols.as<int32_t>(), n_hot, p->hot_slot.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(p->xh.alloc((size_t)n_hot * 8));
-    const int32_t n_top = n_hot < LS_HOT_LDS ? n_hot : LS_HOT_LDS;
-    p->n_hot = n_hot;
-    p->n_hot_lds = n_top;
-    CSRK_HIP(hipStreamSynchronize(s));     // hcnt is freed on return
-    return CSRK_OK;
-}
-
-// Build the arrays of the light stream from a view: view row r (r < nrows_view) is the source entries
-// src[r] .. src[r] + (rpv[r+1] - rpv[r]) of (ci, vs); n_ent entries in n_tiles tiles.
-template <class P, int VT>
-static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, int32_t nrows_view, const int32_t *ci,
-                        const void *vs, int64_t n_ent, int64_t n_tiles, int32_t n_out, const int32_t *slot_map, hipStream_t s,
-                        const P *rp_len = nullptr)
-{
-    // rp_len (dense rows): rpv gives every row of the view at least one slot; a row that is empty in rp_len is one padding
-    // entry.  Run k is then row k, and no row-id table is built.
-    ls->on = false;
-    ls->dense = rp_len != nullptr;
-    DevBuf ridx;
-    CSRK_TRY(ridx.alloc((size_t)(nrows_view + 2) * 4));
-    const unsigned gr = (unsigned)ceil_div((int64_t)nrows_view + 1, 256);
-    ls_rowflag_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(exclusive_scan_i32(ridx.as<int32_t>(), ridx.as<int32_t>(), nrows_view, s));
-    int32_t n_runs = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + nrows_view, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipStreamSynchronize(s));
-    if (n_runs < 1) return CSRK_OK;
-    if (!ls->dense) {
-        CSRK_TRY(ls->rowids.alloc((size_t)n_runs * 4));
-        ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-    }
-    CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
-    CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
-    ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len);
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
-    ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-        rpv, nrows_view, ridx.as<int32_t>(), n_tiles, ls->tile_base.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(ls->carry_row.alloc((size_t)n_tiles * 4));
-    CSRK_TRY(ls->carry_val.alloc((size_t)n_tiles * 8));
-    int cus = 0;
-    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    int64_t wgs = (int64_t)(cus > 0 ? cus : 256);
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)spmv_lstream_kernel<LS_RND, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(160 * 1024)));
-    const int64_t need = ceil_div(n_tiles, LS_THREADS / WAVE);
-    ls->grid = (unsigned)(wgs < need ? wgs : need);
-    ls->n_tiles = n_tiles;
-    ls->n_runs = n_runs;
-    ls->n_out = n_out;
-    CSRK_HIP(hipStreamSynchronize(s));      // ridx, dphys are freed on return; *phys is a host temporary
-    ls->on = true;
-    return CSRK_OK;
-}
-
-// ---- cold staging ----------------------------------------------------------------------------------------------
-// A gather of x[col] that misses L2 moves a 128-B line over the fabric for 8 useful bytes, and on a power-law
-// matrix the light stream's unpacked ("cold") columns nearly all miss: 1.4 of the 2.2 GB the kernel moved.  The
-// whole SpMV runs at the fabric's rate, so those bytes are its time.  Instead, before each light-stream launch one
-// pass copies the cold entries' x values into `xg`, in an order that is cheap on BOTH sides:
-//   * the stream side reads xg[pos]; the positions of the cold entries of one workgroup round (LS_STAGE_TILES
-//     consecutive tiles = the 16 wavefronts of a workgroup, one tile each) form one contiguous range of xg, so
-//     every line of xg is fetched by one workgroup within one round and used completely;
-//   * the copy side (ls_stage_kernel) walks the cold entries sorted by (column block, position): one workgroup per
-//     block of columns, whose x window it holds in LDS (x crosses the fabric once, coalesced), and its
-//     writes land in runs: inside a round the positions are ordered by column block, so the entries of one
-//     (round, block) bucket are neighbours on both sides and neighbouring blocks fill neighbouring pieces of a line.
-// A cold entry's index word then holds its position in xg instead of its column (flags unchanged) and the stream
-// kernel is given xg as the base of its cold gathers: the kernel itself does not change, nor does any result bit.
-// Tiles whose staged values share one contiguous range of xg ("round").  The copy pass pays per store transaction (~13 ps
-// chip-wide; a (round, column block) bucket of several values is one transaction), the stream kernel per line its
-// gathers pull into L1 (the round's range is shared by the wavefronts that process it together): measured on the
-// headline matrix, copy + stream = 0.125 + 0.178 ms at 1 tile (tile-major), 0.071 + 0.203 at 8, 0.064 + 0.215 at 16,
-// 0.055 + 0.229 at 32, 0.049 + 0.257 at 64.
-#ifndef CSRK_STAGE_TILES
-#define CSRK_STAGE_TILES 8
-#endif
-constexpr int LS_STAGE_TILES = CSRK_STAGE_TILES;     // tiles per staging round
-constexpr int LS_STAGE_WMAX = 9984;                   // columns per block at most: a 78-KiB window of x in LDS, two per CU (one per CU with 156 KiB: 58 vs 46 us; three: 49)
-constexpr int LS_STAGE_THREADS = 1024, LS_STAGE_IPT = 8;
-
-__device__ __forceinline__ bool ls_is_cold(uint32_t ix) { return !(ix & LS_HOT_BIT) && (ix & LS_COL_MASK) != LS_PAD; }
-
-// per index word: count into the (round, block) bucket; the old count is the entry's place inside the bucket
-__global__ __launch_bounds__(256) void ls_cold_count_kernel(const uint32_t *__restrict__ sidx, int64_t n_words, int32_t nblk, int32_t W,
-                                                           const int32_t *__restrict__ tile_round, int32_t *__restrict__ cnt,
-                                                           int32_t *__restrict__ off)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint32_t ix = sidx[w];
-    if (!ls_is_cold(ix)) return;
-    const int64_t r = tile_round[w / ACC_TILE];
-    const int32_t b = (int32_t)((ix & LS_COL_MASK) / (uint32_t)W);
-    off[w] = atomicAdd(&cnt[r * nblk + b], 1);
-}
-
-__global__ void ls_cold_transpose_kernel(const int32_t *__restrict__ cnt, int32_t nround, int32_t nblk, int32_t *__restrict__ cntT)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)nround * nblk) return;
-    const int64_t r = i / nblk, b = i % nblk;
-    cntT[b * nround + r] = cnt[i];
-}
-
-// position in xg = bucket base in (round, block) order + place; position in the copy list = bucket base in
-// (block, round) order + place
-// (rel: the index word keeps the position relative to the round's start -- the round-in-LDS form)
-__global__ __launch_bounds__(256) void ls_cold_place_kernel(uint32_t *__restrict__ sidx, int64_t n_words, int32_t nround,
-                                                           int32_t nblk, int32_t W, const int32_t *__restrict__ tile_round, int rel,
-                                                           const int32_t *__restrict__ base_rb,
-                                                           const int32_t *__restrict__ base_br, const int32_t *__restrict__ off,
-                                                           uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint32_t ix = sidx[w];
-    if (!ls_is_cold(ix)) return;
-    const int64_t r = tile_round[w / ACC_TILE];
-    const uint32_t c = ix & LS_COL_MASK;
-    const int32_t b = (int32_t)(c / (uint32_t)W);
-    const int32_t pos = base_rb[r * nblk + b] + off[w];
-    const int32_t pa = base_br[(int64_t)b * nround + r] + off[w];
-    a_col[pa] = (uint16_t)(c - (uint32_t)b * (uint32_t)W);      // offset inside the block's window
-    a_dst[pa] = pos;
-    sidx[w] = (ix & LS_START_BIT) | (uint32_t)(rel ? pos - base_rb[r * nblk] : pos);
-}
-
-// round_start[r] = position in xg of round r's first staged value, r = 0 .. nround_ls (the last = n_cold)
-__global__ void ls_round_start_kernel(const int32_t *__restrict__ base_rb, int32_t nround_ls, int32_t nblk,
-                                      int32_t *__restrict__ round_start)
-{
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= nround_ls) round_start[r] = base_rb[(int64_t)r * nblk];
-}
-
 // xg[a_dst[k]] = x[a_col[k]] for the entries of one column block: the block's window of x is copied into LDS with
 // coalesced loads and the gathers are LDS reads (a gather that misses L1 costs the CU ~4 clocks per lane to pull its
 // 128-B line in, wherever the line comes from: as L2 gathers this pass took 78 us for 9 * 10^6 entries).
@@ -2672,358 +1126,14 @@ __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double
     }
 }
 
-__global__ void ls_stage_starts_kernel(const int32_t *__restrict__ base_br, int32_t nround, int32_t nblk, int32_t *__restrict__ blk_start)
+// the kernels that ask for more dynamic LDS than the default limit allows (per device: the builders call this)
+int spmv_kernel_attributes()
 {
-    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= nblk) blk_start[b] = base_br[(int64_t)b * nround];      // base_br has nround * nblk + 1 entries
-}
-
-// The packed columns ride along: slot k of the pack is entry (column hot_cols[k], position n_cold + k) of a virtual
-// last round, so xh = xg + n_cold is filled by the same pass and hot_pack_kernel (10^5.6 gathers of 128 B) goes.
-__global__ void ls_pack_count_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t W, int32_t *__restrict__ cnt_last,
-                                     int32_t *__restrict__ offp)
-{
-    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_hot) offp[k] = atomicAdd(&cnt_last[hot_cols[k] / W], 1);
-}
-
-__global__ void ls_pack_place_kernel(const int32_t *__restrict__ hot_cols, int32_t n_hot, int32_t W, int32_t nround_all,
-                                     const int32_t *__restrict__ base_br, const int32_t *__restrict__ offp, int32_t n_cold,
-                                     uint16_t *__restrict__ a_col, int32_t *__restrict__ a_dst)
-{
-    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_hot) return;
-    const int32_t c = hot_cols[k];
-    const int32_t pa = base_br[(int64_t)(c / W) * nround_all + (nround_all - 1)] + offp[k];
-    a_col[pa] = (uint16_t)(c % W);
-    a_dst[pa] = n_cold + k;
-}
-
-// Round-in-LDS form (default; CSRK_LS_RND=0 for the round-major form read by gathers): the round is the largest number
-// of tiles (a multiple of the workgroup's wavefronts, at most LS_RND_MAXTILES) whose staged values fit LS_RND_CAP in
-// every round.
-
-// tile_round[t] = the round that holds tile t (round r = tiles round_tile0[r] .. round_tile0[r + 1])
-__global__ void ls_tile_round_kernel(const int32_t *__restrict__ round_tile0, int32_t n_rounds, int64_t n_tiles,
-                                     int32_t *__restrict__ tile_round)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    int32_t lo = 0, hi = n_rounds - 1;
-    while (lo < hi) {
-        const int32_t mid = lo + ((hi - lo + 1) >> 1);
-        if ((int64_t)round_tile0[mid] <= t)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    tile_round[t] = lo;
-}
-
-__global__ void ls_round_total_kernel(const int64_t *__restrict__ tot, int32_t nround_ls, int32_t nblk, int64_t *__restrict__ out)
-{
-    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= nround_ls) out[r] = tot[(int64_t)r * nblk];
-}
-
-static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols, int32_t n_hot, hipStream_t s)
-{
-    ls->n_cold = 0;
-    ls->stage_tiles = 0;
-    const char *env = getenv("CSRK_LS_STAGE");
-    if (env && env[0] == '0') return CSRK_OK;
-    const int64_t n_words = ls->n_tiles * ACC_TILE;
-    // a number of column blocks that fills the chip a whole number of times (two workgroups per CU), each window
-    // at most LS_STAGE_WMAX columns
-    int cus = 0;
-    CSRK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-    const int64_t wave_of_wgs = 2 * (int64_t)(cus > 0 ? cus : 256);
-    const int64_t nblk_goal = wave_of_wgs * ceil_div((int64_t)m->ncols, wave_of_wgs * LS_STAGE_WMAX);
-    const int64_t W = ceil_div(ceil_div((int64_t)m->ncols, nblk_goal), 16) * 16;
-    const int64_t nblk = ceil_div((int64_t)m->ncols, W);
-    // (the smallest rounds make the most buckets; a balanced layout adds at most one round per workgroup)
-    const int64_t nb_max = (ceil_div(ls->n_tiles, LS_STAGE_TILES < LS_THREADS / WAVE ? LS_STAGE_TILES : LS_THREADS / WAVE) + (int64_t)ls->grid + 2) * nblk;
-    if (nb_max < 1 || nb_max > (int64_t)1 << 26) return CSRK_OK;
-    size_t mfree = 0, mtotal = 0;
-    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if ((size_t)n_words * 20 + (size_t)nb_max * 16 + (64u << 20) > mfree) return CSRK_OK;
-    if (ls->n_tiles >= INT32_MAX) return CSRK_OK;
-    DevBuf cnt, cntT, off, offp, tot, tile_round, d_rt0;
-    CSRK_TRY(tile_round.alloc((size_t)ls->n_tiles * 4));
-    CSRK_TRY(d_rt0.alloc((size_t)(ls->n_tiles + 2) * 4));
-    CSRK_TRY(offp.alloc((size_t)n_hot * 4));
-    CSRK_TRY(cnt.alloc((size_t)(nb_max + 1) * 4));
-    CSRK_TRY(cntT.alloc((size_t)(nb_max + 1) * 4));
-    CSRK_TRY(off.alloc((size_t)n_words * 4));
-    CSRK_TRY(tot.alloc((size_t)(nb_max + 1) * 8));
-    const unsigned gw = (unsigned)ceil_div(n_words, 256);
-    int stage_tiles = LS_STAGE_TILES;
-    int64_t nround_ls = 0, nround = 0, nb = 0, n_cold = 0;      // n_cold = where the virtual round starts
-    // counts per (round, block) bucket for rounds of `nt` tiles; the old count is an entry's place inside its bucket
-    // Rounds of at most `nt` tiles: every workgroup of the stream's persistent grid gets an equal share of the tiles, cut
-    // into equal rounds (whole tiles per wavefront).
-    std::vector<int32_t> h_rt0, h_wr0;
-    constexpr int NW_ = LS_THREADS / WAVE;
-    auto count_pass = [&](int nt, int64_t *max_round) -> int {
-        stage_tiles = nt;
-        h_rt0.clear();
-        h_wr0.clear();
-        const int64_t G = ls->grid;
-        for (int64_t w = 0; w < G; w++) {
-            const int64_t tb = ls->n_tiles * w / G, te = ls->n_tiles * (w + 1) / G;
-            h_wr0.push_back((int32_t)h_rt0.size());
-            if (te > tb) {
-                const int64_t k = ceil_div(te - tb, nt);
-                const int64_t per = ceil_div(ceil_div(te - tb, k), NW_) * NW_;
-                for (int64_t t = tb; t < te; t += per) h_rt0.push_back((int32_t)t);
-            }
-        }
-        h_wr0.push_back((int32_t)h_rt0.size());
-        nround_ls = (int64_t)h_rt0.size();
-        h_rt0.push_back((int32_t)ls->n_tiles);
-        nround = nround_ls + 1;      // + the virtual round of the packed columns
-        nb = nround * nblk;
-        if (nb > nb_max) return CSRK_ERR_INVALID;      // (cannot happen: a round holds at least LS_STAGE_TILES or NW tiles)
-        CSRK_HIP(hipMemcpyAsync(d_rt0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
-        ls_tile_round_kernel<<<(unsigned)ceil_div(ls->n_tiles, 256), 256, 0, s>>>(d_rt0.as<int32_t>(), (int32_t)nround_ls, ls->n_tiles,
-                                                                                tile_round.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nb + 1) * 4, s));
-        ls_cold_count_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nblk, (int32_t)W, tile_round.as<int32_t>(),
-                                               cnt.as<int32_t>(), off.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        // the counts are 32-bit: total them in 64 bits before trusting the 32-bit scans
-        CSRK_TRY(exclusive_scan_i32_to_i64(cnt.as<int32_t>(), tot.as<int64_t>(), nround_ls * nblk, s));
-        std::vector<int64_t> rs((size_t)nround_ls + 1);
-        DevBuf drs;
-        CSRK_TRY(drs.alloc((size_t)(nround_ls + 1) * 8));
-        ls_round_total_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(tot.as<int64_t>(), (int32_t)nround_ls, (int32_t)nblk,
-                                                                                   drs.as<int64_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(rs.data(), drs.p, (size_t)(nround_ls + 1) * 8, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        n_cold = rs[(size_t)nround_ls];
-        *max_round = 0;
-        for (int64_t r = 0; r < nround_ls; r++) *max_round = std::max(*max_round, rs[(size_t)r + 1] - rs[(size_t)r]);
-        return CSRK_OK;
-    };
-    // the largest rounds whose staged values fit the LDS round buffer (a round of one tile per wavefront always does)
-    int64_t max_round = 0;
-    {
-        constexpr int NW = LS_THREADS / WAVE;      // a round is a whole number of tiles per wavefront
-        static_assert(NW * ACC_TILE <= LS_RND_CAP, "the smallest round must fit the LDS round buffer");
-        bool fits = false;
-        for (int nt = LS_RND_MAXTILES / NW * NW; nt >= NW;) {
-            CSRK_TRY(count_pass(nt, &max_round));
-            if (max_round <= LS_RND_CAP) {
-                fits = true;
-                break;
-            }
-            // the fullest round scales with the round's size: jump to the size that would just fit, then step down
-            int next = (int)((double)nt * LS_RND_CAP / (double)max_round) / NW * NW;
-            nt = next < nt - NW ? next : nt - NW;
-        }
-        if (!fits) return CSRK_OK;
-    }
-    if (nround > INT32_MAX) return CSRK_OK;
-    CSRK_HIP(hipMemsetAsync(cnt.as<int32_t>() + nround_ls * nblk, 0, (size_t)(nblk + 1) * 4, s));
-    ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
-                                                                       cnt.as<int32_t>() + nround_ls * nblk, offp.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipMemsetAsync(cntT.p, 0, (size_t)(nb + 1) * 4, s));
-    ls_cold_transpose_kernel<<<(unsigned)ceil_div(nb, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
-                                                                       cntT.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    const int64_t n_all = n_cold + n_hot;
-    // worth a pass of its own only when the cold columns cannot live in L2 anyway and there are enough of them
-    if (n_cold < 1 || n_all >= (int64_t)LS_PAD || (!(env && env[0] == '1') && n_cold * 16 < n_words)) return CSRK_OK;
-    CSRK_TRY(exclusive_scan_i32(cnt.as<int32_t>(), cnt.as<int32_t>(), nb + 1, s));
-    CSRK_TRY(exclusive_scan_i32(cntT.as<int32_t>(), cntT.as<int32_t>(), nb + 1, s));
-    CSRK_TRY(ls->xg.alloc((size_t)(n_all + WAVE) * 8));      // (+ padding: the stream kernel's last pair of an odd count)
-    CSRK_TRY(ls->a_col.alloc((size_t)n_all * 2));
-    CSRK_TRY(ls->a_dst.alloc((size_t)n_all * 4));
-    CSRK_TRY(ls->round_start.alloc((size_t)(nround_ls + 1) * 4));
-    ls_round_start_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(cnt.as<int32_t>(), (int32_t)nround_ls, (int32_t)nblk,
-                                                                               ls->round_start.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(ls->round_tile0.alloc(h_rt0.size() * 4));
-    CSRK_TRY(ls->wg_round0.alloc(h_wr0.size() * 4));
-    CSRK_HIP(hipMemcpyAsync(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, hipMemcpyHostToDevice, s));
-    ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W,
-                                           tile_round.as<int32_t>(), 1, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
-                                           ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    ls_pack_place_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W, (int32_t)nround,
-                                                                       cntT.as<int32_t>(), offp.as<int32_t>(), (int32_t)n_cold,
-                                                                       ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_TRY(ls->blk_start.alloc((size_t)(nblk + 1) * 4));
-    ls_stage_starts_kernel<<<(unsigned)ceil_div(nblk + 1, 256), 256, 0, s>>>(cntT.as<int32_t>(), (int32_t)nround, (int32_t)nblk,
-                                                                            ls->blk_start.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    ls->n_stage_blk = (int32_t)nblk;
-    ls->stage_w = (int32_t)W;
+    for (const void *f : {(const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS>, (const void *)spmv_lstream_kernel<LS_PLAIN>,
+                          (const void *)spmv_lstream_kernel<LS_RND>, (const void *)spmv_lstream_kernel<LS_PLAIN, true>,
+                          (const void *)spmv_lstream_kernel<LS_RND, true>})
+        CSRK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
-    CSRK_HIP(hipStreamSynchronize(s));      // the temporaries are freed on return
-    ls->n_cold = n_cold;
-    ls->stage_tiles = stage_tiles;
-    return CSRK_OK;
-}
-
-// Copy the rows of the row-major path (the light view, or the whole matrix when nothing was cut out) into
-// the light stream.  Built with the lazy plan.  Skipped (the tile kernel stays in charge) when ncols needs
-// the two flag bits, when the copy does not fit in device memory, or with CSRK_SPMV_STREAM=0.
-template <class P, int VT>
-static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
-{
-    p->ls.on = false;
-    const char *env = getenv("CSRK_SPMV_STREAM");
-    if (env && env[0] == '0') return CSRK_OK;
-    const int64_t n_view = p->n_heavy ? p->nnz_light : m->nnz;
-    if (m->nrows == 0 || n_view < 1 || (int64_t)m->ncols > (int64_t)LS_COL_MASK) return CSRK_OK;
-    // Without long rows cut out and without a popularity skew worth packing, the gathers are either local
-    // (banded: the tile kernel's entry-per-lane order coalesces them better: 0.526 vs 0.638 ms measured) or
-    // all equally cold (uniform random columns: both kernels run at the 128-B-per-gather fabric rate), and
-    // the stream's copy of the matrix buys nothing.
-    if (!p->n_heavy && !p->n_hot && !(env && env[0] == '1')) return CSRK_OK;
-    const P *rp = (const P *)m->d_rowptrs;
-    const P *rpv = p->n_heavy ? p->rp_light.as<P>() : rp;
-    const int32_t *slot_map = p->n_hot ? p->hot_slot.as<int32_t>() : (const int32_t *)nullptr;
-    const int64_t n_tiles = ceil_div(n_view, ACC_TILE);
-    size_t mfree = 0, mtotal = 0;
-    CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
-    if ((size_t)n_tiles * ACC_TILE * 12 + ((size_t)m->nrows + n_tiles) * 8 + (64u << 20) > mfree && !(env && env[0] == '1'))
-        return CSRK_OK;
-    // Dense rows: when few rows of the view are empty (rows without entries, rows cut out for the tiers: 7 % on the
-    // headline matrix) each of them gets ONE padding entry, so every row has a run, run k IS row k, and the stream kernel
-    // neither loads row ids (4 loads per tile: 12 of its 170 us) nor clears gaps.  rpd = the view's pointers with empty
-    // rows widened to one slot.  Not when the padding would add more than an eighth to the stream, nor past P's range.
-    DevBuf rpd_buf;
-    const P *rp_dense = nullptr;
-    int64_t n_view_d = n_view, n_tiles_d = n_tiles;
-    {
-        DevBuf nz;
-        CSRK_TRY(nz.alloc((size_t)(m->nrows + 2) * 4));
-        ls_rowflag_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, m->nrows, nz.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        CSRK_TRY(exclusive_scan_i32(nz.as<int32_t>(), nz.as<int32_t>(), m->nrows, s));
-        int32_t n_nonempty = 0;
-        CSRK_HIP(hipMemcpyAsync(&n_nonempty, nz.as<int32_t>() + m->nrows, 4, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        const int64_t n_pad = (int64_t)m->nrows - n_nonempty;
-        const bool fits = sizeof(P) == 8 || n_view + n_pad <= (int64_t)INT32_MAX;
-        if (fits && n_pad * 8 <= n_view) {
-            CSRK_TRY(rpd_buf.alloc((size_t)(m->nrows + 1) * sizeof(P)));
-            ls_dense_ptr_kernel<P><<<(unsigned)ceil_div((int64_t)m->nrows + 1, 256), 256, 0, s>>>(rpv, nz.as<int32_t>(), m->nrows,
-                                                                                                rpd_buf.as<P>());
-            CSRK_LAUNCH_CHECK();
-            rp_dense = rpd_buf.as<P>();
-            n_view_d = n_view + n_pad;
-            n_tiles_d = ceil_div(n_view_d, ACC_TILE);
-        }
-        CSRK_HIP(hipStreamSynchronize(s));      // nz is released here
-    }
-    CSRK_TRY((build_stream<P, VT>(m, &p->ls, rp, rp_dense ? rp_dense : rpv, m->nrows, m->d_colinds, m->d_values, n_view_d, n_tiles_d,
-                                  m->nrows, slot_map, s, rp_dense ? rpv : (const P *)nullptr)));
-    if (p->ls.on && p->n_hot) {
-        CSRK_TRY(build_cold_stage(m, &p->ls, p->hot_cols.as<int32_t>(), p->n_hot, s));
-        // (round-in-LDS form: the round's staged values take the place of the hot window's tail)
-        if (p->ls.n_cold && p->ls.round_start.p && p->n_hot_lds > LS_RND_HOT) p->n_hot_lds = LS_RND_HOT;
-    }
-    return CSRK_OK;
-}
-
-struct PlanTrace {
-    bool on;
-    double t0;
-    static double now()
-    {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-    }
-    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
-    {
-        if (on) {
-            (void)hipDeviceSynchronize();
-            t0 = now();
-        }
-    }
-    void lap(const char *what)
-    {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const double t = now();
-        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
-        t0 = t;
-    }
-};
-
-template <class P>
-static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
-{
-    const P *rp = (const P *)m->d_rowptrs;
-    if (p->algo == CSRK_SPMV_MERGE) {
-        p->tile_items = MERGE_ITEMS;
-        p->nnz_light = m->nnz;
-        p->split_considered = allow_split;
-        PlanTrace tr;
-        if (allow_split) CSRK_TRY(build_heavy_split<P>(m, p, s));
-        tr.lap("heavy split");
-        const P *rp_path = p->n_heavy ? p->rp_light.as<P>() : rp;
-        int64_t total = (int64_t)m->nrows + p->nnz_light;
-        p->n_tiles = ceil_div(total, MERGE_ITEMS);
-        CSRK_TRY(p->tile_row.alloc((size_t)(p->n_tiles + 1) * 4));
-        CSRK_TRY(p->carry_row.alloc((size_t)p->n_tiles * 4));
-        CSRK_TRY(p->carry_val.alloc((size_t)p->n_tiles * 8));
-        int64_t nthr = p->n_tiles + 1;
-        merge_plan_kernel<P><<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(rp_path, m->nrows, p->nnz_light, MERGE_ITEMS,
-                                                                          p->n_tiles, p->tile_row.as<int32_t>());
-        CSRK_LAUNCH_CHECK();
-        if (p->n_heavy) {
-            CSRK_TRY(p->tile_cut.alloc((size_t)(p->n_tiles + 1) * 4));
-            heavy_tilecut_kernel<<<(unsigned)ceil_div(nthr, 256), 256, 0, s>>>(
-                p->tile_row.as<int32_t>(), p->n_tiles, MERGE_ITEMS, total, p->cut_pos.as<int64_t>(), p->n_heavy,
-                p->tile_cut.as<int32_t>());
-            CSRK_LAUNCH_CHECK();
-        }
-        tr.lap("merge-path tables");
-        if (allow_split) {
-            CSRK_TRY(build_hot_cache<P>(m, p, s));
-            tr.lap("hot-column census + pack");
-            CSRK_TRY(build_tiers<P>(m, p, s));
-            tr.lap("tiers");
-            if (m->val_type == CSRK_VAL_F64) CSRK_TRY((build_light_stream<P, CSRK_VAL_F64>(m, p, s)));
-            else if (m->val_type == CSRK_VAL_F32) CSRK_TRY((build_light_stream<P, CSRK_VAL_F32>(m, p, s)));
-            else CSRK_TRY((build_light_stream<P, CSRK_VAL_NONE>(m, p, s)));
-            tr.lap("light stream + cold staging");
-            if (p->n_hot && !p->ls.on) {        // no stream (no memory for it, CSRK_SPMV_STREAM=0): the tile kernel reads x itself
-                p->n_hot = 0;
-                p->hot_cols.release();
-                p->xh.release();
-            }
-            p->hot_slot.release();
-        }
-    } else if (p->algo == CSRK_SPMV_VECTOR) {
-        CSRK_TRY(p->seg_off.alloc((size_t)(m->nrows + 1) * 8));
-        if (m->nrows > 0) {
-            vec_count_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->nrows, p->seg_off.as<int64_t>());
-            CSRK_LAUNCH_CHECK();
-        }
-        CSRK_TRY(exclusive_scan_i64(p->seg_off.as<int64_t>(), p->seg_off.as<int64_t>(), m->nrows, s));
-        int64_t n_segs = 0;
-        CSRK_HIP(hipMemcpyAsync(&n_segs, p->seg_off.as<int64_t>() + m->nrows, 8, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        p->n_segs = n_segs;
-        CSRK_TRY(p->seg_row.alloc((size_t)n_segs * 4));
-        CSRK_TRY(p->seg_part.alloc((size_t)n_segs * 8));
-        if (m->nrows > 0) {
-            vec_fill_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(p->seg_off.as<int64_t>(), m->nrows,
-                                                                             p->seg_row.as<int32_t>());
-            CSRK_LAUNCH_CHECK();
-        }
-    }
     return CSRK_OK;
 }
 
@@ -3055,7 +1165,7 @@ static int get_plan_locked(Matrix *m, hipStream_t s, SpmvPlan **out, bool launch
         // Plans are built on the default stream and completed before use: their temporaries come from
         // the caching allocator, whose recycling is safe only in default-stream order.
         (void)s;
-        int rc = m->ptr64 ? build_plan<int64_t>(m, p, nullptr, want_split) : build_plan<int32_t>(m, p, nullptr, want_split);
+        int rc = build_spmv_plan(m, p, want_split);
         if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) {
             set_error("SpMV plan construction failed: %s", hipGetErrorString(hipGetLastError()));
             rc = CSRK_ERR_HIP;
@@ -3560,7 +1670,7 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            a_tiles, a_nb, p->heavy_min, af ? ACC_CB : 0, p->n_heavy ? 2 : 0, a_rows, a_nnz,
-                           t1.nrow, t1.rows, t1.nnz, TIERB_MIN, t1.cb,
+                           t1.nrow, t1.rows, t1.nnz, p->tier1_min, t1.cb,
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
                            p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
                            p->ls.round_start.p ? p->ls.stage_tiles : 0,
