@@ -12,6 +12,8 @@ roofline, a parity flag against the CPU oracle, and the oracle timed on a stated
   abt        configs[4]: mult_abt of ratings blocks A[2000] x B[20000]^T (csr/kernels/numba/multiply.py:41-57),
              values compared bit for bit with the oracle (columns compared as sets per row: DESIGN.md section 3)
   unit_rows  csrk_unit_rows_device on the headline matrix (csr/transform.py:29-66)
+  spmv_f32   float32 values x float32 vector on the headline matrix: products rounded to float32 inside the planned
+             kernels (csrk_spmv_f32x_device; csr/kernels/numba/__init__.py:55-67 as Numba types it)
   protocol   what a caller of the kernel protocol pays for mult_vec on the headline matrix with HOST vectors
              (csr/csr.py:569-590), next to the box's PCIe rates
 """
@@ -349,6 +351,49 @@ def protocol(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, product_ms=
             'parity': {'y_bitwise_equal_to_the_device_product': same, 'ok': same}}
 
 
+def spmv_f32(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, reps=20, cpu_rows=1_000_000):
+    """
+    float32 values times a float32 vector on the headline matrix (the reference's generators draw float32 half the time,
+    csr/test_utils.py:32,57-61): Numba types the loop's product as float32 (csr/kernels/numba/__init__.py:55-67), so every
+    product is rounded to float32 before it joins the float64 sum -- inside the planned kernels (csrk_spmv_f32x_device).
+    """
+    from oracle import oracle as O
+    from csr_amd import _lib
+    if rp is None:
+        nrows = ncols = 10_000_000
+        m = synth.powerlaw_csr(nrows, ncols, 200_000_000, device=dev)
+        rp, ci, vs = m['rowptrs'], m['colinds'], m['values']
+    nnz = int(ci.numel())
+    v32 = vs.to(torch.float32)
+    h = handle_t(0)
+    check(lib.csrk_create_device(nrows, ncols, nnz, rp.data_ptr(), int(rp.dtype == torch.int64), ci.data_ptr(), v32.data_ptr(),
+                                 _lib.VAL_F32, C.byref(h)))
+    x32 = synth.dense_vector(ncols, device=dev).to(torch.float32)
+    y = torch.empty(nrows, dtype=torch.float64, device=dev)
+    go = lambda: check(lib.csrk_spmv_f32x_device(h, x32.data_ptr(), y.data_ptr(), None))
+    ms = _events_ms(go, reps, warm=3)
+    rp_h = rp[:cpu_rows + 1].cpu().numpy()
+    e_s = int(rp_h[-1])
+    ci_h, v_h, x_h = ci[:e_s].cpu().numpy(), v32[:e_s].cpu().numpy(), x32.cpu().numpy()
+    t0 = time.perf_counter()
+    ref = O.mult_vec(cpu_rows, ncols, rp_h, ci_h, v_h, x_h)
+    t_cpu = time.perf_counter() - t0
+    bound = O.mult_vec(cpu_rows, ncols, rp_h, ci_h, np.abs(v_h).astype(np.float64), np.abs(x_h).astype(np.float64))
+    ref64 = O.mult_vec(cpu_rows, ncols, rp_h, ci_h, v_h.astype(np.float64), x_h.astype(np.float64))
+    got = y[:cpu_rows].cpu().numpy()
+    err = float(np.max(np.abs(got - ref) / (bound + 1e-300)))
+    check(lib.csrk_free(h))
+    alg = nnz * 8 + (nrows + 1) * rp.element_size() + ncols * 4 + nrows * 8
+    return {'config': f'mult_vec {nrows}x{ncols} nnz {nnz}, float32 values x float32 vector, y float64', 'entry': 'csrk_spmv_f32x_device',
+            'ms': round(ms, 4), 'timing': f'device events, {reps} products (the float32 vector is widened on the device inside the call)',
+            'gflops': round(2.0 * nnz / (ms * 1e-3) / 1e9, 1), 'bound': 'hbm', **_roof(alg, ms),
+            'parity': {'sample_max_err_over_sum_abs_terms': err, 'tolerance': 1e-6,
+                       'float32_products_differ_from_float64_by': float(np.max(np.abs(ref64 - ref) / (bound + 1e-300))),
+                       'ok': bool(err <= 1e-6 and err < float(np.max(np.abs(ref64 - ref) / (bound + 1e-300))))},
+            'cpu_baseline': {'value': round(2.0 * e_s / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1, 'kind': 'port',
+                             'sample': f'the first {cpu_rows} rows ({e_s} entries), one pass of orc_mult_vec_f32f32 ({t_cpu:.2f} s)'}}
+
+
 def run_all(dev, headline=None, log=None, product_ms=None):
     """
     -> {'protocol': ..., 'spmm': ..., 'transpose': ..., 'abt': ..., 'unit_rows': ..., 'seconds': ...}; a part that raises is reported as
@@ -368,8 +413,10 @@ def run_all(dev, headline=None, log=None, product_ms=None):
             log(f'[bench secondary] {name}: {out[name].get("ms", out[name].get("error"))} ms, {out[name]["seconds"]} s')
     if headline is not None:
         part('protocol', lambda: protocol(dev, *headline, product_ms=product_ms))
+        part('spmv_f32', lambda: spmv_f32(dev, *headline))
         part('unit_rows', lambda: unit_rows(dev, *headline))
     else:
+        part('spmv_f32', lambda: spmv_f32(dev))
         part('protocol', lambda: protocol(dev))
         part('unit_rows', lambda: unit_rows(dev))
     part('spmm', lambda: spmm(dev))

@@ -63,6 +63,7 @@ SIGNATURES = {
     'csrk_device_ptrs': (_int, [handle_t, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     'csrk_spmv': (_int, [handle_t, _vp, _vp]),
     'csrk_spmv_f32x': (_int, [handle_t, _vp, _vp]),
+    'csrk_spmv_f32x_device': (_int, [handle_t, _vp, _vp, _vp]),
     'csrk_spmv_device_part': (_int, [handle_t, _vp, _vp, _vp, _int]),
     'csrk_spmv_cut_rows': (_int, [handle_t, _vp, _i64, C.POINTER(_i64)]),
     'csrk_spmv_device': (_int, [handle_t, _vp, _vp, _vp]),

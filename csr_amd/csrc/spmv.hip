@@ -37,6 +37,17 @@
 #include <ctime>
 
 namespace csrk {
+// R32: float32 values times a float32 vector.  Numba types the reference's loop by its operands (csr/kernels/numba/
+// __init__.py:55-67): the PRODUCT is float32, rounded once, then added to the float64 sum.  The plans hold the values
+// widened to float64 and the vector is widened too, both exactly; their float64 product is exact (24 + 24 significant
+// bits), so rounding it to float32 IS the float32 product.
+template <bool R32>
+__device__ __forceinline__ double spmv_prod(double a, double x)
+{
+    const double t = a * x;
+    return R32 ? (double)(float)t : t;
+}
+
 void free_spmv_plan(SpmvPlan *p) { delete p; }
 
 // device memory the plan holds (private streams, tables, scratch)
@@ -137,7 +148,7 @@ constexpr int MERGE_PAIRS = MERGE_IPT / 2;
 
 // HEAVY: the path runs over the light view (rp = rp_light, nnz = nnz_light); a light entry index
 // jl maps to the actual entry jl + cut_cum[#cuts with cut_pos <= jl].
-template <class P, int VT, bool HEAVY>
+template <class P, int VT, bool HEAVY, bool R32 = false>
 __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ tile_row,
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
 #pragma unroll
     for (int u = 0; u < MERGE_PAIRS; u++) {
         const int k = 2 * (tid + u * MERGE_THREADS);
-        const double t0 = p0[u] * x[c0[u]], t1 = p1[u] * x[c1[u]];
+        const double t0 = spmv_prod<R32>(p0[u], x[c0[u]]), t1 = spmv_prod<R32>(p1[u], x[c1[u]]);
         p0[u] = k < nn ? t0 : 0.0;
         p1[u] = k + 1 < nn ? t1 : 0.0;
         if ((u + 1) % MERGE_GATHER_PAIRS == 0 && u + 1 < MERGE_PAIRS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,7 +331,7 @@ __global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__r
     if (i < n_hot) xh[i] = x[hot_cols[i]];
 }
 
-template <class PP, int PT>
+template <class PP, int PT, bool R32 = false>
 __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
@@ -376,8 +387,8 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-            const double t0 = p0[u] * x[c0[u]];
-            const double t1 = p1[u] * x[c1[u]];
+            const double t0 = spmv_prod<R32>(p0[u], x[c0[u]]);
+            const double t1 = spmv_prod<R32>(p1[u], x[c1[u]]);
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
             p1[u] = k + 1 < nn ? t1 : 0.0;
         }
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #undef PANEL_LOAD_TILE
 }
 
-template <int CB, int PT>
+template <int CB, int PT, bool R32 = false>
 __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__ pvals, const uint16_t *__restrict__ pidx,
                                                      const int32_t *__restrict__ tile_row0,
                                                      const double *__restrict__ x, int32_t ncols,
@@ -563,7 +574,8 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
                     acc = 0.0;
                     cur = r;
                 }
-                acc += a[j] * xv[j];
+                if (R32) acc += spmv_prod<true>(a[j], xv[j]);
+                else acc += a[j] * xv[j];
             }
             const int tr = cur;
             const double ts = acc;
@@ -703,7 +715,7 @@ __global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs
 // the round's range is read by gathers).  Two workgroup barriers per round.
 // DENSE: run k is row k (LightStream::dense): row ids are not loaded and there are no gaps between runs to clear.
 constexpr int LS_PLAIN = 0, LS_RND = 2;
-template <int MODE, bool DENSE = false>
+template <int MODE, bool DENSE = false, bool R32 = false>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const double *__restrict__ x,
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         double pr[ACC_K];
 #pragma unroll
         for (int j = 0; j < ACC_K; j++) {
-            pr[j] = a[j] * (inl[j] ? lv[j] : gv[j]);
+            pr[j] = spmv_prod<R32>(a[j], inl[j] ? lv[j] : gv[j]);
         }
         // Run sums go to the wavefront's staging buffer: slot 0 = the tile's leading run (the part of a row
         // begun in an earlier tile; 0.0 if the tile opens a row), slot k = the run opened by the tile's k-th
@@ -1131,7 +1143,9 @@ int spmv_kernel_attributes()
 {
     for (const void *f : {(const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS>, (const void *)spmv_lstream_kernel<LS_PLAIN>,
                           (const void *)spmv_lstream_kernel<LS_RND>, (const void *)spmv_lstream_kernel<LS_PLAIN, true>,
-                          (const void *)spmv_lstream_kernel<LS_RND, true>})
+                          (const void *)spmv_lstream_kernel<LS_RND, true>, (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, false, true>, (const void *)spmv_lstream_kernel<LS_RND, false, true>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true>, (const void *)spmv_lstream_kernel<LS_RND, true, true>})
         CSRK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
     return CSRK_OK;
@@ -1186,7 +1200,7 @@ static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
     return get_plan_locked(m, s, out, false);
 }
 
-template <class P, int VT>
+template <class P, int VT, bool R32 = false>
 static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, hipStream_t s, int part)
 {
     const P *rp = (const P *)m->d_rowptrs;
@@ -1261,7 +1275,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
-                spmv_acc_kernel<ACC_CB, ACC_THREADS><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
+                spmv_acc_kernel<ACC_CB, ACC_THREADS, R32><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
                     ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols, ap->segs.as<AccSeg>(),
                     ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
                 CSRK_LAUNCH_CHECK();
@@ -1276,8 +1290,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
         pn->carry_val.as<double>(), pn->nnz
             const unsigned grid = (unsigned)pn->groups;
-            if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
-            else spmv_panel_kernel<int32_t, PANEL_T1><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
+            if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
+            else spmv_panel_kernel<int32_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
@@ -1309,10 +1323,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #define LS_GO(D)                                                                                                       \
     do {                                                                                                               \
         if (p->ls.n_cold && p->ls.round_start.p)                                                                       \
-            spmv_lstream_kernel<LS_RND, D><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                                    \
+            spmv_lstream_kernel<LS_RND, D, R32><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                                    \
                 LS_ARGS, p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(), p->ls.wg_round0.as<int32_t>()); \
         else                                                                                                           \
-            spmv_lstream_kernel<LS_PLAIN, D><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, nil, nil, nil);           \
+            spmv_lstream_kernel<LS_PLAIN, D, R32><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, nil, nil, nil);           \
     } while (0)
                 if (p->ls.dense) LS_GO(true);
                 else LS_GO(false);
@@ -1330,9 +1344,9 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             } else {
             KernelTimer kt(p, s);
             if (p->n_heavy)
-                spmv_merge_kernel<P, VT, true><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
+                spmv_merge_kernel<P, VT, true, R32><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
             else
-                spmv_merge_kernel<P, VT, false><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
+                spmv_merge_kernel<P, VT, false, R32><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
 #undef MERGE_ARGS_LIGHT
 #undef MERGE_ARGS_FULL
             kt.stop();
@@ -1387,7 +1401,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     return CSRK_OK;
 }
 
-static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s, int part = 3)
+// r32: float32 values times a (widened) float32 vector -- products rounded to float32 (spmv_prod); merge algorithm only
+static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s, int part = 3, bool r32 = false)
 {
     // One SpMV = several kernels that share the plan's carry / partial arrays.  The per-handle lock keeps
     // the launch group together so that concurrent callers (the reference's kernels are nogil) are
@@ -1401,6 +1416,11 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     // the decision taken for its part 1 instead of counting as a call of its own
     if (part != 2) p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
 #define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s, part)
+    if (r32) {
+        CSRK_REQUIRE(m->val_type == CSRK_VAL_F32 && p->algo == CSRK_SPMV_MERGE, "float32 products need float32 values and the merge algorithm");
+        if (m->ptr64) return launch_spmv<int64_t, CSRK_VAL_F32, true>(m, p, d_x, d_y, s, part);
+        return launch_spmv<int32_t, CSRK_VAL_F32, true>(m, p, d_x, d_y, s, part);
+    }
     if (m->ptr64) {
         if (m->val_type == CSRK_VAL_F64) GO(int64_t, CSRK_VAL_F64);
         if (m->val_type == CSRK_VAL_F32) GO(int64_t, CSRK_VAL_F32);
@@ -1421,7 +1441,8 @@ namespace csrk {
 // float32 values times a float32 x: the reference's loop (csr/kernels/numba/__init__.py:55-67) is typed by Numba with a
 // float32 product -- ONE rounding -- that is then added to the float64 accumulator.  One wavefront per row, lanes take the
 // entries 64 apart, ordered tree over the lanes.  (A parity path: float32 matrices are the reference's test inputs, not the
-// headline workload; every other dtype combination multiplies in float64, which the planned kernels do.)
+// headline workload; every other dtype combination multiplies in float64, which the planned kernels do.)  Serves the
+// `vector` / `scalar` algorithms only: under `merge` (the default) the planned kernels round the products themselves (R32).
 template <class P>
 __global__ __launch_bounds__(256) void spmv_f32x_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                                        const float *__restrict__ vs, const float *__restrict__ x, int32_t nrows,
@@ -1508,8 +1529,10 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
     CSRK_TRY(dx32.alloc((size_t)m->ncols * 4 + 4));
     CSRK_TRY(dy.alloc((size_t)m->nrows * 8));
     if (m->ncols) CSRK_HIP(hipMemcpy(dx32.p, x, (size_t)m->ncols * 4, hipMemcpyHostToDevice));
-    if (m->val_type == CSRK_VAL_F32) {
-        // float32 x float32: the product is rounded to float32 (the reference's arithmetic), outside the planned kernels.
+    const bool f32_values = m->val_type == CSRK_VAL_F32;
+    const bool planned = m->spmv_algo == CSRK_SPMV_AUTO || m->spmv_algo == CSRK_SPMV_MERGE;
+    if (f32_values && !planned) {
+        // float32 x float32 under the `vector` / `scalar` baselines: a kernel of its own on the handle's arrays.
         // Reads the handle's arrays directly: under the handle's lock like every other product (unit_rows, center_rows
         // and order_columns rewrite them under it), held until the kernel has finished.
         std::lock_guard<std::mutex> lk(m->mu);
@@ -1523,16 +1546,35 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipDeviceSynchronize());
     } else {
-        // float64 (or absent) values: Numba widens x, the product is float64 -- the usual kernels on the widened vector
+        // the usual kernels on the widened vector: float64 (or absent) values multiply in float64, as Numba types that
+        // loop; float32 values round every product to float32 first (spmv_prod)
         CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
         if (m->ncols) {
             widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256>>>(dx32.as<float>(), dx.as<double>(), m->ncols);
             CSRK_LAUNCH_CHECK();
         }
-        CSRK_TRY(spmv_dispatch(m, dx.as<double>(), dy.as<double>(), nullptr));
+        CSRK_TRY(spmv_dispatch(m, dx.as<double>(), dy.as<double>(), nullptr, 3, f32_values));
     }
     CSRK_HIP(hipMemcpy(y, dy.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost));
     return CSRK_OK;
+}
+
+int csrk_spmv_f32x_device(csrk_handle_t h, const float *d_x, double *d_y, void *stream)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE((d_x || m->ncols == 0) && (d_y || m->nrows == 0), "x or y is NULL");
+    if (m->nrows == 0) return CSRK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dx;      // (pooled: recycled in default-stream order; a caller's stream is drained before it goes back)
+    CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
+    if (m->ncols) {
+        widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256, 0, s>>>(d_x, dx.as<double>(), m->ncols);
+        CSRK_LAUNCH_CHECK();
+    }
+    const int rc = spmv_dispatch(m, dx.as<double>(), d_y, s, 3, m->val_type == CSRK_VAL_F32);
+    if (s) CSRK_HIP(hipStreamSynchronize(s));      // the widened vector is released on return
+    return rc;
 }
 
 int csrk_set_spmv_algo(csrk_handle_t h, int algo)

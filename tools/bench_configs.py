@@ -4,7 +4,7 @@ The other BASELINE.json configs, one JSON line each: configs[2] (dense-panel SpM
 MovieLens-25M shape) and unit_rows on the headline matrix are bench_secondary.py's functions -- the same ones bench.py
 puts into its `secondary` block -- followed by SpGEMM throughput lines for more block sizes and a power-law A B.
 Run under rocprofv3 by tools/collect_profiles_configs.sh; the lines go into profiles/rNN_configs.json.
-    python tools/bench_configs.py [spmm|transpose|abt|unit_rows|ab|all]
+    python tools/bench_configs.py [spmm|transpose|abt|unit_rows|spmv_f32|protocol|ab|all]
 """
 import ctypes as C
 import json
@@ -47,6 +47,10 @@ def mk(m, nrows, ncols):
 
 import bench_secondary as S                                 # noqa: E402
 
+if what in ('spmv_f32', 'all'):
+    print(json.dumps(S.spmv_f32(dev)), flush=True)
+if what in ('protocol', 'all'):
+    print(json.dumps(S.protocol(dev)), flush=True)
 if what in ('unit_rows', 'all'):
     print(json.dumps(S.unit_rows(dev)), flush=True)
     check(lib.csrk_trim_cache())
