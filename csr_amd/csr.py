@@ -12,6 +12,7 @@ int64; colinds int32; values any float dtype or None; all C-contiguous.
 """
 import logging
 import sys
+import weakref
 
 import numpy as np
 
@@ -54,6 +55,8 @@ class CSR:
     __csrk_cacheable__ = True
 
     _parent = None      # subset_rows: the matrix whose colinds / values this one views
+    _views = None       # subset_rows: the live sub-matrices that view this one's arrays (weak): while there are any, no
+                        # device copy of this matrix is cached -- a write through a view would not be seen
 
     def _edited(self):
         """
@@ -217,6 +220,9 @@ class CSR:
         sub = CSR(end - begin, self.ncols, hi - lo, self.rowptrs[begin:end + 1] - lo, self.colinds[lo:hi],
                   None if self._values is None else self._values[lo:hi])
         sub._parent = self
+        if self._views is None:
+            self._views = weakref.WeakSet()
+        self._views.add(sub)
         return sub
 
     def pick_rows(self, rows, *, include_values=True):

@@ -477,14 +477,13 @@ __global__ __launch_bounds__(RS_THREADS) void row_stat_c3_kernel(T *__restrict__
     }
 }
 
-constexpr int RS_PIN_SLOTS = 256;
-static std::atomic<unsigned> g_pin_next{0};
-// a non-blocking stream and an event per device, made on first use (small copies that should not queue behind a kernel)
+// a non-blocking stream, two events and four words of pinned host memory per device, made on first use; `turn` is held by
+// the call that is using them (calls on one device take turns, calls on different devices do not meet)
 struct SideStream {
     hipStream_t st;
     hipEvent_t ev, ev2;
-    int32_t *pinned;      // RS_PIN_SLOTS x 4 words of pinned host memory a kernel on `st` can store to (hipHostMalloc); a call
-                          // takes the next slot, so calls on different handles (threads) never read each other's lengths
+    int32_t *pinned;      // 4 words of pinned host memory a kernel on `st` can store to (hipHostMalloc)
+    std::mutex *turn;
 };
 
 // the four list boundaries of the class scan -> pinned host memory, by a one-wavefront kernel on the side stream: a
@@ -506,7 +505,8 @@ static int side_stream(SideStream *out)
         CSRK_HIP(hipStreamCreateWithFlags(&per_dev[dev].st, hipStreamNonBlocking));
         CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev, hipEventDisableTiming));
         CSRK_HIP(hipEventCreateWithFlags(&per_dev[dev].ev2, hipEventDisableTiming));
-        CSRK_HIP(hipHostMalloc((void **)&per_dev[dev].pinned, RS_PIN_SLOTS * 4 * sizeof(int32_t), hipHostMallocDefault));
+        CSRK_HIP(hipHostMalloc((void **)&per_dev[dev].pinned, 4 * sizeof(int32_t), hipHostMallocDefault));
+        per_dev[dev].turn = new std::mutex();
     }
     *out = per_dev[dev];
     return CSRK_OK;
@@ -553,13 +553,17 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     const unsigned ga = (unsigned)ceil_div((int64_t)m->nrows, 256);
     SideStream side;
     CSRK_TRY(side_stream(&side));
-    // The side stream and its two events are the device's, not this call's: calls from several threads (different
-    // handles) take turns.  Nothing is lost: every call ends by draining the device.
-    static std::mutex side_mu;
-    std::lock_guard<std::mutex> side_lk(side_mu);
-    // declared after every DevBuf above: on ANY return the device drains (both streams) before the buffers go back to the pool
+    // The side stream, its events and its pinned words are the device's, not this call's: calls from several threads
+    // (different handles) on ONE device take turns.  Nothing is lost: every call ends by draining the device.
+    std::lock_guard<std::mutex> side_lk(*side.turn);
+    // declared after every DevBuf above: on ANY early return the device drains (both streams) before the buffers go back to
+    // the pool (the normal path ends in a synchronisation of its own and disarms this one)
     struct DrainOnExit {
-        ~DrainOnExit() { (void)hipDeviceSynchronize(); }
+        bool armed = true;
+        ~DrainOnExit()
+        {
+            if (armed) (void)hipDeviceSynchronize();
+        }
     } drain_on_exit;
 #define GO(P, T)                                                                                                       \
     do {                                                                                                               \
@@ -575,7 +579,7 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipEventRecord(side.ev2, nullptr));      /* the lists exist */                                        \
         CSRK_HIP(hipStreamWaitEvent(side.st, side.ev, 0));                                                             \
-        int32_t *pin = side.pinned + (size_t)(g_pin_next.fetch_add(1) % RS_PIN_SLOTS) * 4;                              \
+        int32_t *pin = side.pinned;                                                                                    \
         row_list_bounds_kernel<<<1, 64, 0, side.st>>>(counts.as<int32_t>(), n_waves, pin);                             \
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipStreamSynchronize(side.st));                                                                       \
@@ -638,6 +642,7 @@ static int row_stat(Matrix *m, void *out_host, void *out_dev)
     }
 #undef GO
     CSRK_HIP(hipDeviceSynchronize());
+    drain_on_exit.armed = false;      // both streams have drained
     if (out_host) CSRK_HIP(hipMemcpy(out_host, out, (size_t)m->nrows * m->val_bytes(), hipMemcpyDeviceToHost));
     return CSRK_OK;
 }

@@ -467,7 +467,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
 {
     constexpr bool HAS_V = VT != CSRK_VAL_NONE;
     if (n == 0) {
-        CSRK_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(key_range + 1) * sizeof(P), s));
+        if (out_ptr) CSRK_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(key_range + 1) * sizeof(P), s));
         CSRK_HIP(hipStreamSynchronize(s));
         return CSRK_OK;
     }
@@ -565,8 +565,10 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
         r_in = r_out;
         v_in = v_out;
     }
-    rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(ceil_div(n + 1, 4), 256), 256, 0, s>>>(keyL.as<int32_t>(), n, key_range, out_ptr);
-    CSRK_LAUNCH_CHECK();
+    if (out_ptr) {
+        rowptr_from_sorted_keys<P><<<(unsigned)ceil_div(ceil_div(n + 1, 4), 256), 256, 0, s>>>(keyL.as<int32_t>(), n, key_range, out_ptr);
+        CSRK_LAUNCH_CHECK();
+    }
     CSRK_HIP(hipStreamSynchronize(s));   // temporaries go back to the pool on return
     return CSRK_OK;
 }
@@ -583,10 +585,13 @@ static int transpose_impl(Matrix *a, Matrix *t, hipStream_t s)
 int stable_sort_payload_by_key(const int32_t *keys, const int32_t *payload, int64_t n, int32_t key_range,
                                int64_t payload_range, int32_t *out_payload, hipStream_t s)
 {
+    // (the run starts are not wanted: with a key range of 2^30 they would be 8 GB)
     DevBuf ptrs;
-    CSRK_TRY(ptrs.alloc((size_t)((int64_t)key_range + 1) * 8));
+    const bool packed_route = key_range > 256 && key_range <= 65536 && payload_range <= (1ll << 24);      // (that route derives them anyway)
+    if (packed_route) CSRK_TRY(ptrs.alloc((size_t)((int64_t)key_range + 1) * 8));
     return sort_records<int64_t, CSRK_VAL_NONE, false>(keys, payload, nullptr, (const int64_t *)nullptr, 0, n, key_range,
-                                                       payload_range, ptrs.as<int64_t>(), out_payload, nullptr, s);
+                                                       payload_range, packed_route ? ptrs.as<int64_t>() : (int64_t *)nullptr,
+                                                       out_payload, nullptr, s);
 }
 
 // Stable sort of (key, int32 payload, float64 value) records by key in [0, key_range): the sorted payloads and values,

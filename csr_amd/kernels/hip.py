@@ -328,7 +328,9 @@ def to_handle(csr):
         if not (isinstance(orig, np.ndarray) and a.ctypes.data == orig.ctypes.data):
             return False
         return not guarded or orig.base is None or _is_lease(orig.base)      # (a result array of this module: _out)
+    # (a matrix with live subset_rows views is copied per handle: the views write through to its host arrays unguarded)
     cacheable = (mode != 'off' and nnz >= 4096 and (not guarded or getattr(type(csr), '__csrk_cacheable__', False))
+                 and not getattr(csr, '_views', None)
                  and own(rps, csr.rowptrs) and own(cis, csr.colinds) and own(vs, csr.values))
     if cacheable:
         key = (id(csr), nr, nc, nnz, _arr_key(rps), _arr_key(cis), _arr_key(vs))

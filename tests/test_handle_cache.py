@@ -267,7 +267,8 @@ def test_invalidate_reaches_copies_that_share_an_array(K):
 def test_subset_rows_under_the_guard_gives_writeable_views(K, monkeypatch):
     """
     A product caches A and write-protects its arrays; a row range taken afterwards must still behave like the
-    reference's (csr/structure.py:70-81: views that write through), and its edits must drop A's device copy.
+    reference's (csr/structure.py:70-81: views that write through).  While such a sub-matrix is alive A is NOT cached
+    again: a write through the view -- announced or not -- must reach the next product.
     """
     A = _mat()
     K.release_handle(K.to_handle(A))
@@ -275,17 +276,22 @@ def test_subset_rows_under_the_guard_gives_writeable_views(K, monkeypatch):
     S = A.subset_rows(10, 5000)
     assert S.values.flags.writeable and S.colinds.flags.writeable and np.shares_memory(S.values, A.values)
     assert not K.lib.live                             # taking the views dropped the cached copy
-    K.release_handle(K.to_handle(A))                  # cached (and guarded) again while S is alive
-    assert K.lib.created == 2 and K.lib.live
+    K.release_handle(K.to_handle(A))                  # copied for this handle only: S could write behind a cached copy
+    assert K.lib.created == 2 and not K.lib.live and A.values.flags.writeable
     before = A.values[10]
-    S._edited()                                       # what S.normalize_rows() / S.sort_rows() call before writing
-    S.values[...] = 7.0                               # a view of A's array: the write goes through
-    assert A.values[10] == 7.0 and before != 7.0 and not K.lib.live
+    S.values[...] = 7.0                               # a view of A's array, written WITHOUT announcing it
+    assert A.values[10] == 7.0 and before != 7.0
     K.release_handle(K.to_handle(A))
-    S.values = S.values * 2.0                         # replaces S's array: still announces the edit up the chain
-    assert not K.lib.live
+    assert K.lib.created == 3 and not K.lib.live      # ... and the next handle is a fresh copy that holds the 7.0s
+    del S
+    gc.collect()
+    K.release_handle(K.to_handle(A))                  # no view left: cached (and guarded) again
+    assert K.lib.created == 4 and K.lib.live and not A.values.flags.writeable
     K.release_handle(K.to_handle(A))
     assert K.lib.created == 4
+    S2 = A.subset_rows(0, 100)                        # the sub-matrix's own mutators still announce their edits up the chain
+    S2._edited()
+    assert not K.lib.live
 
 
 def test_in_place_operations_are_not_retried(K, monkeypatch):
