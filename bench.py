@@ -405,8 +405,8 @@ def main():
     # colinds 4 B + values 8 B per entry it processes; the tile kernel also reads one row pointer and
     # writes one y entry per row; a panel kernel reads one 4-B row pointer and writes one 8-B partial per
     # (column block, row) pair of its tier; each kernel reads x once.
-    # st[20]: the short rows run as the light stream (else the merge-path tile kernel); st[18]: tier 0 in
-    # accumulator form (st[9] = its rows; one row pointer + one y entry each) or in pair form (st[9] = pairs).
+    # st[20]: the short rows run as the light stream (else the merge-path tile kernel); tier 0 is in accumulator form
+    # (st[9] = its rows; one row pointer + one y entry each).
     if int(st[20]):
         light = {'kernel': 'spmv_lstream_kernel', 'role': 'short rows: one wavefront per 512-entry tile of the light stream'}
     else:
@@ -421,10 +421,8 @@ def main():
                     algorithmic_bytes=nnz_path * 12 + (n_loc + 1) * rp.element_size() + n_loc * 8 + ncols * 8,
                     stream_bytes=nnz_path * 12 + int(st[22]) * 4 + n_loc * 8 + int(st[24]) * 8)]
     if int(st[10]):
-        t0 = {'kernel': 'spmv_acc_kernel', 'role': 'tier 0 (longest rows): x window + one accumulator per row in LDS, 10-B entries (f64 value + 16-bit column/row-step word)'} \
-            if int(st[18]) else {'kernel': 'spmv_panel_kernel<tier0>', 'role': 'tier 0, (block, row) pair form: x window in LDS'}
-        t0_stream = (int(st[4]) * 512 * 10 + int(st[4]) * 4 + ncols * 8 + 256 * int(st[9]) * 8) if int(st[18]) \
-            else int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8
+        t0 = {'kernel': 'spmv_acc_kernel', 'role': 'tier 0 (longest rows): x window + one accumulator per row in LDS, 10-B entries (f64 value + 16-bit column/row-step word)'}
+        t0_stream = int(st[4]) * 512 * 10 + int(st[4]) * 4 + ncols * 8 + 256 * int(st[9]) * 8
         kernels.append(dict(t0, ms=k_ms2[1], events=k_src[1], entries=int(st[10]),
                             algorithmic_bytes=int(st[10]) * 12 + int(st[9]) * 12 + ncols * 8, stream_bytes=t0_stream))
     if int(st[13]):
@@ -451,19 +449,11 @@ def main():
             traffic_all[k['kernel']] = tr
             k['traffic_gbs'] = round(tr / (k['ms'] * 1e-3) / 1e9, 1) if k['ms'] > 0 else 0.0
             k['traffic_over_algorithmic'] = round(tr / k['algorithmic_bytes'], 3) if k['algorithmic_bytes'] else None
-    # the dominant kernel: the slowest one on the main stream.  A kernel that runs on the plan's side stream BESIDE another
-    # (tier 1's pair kernel next to the accumulator kernel) lasts as long as its neighbour lets it; its duration is
-    # reported, but it does not bound the step
-    for k in kernels:
-        if int(st[28]) and k['kernel'] == 'spmv_panel_kernel<tier1>':
-            k['runs_beside'] = 'spmv_acc_kernel'
-    dom = max((k for k in kernels if 'runs_beside' not in k), key=lambda k: k['ms'])
+    # the dominant kernel: the slowest one (they run one after the other on one stream)
+    dom = max(kernels, key=lambda k: k['ms'])
     k_sum_ms = sum(k['ms'] for k in kernels)
     frac_step = round(whole_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
     notes = []
-    if int(st[28]):
-        notes.append('tier 1\'s pair kernel runs on a side stream beside the tier-0 accumulator kernel: the per-kernel times overlap '
-                     'and add up to more than the step; frac_whole_spmv_over_step is the whole product over the wall time')
     if dom['stream_gbs'] > 6290.0 * 1.1:
         notes.append('accounting check: the dominant kernel\'s own-stream rate exceeds the measured copy rate by more than 10 %')
     roofline = {
@@ -506,7 +496,7 @@ def main():
                    'columns': 'Zipf(1.0) popularity over a permuted column space, distinct+sorted per row',
                    'algo': algo_name, 'tile_items': tile_items.value, 'tiles': n_tiles.value,
                    'rows_in_panels': n_heavy, 'tier0': {'min_entries': int(st[6]), 'column_block': int(st[7]), 'entries': int(st[10]), 'pairs': int(st[9]),
-                             'accumulator_workgroups': int(st[27]), 'tier1_kernel_beside_it': bool(st[28])},
+                             'accumulator_workgroups': int(st[27])},
                    'tier1': {'min_entries': int(st[14]), 'column_block': int(st[15]), 'rows': int(st[11]), 'entries': int(st[13]), 'pairs': int(st[12])},
                    'hot_column_cache': {'columns': int(st[16]), 'entry_share_sampled': round(int(st[17]) / 1e6, 4), 'slots': int(st[19])},
                    'cold_staged_entries': int(st[24]),

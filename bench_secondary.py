@@ -108,12 +108,41 @@ def spmm(dev, reps=10, cpu_entries=2_000_000):
     t_cpu = time.perf_counter() - t0
     # |C - C_oracle| <= 1e-6 * sum_j |a_ij| max_c |B_jc| is implied by the max-norm check below on U(-1,1) data
     samp = float(np.max(np.abs(C_h - Cm[:r_s].cpu().numpy())) / max(1e-300, float(np.max(np.abs(C_h)))))
+    # What bounds this product is not its algorithmic bytes but the rows of B that have to ENTER a CU: one 8 k-byte row per
+    # entry of a light row (L1 line fills: the guide's ~17 TB/s chip-wide for gathers served by L2), one LDS-staged tile
+    # sweep of B per heavy row group (coalesced), and what crosses the fabric (measured by the PMC passes of the newest
+    # profile, at the ~6.4 TB/s the fabric delivers).  The larger of the two times is the design's own bound.
+    st = (C.c_int64 * 9)()
+    check(lib.csrk_spmm_plan_stats(h, st, 9))
+    heavy_nnz = int(st[5]) if int(st[0]) else 0
+    light_fill = (nnz - heavy_nnz) * k * 8
+    heavy_stage = int(st[3]) * n * k * 8 if int(st[0]) else 0
+    fabric = None
+    try:
+        import glob
+        import json
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        js = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_configs_pmc_traffic.json')))
+        tr = json.load(open(js[-1]))['hbm_bytes_per_launch'] if js else {}
+        fabric = sum(v for kn, v in tr.items() if kn.startswith('spmm_')) or None
+        fabric_src = os.path.basename(js[-1]) if js else None
+    except Exception:                         # noqa: BLE001 -- the bound is reported without the measured half
+        fabric_src = None
+    l1_ms = (light_fill + heavy_stage) / 17e12 * 1e3
+    fab_ms = fabric / 6.4e12 * 1e3 if fabric else None
+    gather = {'light_row_l1_fill_bytes': light_fill, 'heavy_tile_staging_bytes': heavy_stage, 'l1_side_ms_at_17_TBs': round(l1_ms, 4),
+              'fabric_bytes_measured': fabric, 'fabric_source': fabric_src, 'fabric_ms_at_6.4_TBs': None if fab_ms is None else round(fab_ms, 4),
+              'bound_ms': round(max(l1_ms, fab_ms or 0.0), 4), 'frac_of_gather_bound': round(max(l1_ms, fab_ms or 0.0) / ms, 4),
+              'heavy_rows': {'on': bool(st[0]), 'min_entries': int(st[1]), 'rows': int(st[2]), 'row_groups': int(st[3]),
+                             'column_ranges': int(st[4]), 'entries': heavy_nnz}}
     check(lib.csrk_free(h))
     check(lib.csrk_free(habs))
     out = {'config': 'spmm_dense A 2000000x2000000 nnz 50000000 (power-law) x B 2000000x64 f64', 'entry': 'csrk_spmm_dense_device',
            'ms': round(ms, 4), 'gflops': round(2.0 * nnz * k / ms / 1e6, 1), 'bound': 'hbm', **_roof(alg, ms),
            'parity': {'col0_vs_spmv_max_err_over_sum_abs_terms': col0, 'sample_vs_oracle_max_rel_err': samp,
                       'tolerance': 1e-6, 'ok': bool(col0 <= 1e-6 and samp <= 1e-6)},
+           'gather_bound': gather,
            'cpu_baseline': {'value': round(2.0 * e_s * k / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1, 'kind': 'port',
                             'sample': f'the first {r_s} rows of A ({e_s} entries) x the same B, one pass of orc_spmm_dense ({t_cpu:.2f} s)'}}
     return out

@@ -81,6 +81,7 @@ SIGNATURES = {
     'csrk_spgemm_set_order': (_int, [_int]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),
     'csrk_spmm_dense_device': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64, _vp]),
+    'csrk_spmm_plan_stats': (_int, [handle_t, _vp, _int]),
     'csrk_from_coo': (_int, [_i32, _i32, _i64, _vp, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_transpose': (_int, [handle_t, _int, C.POINTER(handle_t)]),
     'csrk_row_nnzs': (_int, [handle_t, _vp]),

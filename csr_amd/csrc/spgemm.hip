@@ -1654,9 +1654,9 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
             if (bad) strips = 0;
         }
         // expand-sort-compress takes the rows above esc_min products that are not dense enough for the strips
-        // (CSRK_SPGEMM_ESC=0: off; CSRK_SPGEMM_ESC_MIN=n: its lower bound, default SGE_MIN)
-        const char *esc_env = getenv("CSRK_SPGEMM_ESC"), *escmin_env = getenv("CSRK_SPGEMM_ESC_MIN");
-        int64_t esc_min = (esc_env && atoi(esc_env) == 0) ? -1 : (escmin_env && atoll(escmin_env) >= 0 ? atoll(escmin_env) : SGE_MIN);
+        // (CSRK_SPGEMM_ESC=0: off -- the fallback paths run instead, as they do beyond the sort's budget)
+        const char *esc_env = getenv("CSRK_SPGEMM_ESC");
+        int64_t esc_min = (esc_env && atoi(esc_env) == 0) ? -1 : SGE_MIN;
         int32_t s_dense = (int32_t)ceil_div(b->ncols, SGS_W);       // the strips' density test, whether they can be used or not
         if (s_dense > SGS_MAX_S) s_dense = 0;
         CSRK_TRY(route.alloc((size_t)nr + 1));
@@ -1772,9 +1772,10 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
         }
         // symbolic (rows with no products keep the zero count of the memset)
         const unsigned gq = (unsigned)ceil_div(nr, 16), gq2 = (unsigned)ceil_div(nr, 8);
-        // the rows of at most SG_WAVE_CAP products: one pass into temporaries when they fit (CSRK_SPGEMM_SMALL_FUSED=0: two passes)
+        // the rows of at most SG_WAVE_CAP products: one pass into temporaries when they fit (CSRK_SPGEMM_FUSED=0: two passes,
+        // the form a product whose temporaries exceed the budget takes)
         {
-            const char *sf_env = getenv("CSRK_SPGEMM_SMALL_FUSED");
+            const char *sf_env = getenv("CSRK_SPGEMM_FUSED");
             if (!(sf_env && atoi(sf_env) == 0)) {
                 CSRK_TRY(small_room.alloc((size_t)(nr + 1) * 4));
                 CSRK_TRY(small_off.alloc((size_t)(nr + 1) * 8));
@@ -1850,8 +1851,8 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
                     CSRK_LAUNCH_CHECK();
                 }
                 grid_strip = (unsigned)(n_units < (int64_t)grid_lds * SGS_WAVES_PER_CU ? n_units : (int64_t)grid_lds * SGS_WAVES_PER_CU);
-                // one pass into a temporary when it fits (CSRK_SPGEMM_STRIP_FUSED=0: the two-pass form, for measurements)
-                const char *fu_env = getenv("CSRK_SPGEMM_STRIP_FUSED");
+                // one pass into a temporary when it fits (CSRK_SPGEMM_FUSED=0: the two-pass form)
+                const char *fu_env = getenv("CSRK_SPGEMM_FUSED");
                 if (!(fu_env && atoi(fu_env) == 0)) {
                     DevBuf cap;
                     CSRK_TRY(cap.alloc((size_t)(n_units + 1) * 4));

@@ -40,8 +40,8 @@ struct SegDesc {
 };
 
 // ---- heavy rows: accumulators in registers, B tiles staged in LDS (north_star: "dense B tile staged in LDS") ----------
-// The longest rows hold most of a power-law matrix (BASELINE matrix: 58 % of the entries in 2039 rows of >= 2048
-// entries): read row by row, each entry pulls a 512-B row of B into a CU, and nothing is reused.  Turned round: a
+// The longest rows hold most of a power-law matrix (BASELINE matrix: 46 % of the entries in its 512 longest rows, 52 % in
+// 1024): read row by row, each entry pulls a 512-B row of B into a CU, and nothing is reused.  Turned round: a
 // persistent 1024-thread workgroup owns HR_ROWS = 512 heavy rows -- wavefront w holds rows 32 w .. 32 w + 31, one
 // accumulator per (row, panel column) in REGISTERS (lane = panel column: 32 doubles = 64 VGPRs per lane) -- and sweeps a
 // range of column TILES of HR_TILE = 128 rows of B (64 KiB at 64 panel columns), copied into LDS with coalesced 16-B loads,
@@ -50,12 +50,13 @@ struct SegDesc {
 // value}; an entry is one ds_read_b64 per lane (the 64 lanes read one contiguous 512-B row: no bank conflicts) and one
 // FMA into the accumulator of its row.  The row is wavefront-uniform, so that accumulator is a dynamically indexed
 // REGISTER: s_set_gpr_idx_on + v_fma_f64 with relative destination (the accumulators are pinned to v[64:127]; the
-// compiler alone puts a dynamically indexed array of this size into scratch memory).  Entries, values and bucket
-// bounds are wavefront-uniform too: scalar loads.
+// compiler alone puts a dynamically indexed array of this size into scratch memory).  What bounds the kernel is the
+// number of instructions an entry needs -- a SIMD starts one vector and the CU one scalar instruction per clock -- not
+// bytes: see spmm_hrows_kernel.
 // With G row groups and R column ranges (G R = number of CUs; the G workgroups of a column range sit on ONE XCD and walk
 // the same tiles at the same pace, so the tile a workgroup stages is usually in that XCD's L2) every staged B row serves
-// all the entries the workgroup's 512 rows have on it (3.6 on average on the BASELINE matrix) instead of one: 4 GB of
-// coalesced tile loads from L2 instead of 14.8 GB of 128-B line fills.  Each workgroup writes the partial panel of its
+// all the entries the workgroup's 512 rows have on it (11 on average for the BASELINE matrix' first row group, 1.6 for
+// its second) instead of one: G x 1 GB of coalesced tile loads instead of 512 B of 128-B line fills per entry.  Each workgroup writes the partial panel of its
 // rows over its column range; the reduce kernel adds a row's R partials in range order (fixed order: bitwise
 // reproducible; inside a tile a row's entries keep their storage order).
 constexpr int HR_THREADS = 1024;
@@ -600,9 +601,9 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
     std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return len[(size_t)a] != len[(size_t)b] ? len[(size_t)a] > len[(size_t)b] : a < b; });
     // Every row group sweeps all of B once (G n_cols rows of B staged in all), tile by tile, whatever it finds there: a
     // group costs its tiles (staging, a barrier, a partial batch per wavefront) plus ~21 ps per entry, and saves the ~63 ps
-    // per entry of the light-row kernel.  Measured on the BASELINE matrix (2M columns): the second group of 512 rows
-    // (4.9 M entries... see DESIGN.md section 7) pays, the third and fourth (2 M each) do not.  Take row groups, longest
-    // rows first, while the group's entries are at least 1.25 x the rows of B it stages.
+    // per entry of the light-row kernel.  Measured on the BASELINE matrix (2M columns; groups of 23.0 / 3.2 / 1.8 / 1.2 M
+    // entries): one group 2.22 ms for the product, two 2.12, four 2.13, eight 2.55.  Take row groups, longest rows first,
+    // while the group's entries are at least 1.25 x the rows of B it stages.
     int G = 0;
     int64_t nnz_h = 0;
     size_t taken = 0;
@@ -823,6 +824,19 @@ int csrk_spmm_dense_device(csrk_handle_t h, const double *d_B, int32_t k, int64_
     if (!m) return CSRK_ERR_INVALID;
     CSRK_REQUIRE(d_B && d_C, "B or C is NULL");
     return spmm_device(m, d_B, k, ldb, d_C, ldc, (hipStream_t)stream);
+}
+
+int csrk_spmm_plan_stats(csrk_handle_t h, int64_t *out, int n)
+{
+    Matrix *m = from_handle(h);
+    if (!m) return CSRK_ERR_INVALID;
+    CSRK_REQUIRE(out && n >= 0, "out is NULL");
+    std::lock_guard<std::mutex> lk(m->mu);
+    const SpmmPlan *p = m->spmm_plan;
+    const int64_t v[9] = {p && p->hr_on ? 1 : 0, p ? p->hr_min : 0, p ? p->hr_n : 0, p ? p->hr_G : 0, p ? p->hr_R : 0,
+                          p ? p->hr_nnz : 0, p ? p->hr_tiles : 0, p ? p->n_segs : 0, p ? p->n_multi : 0};
+    for (int i = 0; i < n && i < 9; i++) out[i] = p && !p->hr_on && i >= 1 && i <= 6 ? 0 : v[i];
+    return CSRK_OK;
 }
 
 int csrk_spmm_dense(csrk_handle_t h, const double *B, int32_t k, int64_t ldb, double *C, int64_t ldc)

@@ -477,8 +477,7 @@ static int sort_records(const int32_t *keys, const int32_t *payload, const void 
     const int64_t n_chunks = ceil_div(n, RX_CHUNK);
 
     DevBuf table, total, rlo, rhi, keyA, keyB, rowA, rowB, valA, valB, keyL;
-    static const bool packed_ok = [] { const char *e = getenv("CSRK_TRANSPOSE_PACKED"); return !(e && e[0] == '0'); }();
-    const bool packed = passes == 2 && payload_range <= (1ll << 24) && packed_ok;
+    const bool packed = passes == 2 && payload_range <= (1ll << 24);
     const int64_t n_chunks2 = packed ? n_chunks + 256 : n_chunks;      // aligned chunks: at most one partial chunk per run more
     CSRK_TRY(table.alloc((size_t)(256 * n_chunks2 + 1) * 8));
     CSRK_TRY(total.alloc(256 * 8));

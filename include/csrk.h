@@ -195,6 +195,10 @@ CSRK_API int csrk_spmm_dense(csrk_handle_t a, const double *B, int32_t k, int64_
                              double *C, int64_t ldc);
 CSRK_API int csrk_spmm_dense_device(csrk_handle_t a, const double *d_B, int32_t k, int64_t ldb,
                                     double *d_C, int64_t ldc, void *stream);
+/* Diagnostics: the dense-panel plan of a handle after its first csrk_spmm_dense*: out[0] = 1 when the longest rows run in
+ * the register-accumulator form (csrc/spmm_dense.hip), [1] their row-length threshold, [2] their number, [3] row groups,
+ * [4] column ranges, [5] their entries, [6] column tiles, [7] segments of the other rows, [8] of which partial (split rows). */
+CSRK_API int csrk_spmm_plan_stats(csrk_handle_t a, int64_t *out, int n);
 
 /* ---- transpose ------------------------------------------------------------------------
  * csr/structure.py:172-247 (_transpose_values / _transpose_structure / transpose).

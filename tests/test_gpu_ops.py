@@ -436,10 +436,9 @@ def test_spgemm_deterministic(paths, monkeypatch):
     rows are unsorted or the products exceed the sort's budget): LDS tiles, the big LDS hash table, HBM work rows.
     """
     if paths == 'two-pass strips':          # (the strips' form for products whose temporary exceeds the budget)
-        monkeypatch.setenv('CSRK_SPGEMM_STRIP_FUSED', '0')
-        monkeypatch.setenv('CSRK_SPGEMM_SMALL_FUSED', '0')      # (and the wave-per-row kernels in two passes)
+        monkeypatch.setenv('CSRK_SPGEMM_FUSED', '0')            # (strips and wave-per-row kernels in two passes)
     if paths == 'fallbacks':
-        monkeypatch.setenv('CSRK_SPGEMM_SMALL_FUSED', '0')
+        monkeypatch.setenv('CSRK_SPGEMM_FUSED', '0')
         monkeypatch.setenv('CSRK_SPGEMM_STRIPS', '0')
         monkeypatch.setenv('CSRK_SPGEMM_ESC', '0')
     from oracle import oracle as O

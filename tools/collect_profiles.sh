@@ -6,6 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
+python3 tools/tree_stamp.py > $OUT/tree.txt      # the sources these profiles are taken from
 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err      # the driver's command line (secondary block included)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --no-cpu-baseline --no-secondary > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/fetch.log 2>&1

@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 export PYTHONPATH=$GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}cfg
 rm -rf $OUT; mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/tools/tree_stamp.py > $OUT/tree.txt      # the sources these profiles are taken from
 cd /tmp
 # a plain run first: its JSON lines are profiles/${TAG}_configs.json (timings without the profiler attached)
 python $GRAFT_REPO_ROOT/tools/bench_configs.py all > $OUT/plain.log 2>&1

@@ -26,8 +26,8 @@ def pmc(d):
                 or 'csrk::hot_pack' in r['Kernel_Name'] or 'csrk::ls_stage_kernel' in r['Kernel_Name']:
             full = r['Kernel_Name'].split('csrk::')[1].split('(')[0]
             name = full.split('<')[0]
-            if name == 'spmv_panel_kernel':      # two instantiations: tier 0 (LDS window), tier 1 (L2 window)
-                name += '<tier0>' if ', true,' in full else '<tier1>'
+            if name == 'spmv_panel_kernel':      # (bench.py's name for the pair kernel)
+                name += '<tier1>'
             agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 allc = {}
@@ -55,3 +55,6 @@ if bench['roofline'].get('traffic') is None and bench['roofline']['kernel'] in t
 open(f'profiles/{tag}_bench.json', 'w').write(json.dumps(bench) + '\n')
 print(json.dumps(out['hbm_bytes_per_launch']))
 print({k: v for k, v in bench['roofline'].items() if k != 'all_kernels'})
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from record_tree import record      # noqa: E402
+record(tag, 'spmv', src)

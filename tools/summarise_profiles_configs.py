@@ -51,3 +51,6 @@ json.dump({'workload': 'tools/bench_configs.py all (unit_rows on the headline ma
                      'read bytes = 2 x FETCH_SIZE x 1024 (128-B requests tallied at 64 B on gfx950), writes = WRITE_SIZE x 1024'},
           open(f'profiles/{tag}_configs_pmc_traffic.json', 'w'), indent=1)
 print(json.dumps({k: round(v / 1e6, 1) for k, v in sorted(traffic.items())}))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from record_tree import record      # noqa: E402
+record(tag, 'configs', src)
