@@ -330,7 +330,7 @@ def test_spgemm_reference_order_golden(golden, reference_order):
     assert n_reordered > 0            # the fixtures do hold rows whose reference order is not ascending
 
 
-@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'unsorted_b', 'abt_block'])
+@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'unsorted_b', 'abt_block', 'wide', 'wider'])
 def test_spgemm_reference_order_vs_oracle(case, reference_order):
     "the same on products that take every accumulator path (hash, strips, expand-sort-compress), against the oracle's raw output"
     from oracle import oracle as O
@@ -351,6 +351,15 @@ def test_spgemm_reference_order_vs_oracle(case, reference_order):
     elif case == 'unsorted_b':        # discovery order follows B's STORAGE order, not its columns
         A = _rand(rng, 800, 600, rng.integers(0, 25, 800))
         B = _rand(rng, 600, 900, rng.integers(0, 40, 600))
+    elif case in ('wide', 'wider'):   # a product too wide for the discovery pass's per-column LDS tables (30 000 columns: the
+        # rows of C still fit LDS for the bisection; 70 000: 16-bit positions do not reach, bisection in memory for long rows)
+        nc = 30000 if case == 'wide' else 70000
+        la = rng.integers(0, 10, 900)
+        la[::60] = 300
+        A = _rand(rng, 900, 700, la)
+        lb = rng.integers(0, 60, 700)
+        lb[::35] = 12000 if case == 'wide' else 45000
+        B = _rand(rng, 700, nc, lb)
     else:
         m = synth.movielens_like(device='cpu')
         M = CSR(m['nrows'], m['ncols'], int(m['colinds'].numel()), m['rowptrs'].numpy(), m['colinds'].numpy(),

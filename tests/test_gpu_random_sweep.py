@@ -93,3 +93,80 @@ def test_sweep_unit_and_center():
         tol = (float(np.max(np.abs(m.values))) if m.nnz else 1.0) * (1e-6 if f4 else 1e-12)
         assert means == pytest.approx(rm, rel=rel, abs=tol)
         assert c.values == pytest.approx(cr, rel=rel, abs=tol)
+
+
+def test_sweep_multiply_reference_order():
+    "mult_ab with the reference's own column order switched on: raw arrays bit for bit the oracle's (csr/kernels/numba/multiply.py:79-97)"
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(4711)
+    K.set_spgemm_order('reference')
+    try:
+        for _ in range(100):
+            r, mid, k = (int(rng.integers(1, 101)) for _ in range(3))
+            A = _draw(rng, r, mid, values=True)
+            B = _draw(rng, mid, k, values=True)
+            ah, bh = K.to_handle(A), K.to_handle(B)
+            try:
+                ch = K.mult_ab(ah, bh)
+                C = K.from_handle(ch)
+                K.release_handle(ch)
+            finally:
+                K.release_handle(ah)
+                K.release_handle(bh)
+            _, _, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values),
+                                            (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values))
+            assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, cci)
+            # (from_coo rows hold no column twice: the sums are the sequential loop's, bit for bit)
+            assert np.array_equal(C.values.view(np.int64), np.asarray(cvs, dtype=np.float64).view(np.int64))
+    finally:
+        K.set_spgemm_order(None)
+
+
+def test_sweep_spmm_heavy_rows():
+    """
+    The dense-panel SpMM with its heavy-row form forced on (CSRK_SPMM_HEAVY=1: B tiles in LDS, accumulators in dynamically
+    indexed registers) over random shapes: 1 .. 8 row groups, panel widths around the 64-column launch and the odd / even
+    tile loads, f4 / f8 / absent values, matrices narrower than a tile and tiles cut by the matrix' width.
+    """
+    import os
+    from oracle import oracle as O
+    from csr_amd import CSR
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(90210)
+    old = {k: os.environ.get(k) for k in ('CSRK_SPMM_HEAVY', 'CSRK_SPMM_HEAVY_GROUPS')}
+    os.environ['CSRK_SPMM_HEAVY'] = '1'
+    try:
+        for it in range(40):
+            nrows = int(rng.integers(1, 2500))
+            ncols = int(rng.integers(1, 3000))
+            lens = np.minimum(rng.integers(0, 12, nrows), ncols)
+            n_long = int(rng.integers(1, max(2, min(nrows, 700))))
+            long_rows = rng.choice(nrows, min(n_long, nrows), replace=False)
+            lens[long_rows] = np.minimum(rng.integers(256, 1200, len(long_rows)), ncols)
+            rp = np.zeros(nrows + 1, np.int32)
+            rp[1:] = np.cumsum(lens)
+            ci = np.concatenate([rng.choice(ncols, int(n), replace=False) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+            kind = it % 3
+            vals = None if kind == 2 else rng.uniform(-1, 1, len(ci)).astype(np.float32 if kind == 1 else np.float64)
+            A = CSR(nrows, ncols, len(ci), rp, ci, vals, _cast=False)
+            k = int(rng.choice([1, 2, 3, 8, 31, 64, 65, 100, 129]))
+            B = rng.uniform(-1, 1, (ncols, k))
+            os.environ['CSRK_SPMM_HEAVY_GROUPS'] = str(int(rng.integers(1, 9)))
+            h = K.to_handle(A)
+            try:
+                Cm = K.mult_dense(h, B)
+            finally:
+                K.release_handle(h)
+                K.invalidate(A)
+            v64 = np.ones(len(ci)) if vals is None else vals.astype(np.float64)
+            ref = O.spmm_dense(nrows, rp, ci, v64, B)
+            bound = O.spmm_dense(nrows, rp, ci, np.abs(v64), np.abs(B))
+            assert Cm.shape == ref.shape
+            assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300), (it, nrows, ncols, k)
+    finally:
+        for k_, v_ in old.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
