@@ -83,6 +83,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
                                                                 int32_t a_nrows, const PB *__restrict__ b_rp,
                                                                 const int32_t *__restrict__ b_ci, const int32_t *__restrict__ c_rp,
                                                                 const int32_t *__restrict__ c_ci, int32_t ncols, int32_t cols_cap,
+                                                                const int32_t *__restrict__ row_list,
                                                                 unsigned long long *__restrict__ key)
 {
     extern __shared__ unsigned int so_lds[];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
     int32_t *cols = (int32_t *)so_lds;
     __shared__ int64_t s_bs[SO_BATCH];
     __shared__ int64_t s_off[SO_BATCH + 1];          // (32 rows of B can hold more than 2^31 entries between them)
-    const int32_t i = blockIdx.x;
+    const int32_t i = row_list[blockIdx.x];          // (the rows of more than SO_SHORT products)
     if (i >= a_nrows) return;
     const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
     const int64_t a0 = a_rp[i], a1 = a_rp[i + 1];
@@ -193,6 +194,62 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
     }
 }
 
+// The rows of at most SO_SHORT products -- most rows of a sparse product: a workgroup each would be sixteen wavefronts
+// to start and three barriers to pass for a handful of products (12 ms of a 14.7-ms call on a power-law 1M x 1M product).
+// SO_SUB lanes per row instead (four rows per wavefront: the walk is a chain of dependent loads -- entry of A, extent of the
+// row of B, its columns, the bisection -- and only rows in flight hide it: a wavefront per row 4.2 ms on that product):
+// A's entries one after the other, the row of B over the lanes, bisection in that row of C, the 64-bit atomic min with a
+// read as a filter.
+constexpr int SO_SHORT = 4096;
+constexpr int SO_SUB = 16;
+template <class PA, class PB>
+__global__ __launch_bounds__(256) void so_discover_short_kernel(const PA *__restrict__ a_rp, const int32_t *__restrict__ a_ci,
+                                                               int32_t a_nrows, const PB *__restrict__ b_rp,
+                                                               const int32_t *__restrict__ b_ci, const int32_t *__restrict__ c_rp,
+                                                               const int32_t *__restrict__ c_ci, const int64_t *__restrict__ tp,
+                                                               unsigned long long *__restrict__ key)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SO_SUB;
+    const int lane = threadIdx.x & (SO_SUB - 1);
+    if (i >= a_nrows || tp[i] > SO_SHORT || tp[i] == 0) return;
+    const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
+    const int32_t *crow = c_ci + c0;
+    int64_t base = 0;
+    for (int64_t e = a_rp[i]; e < (int64_t)a_rp[i + 1]; e++) {
+        const int32_t j = a_ci[e];
+        const int64_t bs = b_rp[j], len = (int64_t)b_rp[j + 1] - bs;
+        for (int64_t t = lane; t < len; t += SO_SUB) {
+            const int32_t k = b_ci[bs + t];
+            int32_t lo = 0, hi = nc;
+            while (lo < hi) {
+                const int32_t mid = lo + ((hi - lo) >> 1);
+                if (crow[mid] < k) lo = mid + 1;
+                else hi = mid;
+            }
+            const unsigned long long cand = (unsigned long long)(base + t);
+            if (key[c0 + lo] > cand) atomicMin(&key[c0 + lo], cand);
+        }
+        base += len;
+    }
+}
+
+// the rows of more than SO_SHORT products, in any order (one atomic per workgroup of 256 rows)
+__global__ __launch_bounds__(256) void so_long_rows_kernel(const int64_t *__restrict__ tp, int32_t nrows, int32_t *__restrict__ list,
+                                                          int32_t *__restrict__ count)
+{
+    __shared__ int32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is_long = r < nrows && tp[r] > SO_SHORT;
+    int32_t at = 0;
+    if (is_long) at = atomicAdd(&s_n, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
+    __syncthreads();
+    if (is_long) list[s_base + at] = (int32_t)r;
+}
+
 // g[e] = products of the rows before e's row + (products of its row - 1 - key[e]): ascending g = rows in order, inside a
 // row the reference's order (last discovered first).  *bad is raised if an entry of C was never discovered.
 __global__ void so_sortkey_kernel(const unsigned long long *__restrict__ key, const int32_t *__restrict__ row_of,
@@ -238,7 +295,7 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     const int64_t n = c->nnz;
     if (n <= 1 || c->nrows == 0 || a->nnz == 0) return CSRK_OK;
     CSRK_REQUIRE(!c->ptr64 && c->val_type == CSRK_VAL_F64, "product has an unexpected layout");
-    DevBuf key, g, tp, permA, permB, keys, flag, oci, ovs, c_row;
+    DevBuf key, g, tp, permA, permB, keys, flag, oci, ovs, c_row, long_rows, n_long_d;
     CSRK_TRY(key.alloc((size_t)n * 8));
     CSRK_TRY(g.alloc((size_t)n * 8));
     CSRK_TRY(tp.alloc((size_t)(a->nrows + 1) * 8));
@@ -247,6 +304,9 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     CSRK_TRY(keys.alloc((size_t)n * 4));
     CSRK_TRY(c_row.alloc((size_t)n * 4));
     CSRK_TRY(flag.alloc(4));
+    CSRK_TRY(long_rows.alloc((size_t)a->nrows * 4 + 4));
+    CSRK_TRY(n_long_d.alloc(4));
+    CSRK_HIP(hipMemsetAsync(n_long_d.p, 0, 4, nullptr));
     CSRK_TRY(oci.alloc((size_t)n * 4));
     CSRK_TRY(ovs.alloc((size_t)n * 8));
     CSRK_HIP(hipMemsetAsync(key.p, 0xff, (size_t)n * 8, nullptr));
@@ -270,19 +330,32 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     do {                                                                                                               \
         CSRK_HIP(hipFuncSetAttribute((const void *)so_discover_kernel<PA, PB, COLS>,                                   \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-        so_discover_kernel<PA, PB, COLS><<<(unsigned)a->nrows, SO_THREADS, lds>>>(                                     \
+        so_discover_kernel<PA, PB, COLS><<<(unsigned)n_long, SO_THREADS, lds>>>(                                       \
             (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, b->d_colinds,                  \
-            (const int32_t *)c->d_rowptrs, c->d_colinds, c->ncols, cols_cap, key.as<unsigned long long>());            \
+            (const int32_t *)c->d_rowptrs, c->d_colinds, c->ncols, cols_cap, long_rows.as<int32_t>(),                  \
+            key.as<unsigned long long>());                                                                             \
     } while (0)
 #define DISCOVER(PA, PB)                                                                                               \
     do {                                                                                                               \
         so_row_products_kernel<PA, PB><<<ga, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                  \
                                                     (const PB *)b->d_rowptrs, tp.as<int64_t>());                       \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        if (cols_mode) DISCOVER_GO(PA, PB, true);                                                                      \
-        else DISCOVER_GO(PA, PB, false);                                                                               \
+        so_long_rows_kernel<<<(unsigned)ceil_div(a->nrows, 256), 256>>>(tp.as<int64_t>(), a->nrows, long_rows.as<int32_t>(), \
+                                                                      n_long_d.as<int32_t>());                        \
         CSRK_LAUNCH_CHECK();                                                                                           \
+        so_discover_short_kernel<PA, PB><<<(unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256), 256>>>(               \
+                                                      (const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
+                                                      (const PB *)b->d_rowptrs, b->d_colinds, (const int32_t *)c->d_rowptrs, \
+                                                      c->d_colinds, tp.as<int64_t>(), key.as<unsigned long long>());   \
+        CSRK_LAUNCH_CHECK();                                                                                           \
+        CSRK_HIP(hipMemcpy(&n_long, n_long_d.p, 4, hipMemcpyDeviceToHost));                                            \
+        if (n_long > 0) {                                                                                              \
+            if (cols_mode) DISCOVER_GO(PA, PB, true);                                                                  \
+            else DISCOVER_GO(PA, PB, false);                                                                           \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+        }                                                                                                              \
     } while (0)
+    int32_t n_long = 0;
     if (a->ptr64) {
         if (b->ptr64) DISCOVER(int64_t, int64_t);
         else DISCOVER(int64_t, int32_t);
