@@ -336,8 +336,8 @@ def main():
             check(lib.csrk_spmv_profile_end4(hp, C.byref(n_w), k_w))
             k_warm, n_warm = [float(v) for v in k_w], n_w.value
             if n_warm > 0 and max(k_warm) > 0:
-                stb = (C.c_int64 * 29)()
-                check(lib.csrk_spmv_plan_stats(hp, stb, 29))
+                stb = (C.c_int64 * 34)()
+                check(lib.csrk_spmv_plan_stats(hp, stb, 34))
                 cands = [c for c in range(4) if not (c == 2 and int(stb[28]))]      # (tier 1 beside tier 0: see `dom` below)
                 chan_mask = 1 << max(cands, key=lambda c: k_warm[c])
         if events:
@@ -393,8 +393,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-    st = (C.c_int64 * 29)()
-    check(lib.csrk_spmv_plan_stats(hp, st, 29))
+    st = (C.c_int64 * 34)()
+    check(lib.csrk_spmv_plan_stats(hp, st, 34))
     if op_handles:
         # the roofline block describes the first chunk's handle (the kernels that were timed)
         i_r, i_c, i_n, i_p, i_v = C.c_int32(0), C.c_int32(0), C.c_int64(0), C.c_int(0), C.c_int(0)
@@ -517,6 +517,11 @@ def main():
         # three tiers, cold-staging lists, tables)
         'matrix_bytes': nnz_loc * 12 + (n_loc + 1) * rp.element_size(), 'plan_bytes': int(st[25]),
         'plan_over_matrix': round(int(st[25]) / max(1, nnz_loc * 12 + (n_loc + 1) * rp.element_size()), 3),
+        # where the plan's bytes are: the private streams re-state the matrix almost 1 : 1 -- tier 0 in 10 B
+        # per entry, tier 1 and the light stream in 12 -- because the kernels read THEM, never the CSR arrays, after the
+        # first product; the arrays stay for export, the other operations and plan-less algorithms
+        'plan_bytes_by_part': {'tier0_accumulator_stream': int(st[29]), 'tier1_pair_panel': int(st[30]), 'light_stream': int(st[31]),
+                               'cold_staging_and_pack': int(st[32]), 'tables': int(st[33])},
     }
     if compute_ms is not None:
         # per step: the slowest rank's local SpMV (device events) and what the exchange adds on top

@@ -51,29 +51,30 @@ __device__ __forceinline__ double spmv_prod(double a, double x)
 void free_spmv_plan(SpmvPlan *p) { delete p; }
 
 // device memory the plan holds (private streams, tables, scratch)
+// by part: [0] tier 0 (accumulator stream, segment tables, partials), [1] tier 1 (pair panel, tiles, partials), [2] the light
+// stream (values, index words, run tables), [3] cold staging (copy list, staged values, round tables) and the pack,
+// [4] everything else (merge-path tables, the cut view, vector segments)
+void spmv_plan_bytes_by_part(const SpmvPlan *p, int64_t out[5])
+{
+    for (int i = 0; i < 5; i++) out[i] = 0;
+    auto add = [&](int part, std::initializer_list<const DevBuf *> bufs) {
+        for (const DevBuf *b : bufs) out[part] += (int64_t)b->bytes;
+    };
+    for (const AccPanel *ap : p->acc) add(0, {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial});
+    const Panel &t = p->tier1;
+    add(1, {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx});
+    const LightStream *l = &p->ls;
+    add(2, {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_row, &l->carry_val});
+    add(3, {&l->xg, &l->a_col, &l->a_dst, &l->blk_start, &l->round_start, &l->round_tile0, &l->wg_round0, &p->hot_slot, &p->hot_cols, &p->xh});
+    add(4, {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut, &p->heavy_row, &p->seg_off,
+            &p->seg_row, &p->seg_part});
+}
+
 int64_t spmv_plan_bytes(const SpmvPlan *p)
 {
-    int64_t plan_bytes = 0;
-    {
-        auto add = [&](const DevBuf &b) { plan_bytes += (int64_t)b.bytes; };
-        for (const DevBuf *b : {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut,
-                                &p->heavy_row, &p->hot_slot, &p->hot_cols, &p->xh, &p->seg_off, &p->seg_row, &p->seg_part})
-            add(*b);
-        {
-            const Panel &t = p->tier1;
-            for (const DevBuf *b : {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx})
-                add(*b);
-        }
-        for (const AccPanel *ap : p->acc)
-            for (const DevBuf *b : {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial}) add(*b);
-        {
-            const LightStream *l = &p->ls;
-            for (const DevBuf *b : {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_row, &l->carry_val, &l->xg, &l->a_col,
-                                    &l->a_dst, &l->blk_start, &l->round_start, &l->round_tile0, &l->wg_round0})
-                add(*b);
-        }
-    }
-    return plan_bytes;
+    int64_t part[5];
+    spmv_plan_bytes_by_part(p, part);
+    return part[0] + part[1] + part[2] + part[3] + part[4];
 }
 
 
@@ -1707,8 +1708,11 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
     }
     const bool af = !p->acc.empty();
     const int64_t plan_bytes = spmv_plan_bytes(p);      // [25]
-    // [26] tiles per staging round (0: nothing staged); [27] workgroups of the accumulator kernel; [28] 0 (was: tier 1 on a side stream)
-    const int64_t v[29] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
+    // [26] tiles per staging round (0: nothing staged); [27] workgroups of the accumulator kernel; [28] 0 (was: tier 1 on a side
+    // stream); [29..33] the plan's bytes by part (spmv_plan_bytes_by_part: tier 0, tier 1, light stream, staging + pack, rest)
+    int64_t part[5];
+    spmv_plan_bytes_by_part(p, part);
+    const int64_t v[34] = {p->algo == CSRK_SPMV_MERGE ? p->n_tiles : p->n_segs,
                            p->algo == CSRK_SPMV_MERGE ? p->tile_items : VEC_SEG,
                            p->n_heavy, p->algo == CSRK_SPMV_MERGE ? p->nnz_light : m->nnz,
                            a_tiles, a_nb, p->heavy_min, af ? ACC_CB : 0, p->n_heavy ? 2 : 0, a_rows, a_nnz,
@@ -1716,8 +1720,8 @@ int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n)
                            p->n_hot, (int64_t)(p->hot_cover * 1e6), af ? 1 : 0, p->hot_slots,
                            p->ls.on ? 1 : 0, p->ls.n_tiles, p->ls.n_runs, p->ls.grid, p->ls.n_cold, plan_bytes,
                            p->ls.round_start.p ? p->ls.stage_tiles : 0,
-                           af ? (int64_t)p->acc[0]->n_wg : 0, 0};
-    for (int i = 0; i < n && i < 29; i++) out[i] = v[i];
+                           af ? (int64_t)p->acc[0]->n_wg : 0, 0, part[0], part[1], part[2], part[3], part[4]};
+    for (int i = 0; i < n && i < 34; i++) out[i] = v[i];
     return CSRK_OK;
 }
 

@@ -141,15 +141,15 @@ CSRK_API int csrk_spmv_plan_info(csrk_handle_t h, int64_t *n_tiles, int32_t *til
 
 /* out[0..n) <- {0 tiles (or segments), 1 items per tile, 2 rows cut out of the tile path, 3 entries on
  * the tile path, 4 tier-0 tiles, 5 tier-0 column blocks, 6 tier-0 row threshold, 7 tier-0 block width,
- * 8 split mode (0 none, 2 panels), 9 tier-0 (block,row) pairs (pair form) or rows (accumulator form),
+ * 8 split mode (0 none, 2 panels), 9 tier-0 rows,
  * 10 tier-0 entries, 11 tier-1 rows, 12 tier-1 pairs, 13 tier-1 entries, 14 tier-1 row threshold,
  * 15 tier-1 block width, 16 columns in the hot-column pack (0: none), 17 sampled share of the row-major
- * path's entries on packed columns (ppm), 18 tier-0 form (0 pairs, 1 accumulator), 19 pack slots,
+ * path's entries on packed columns (ppm), 18 1 (tier 0 in accumulator form: the only one), 19 pack slots,
  * 20 short rows on the light stream (1) or on the merge-path tile kernel (0), 21 light-stream tiles,
  * 22 non-empty rows of the light stream, 23 its workgroups, 24 light-stream entries whose x values are staged
  * per call (cold staging), 25 bytes of device memory the plan holds, 26 tiles per staging round held in LDS (0: none),
- * 27 workgroups of the tier-0 accumulator kernel, 28 tier 1's kernel runs beside it on a side stream (1) or after it (0)};
- * n <= 29. */
+ * 27 workgroups of the tier-0 accumulator kernel, 28 0 (reserved), 29..33 the plan's bytes by part: tier 0's accumulator
+ * stream, tier 1's pair panel, the light stream, cold staging + pack, tables};  n <= 34. */
 CSRK_API int csrk_spmv_plan_stats(csrk_handle_t h, int64_t *out, int n);
 
 /* Kernel timing for roofline accounting: between begin and end every csrk_spmv_device call on
