@@ -877,6 +877,42 @@ def test_spmm_dense_heavy_rows_blocked(k, monkeypatch):
     assert np.all(np.abs(Cm - ref) <= 1e-12 * bound + 1e-300)
 
 
+@pytest.mark.parametrize('k,ldb,ldc', [(64, 64, 64), (64, 70, 67), (37, 41, 64), (130, 131, 140)])
+def test_spmm_dense_strided_panels(k, ldb, ldc, monkeypatch):
+    "csrk_spmm_dense_device with leading dimensions wider than the panel (B and C as column slices of wider arrays), heavy rows forced"
+    import ctypes as C
+    import torch
+    from oracle import oracle as O
+    from csr_amd._lib import lib, check, handle_t
+    monkeypatch.setenv('CSRK_SPMM_HEAVY', '1')
+    rng = np.random.default_rng(k * 1000 + ldb)
+    nrows, ncols = 1500, 5000
+    lens = rng.integers(0, 9, size=nrows)
+    lens[rng.choice(nrows, 300, replace=False)] = rng.integers(256, 900, size=300)
+    A = _rand(rng, nrows, ncols, lens, sort=True)
+    Bw = rng.uniform(-1, 1, (ncols, ldb))
+    dev = 'cuda'
+    rp, ci, vs = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (A.rowptrs, A.colinds, A.values))
+    dB = torch.from_numpy(Bw).to(dev)
+    dC = torch.full((nrows, ldc), 7.0, dtype=torch.float64, device=dev)
+    h = handle_t(0)
+    check(lib.csrk_create_device(nrows, ncols, A.nnz, rp.data_ptr(), 0, ci.data_ptr(), vs.data_ptr(), 2, C.byref(h)))
+    try:
+        check(lib.csrk_spmm_dense_device(h, dB.data_ptr(), k, ldb, dC.data_ptr(), ldc, None))
+        torch.cuda.synchronize()
+        st = (C.c_int64 * 9)()
+        check(lib.csrk_spmm_plan_stats(h, st, 9))
+        assert st[0] == 1 and st[2] >= 300                 # the heavy-row form is in use
+    finally:
+        check(lib.csrk_free(h))
+    got = dC.cpu().numpy()
+    B = np.ascontiguousarray(Bw[:, :k])
+    ref = O.spmm_dense(nrows, A.rowptrs, A.colinds, A.values, B)
+    bound = O.spmm_dense(nrows, A.rowptrs, A.colinds, np.abs(A.values), np.abs(B))
+    assert np.all(np.abs(got[:, :k] - ref) <= 1e-12 * bound + 1e-300)
+    assert np.all(got[:, k:] == 7.0)                       # nothing is written past the panel's width
+
+
 def test_spmm_survives_spmv_algo_change(monkeypatch):
     "the SpMM plan is independent of the SpMV plan: changing the SpMV algorithm between products changes nothing"
     from oracle import oracle as O
