@@ -336,10 +336,7 @@ def main():
             check(lib.csrk_spmv_profile_end4(hp, C.byref(n_w), k_w))
             k_warm, n_warm = [float(v) for v in k_w], n_w.value
             if n_warm > 0 and max(k_warm) > 0:
-                stb = (C.c_int64 * 34)()
-                check(lib.csrk_spmv_plan_stats(hp, stb, 34))
-                cands = [c for c in range(4) if not (c == 2 and int(stb[28]))]      # (tier 1 beside tier 0: see `dom` below)
-                chan_mask = 1 << max(cands, key=lambda c: k_warm[c])
+                chan_mask = 1 << max(range(4), key=lambda c: k_warm[c])      # the slowest kernel is the one bracketed in the timed region
         if events:
             every = 10 if args.steps >= 20 else (5 if args.steps >= 10 else 1)
             check(lib.csrk_spmv_profile_channels(hp, chan_mask))
