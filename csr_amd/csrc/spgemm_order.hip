@@ -9,9 +9,10 @@
 //
 //   1. key[e] for every entry e = (i, k) of C: the index, in the reference's walk of row i's products, of the first
 //      product that lands on it -- the product that discovers k (so_discover_kernel).
-//   2. entries sorted by (row, key descending): the two are folded into one number below the product count of A B
-//      (so_sortkey_kernel), and an index permutation is radix-sorted by its 30-bit digits (transpose.hip's passes: one
-//      sort for up to 10^9 products), then one gather of columns and values.
+//   2. every entry's place from its key, without a sort: the keys of a row are distinct numbers below the row's product
+//      count, so a bitmap over product indices (in LDS, a window of 2^19 at a time) with a running population count gives
+//      each key its rank among the row's keys -- a counting sort that never moves a key -- and the entry (column, value)
+//      goes straight to row end - 1 - rank (so_place_kernel; so_place_short_kernel for the rows of few products).
 //
 // Values are not touched: each keeps the bits the product kernels gave it.  tests/test_gpu_ops.py compares the result
 // with the reference's own raw arrays (tests/golden/spgemm.npz, c*_raw_*) bit for bit.
@@ -22,9 +23,6 @@
 
 namespace csrk {
 
-int stable_sort_payload_by_key(const int32_t *keys, const int32_t *payload, int64_t n, int32_t key_range,
-                               int64_t payload_range, int32_t *out_payload, hipStream_t s);      // transpose.hip
-
 static std::atomic<int> g_spgemm_order{-1};      // -1: follow CSRK_SPGEMM_ORDER; 0 ascending; 1 reference
 
 bool spgemm_reference_order_wanted()
@@ -33,17 +31,6 @@ bool spgemm_reference_order_wanted()
     if (o >= 0) return o == 1;
     const char *e = getenv("CSRK_SPGEMM_ORDER");
     return e && (e[0] == 'r' || e[0] == 'R' || e[0] == '1');
-}
-
-// row of every entry of a CSR (one wavefront per row writes its extent)
-template <class P>
-__global__ void so_row_of_kernel(const P *__restrict__ rp, int32_t nrows, int32_t *__restrict__ row_of)
-{
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    if (w >= nrows) return;
-    const int64_t s = rp[w], e = rp[w + 1];
-    for (int64_t k = s + lane; k < e; k += WAVE) row_of[k] = (int32_t)w;
 }
 
 // products of every row of A B: tp[i] = sum over the entries (i, j) of A of |B_j| (one wavefront per row)
@@ -67,11 +54,13 @@ __global__ __launch_bounds__(256) void so_row_products_kernel(const PA *__restri
 // order: multiply.py:69-83), of the FIRST product that lands on entry e of C -- the product that discovers its column.
 // One workgroup per row of A walks that row's products IN ORDER, SO_BATCH entries of A at a time, their products
 // flattened over the threads (a 20 000-entry row of B next to fifteen short ones costs every thread the same).
-//   COLS (the product has few enough columns for 6.25 B of LDS each): a bit per COLUMN of C says "discovered by an earlier
-//   batch" -- such a product, nearly all of them, ends at the bit test; the others mark their column in the batch's own
-//   bitmap and take an LDS atomic min of their index inside the batch (an integer minimum: any order gives the same
-//   result).  After the batch the marked columns are final: each is discovered exactly once, so its key is a plain store
-//   (the entry of C through a column -> position map built at the start of the row), no atomic on memory at all.
+//   COLS (the product has few enough columns for 6.125 B of LDS each): a bit per COLUMN of C says "discovered by an earlier
+//   batch" -- such a product, nearly all of them, ends at the bit test; the others take an LDS atomic min of their index
+//   inside the batch (an integer minimum: any order gives the same result; a read first, so that a column's later products
+//   in the batch skip the atomic).  After the batch the columns with a minimum and no bit are final: each is discovered
+//   exactly once, so its key is a plain store (the entry of C through a column -> position map built at the start of the
+//   row), no atomic on memory at all.  The walk stops when every entry of the row has its key: a long row of a dense product
+//   (the rows the kernel's time hangs on) has found all its columns 40 % of the way.
 //   otherwise: every product finds its entry of C by bisection (that row of C's columns, in LDS when they fit) and sends
 //   its index to a 64-bit atomic min on memory, with a read of the key as a filter.
 constexpr int SO_THREADS = 1024;
@@ -87,13 +76,14 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
                                                                 unsigned long long *__restrict__ key)
 {
     extern __shared__ unsigned int so_lds[];
-    // COLS: [seen: words][fresh: words][mn: ncols u32][pos: ncols u16]; else [cols: cols_cap int32]
+    // COLS: [seen: words][mn: ncols u32][pos: ncols u16]; else [cols: cols_cap int32]
     const int32_t words = COLS ? (ncols + 31) / 32 : 0;
-    unsigned int *seen = so_lds, *fresh = seen + words, *mn = fresh + words;
+    unsigned int *seen = so_lds, *mn = seen + words;
     unsigned short *pos = (unsigned short *)(mn + (COLS ? ncols : 0));
     int32_t *cols = (int32_t *)so_lds;
     __shared__ int64_t s_bs[SO_BATCH];
     __shared__ int64_t s_off[SO_BATCH + 1];          // (32 rows of B can hold more than 2^31 entries between them)
+    __shared__ int32_t s_found;                      // COLS: entries of the row that have their key
     const int32_t i = row_list[blockIdx.x];          // (the rows of more than SO_SHORT products)
     if (i >= a_nrows) return;
     const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
@@ -103,7 +93,8 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
     const int32_t *crow = c_ci + c0;
     const bool in_lds = !COLS && nc <= cols_cap;
     if (COLS) {
-        for (int32_t q = tid; q < 2 * words; q += SO_THREADS) seen[q] = 0u;      // (both bitmaps)
+        if (tid == 0) s_found = 0;
+        for (int32_t q = tid; q < words; q += SO_THREADS) seen[q] = q * 32 + 32 <= ncols ? 0u : ~0u << (ncols & 31);   // (no column past the last)
         for (int32_t q = tid; q < ncols; q += SO_THREADS) mn[q] = 0xffffffffu;
         for (int32_t q = tid; q < nc; q += SO_THREADS) pos[crow[q]] = (unsigned short)q;
     } else if (in_lds) {
@@ -153,8 +144,7 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
                 const int32_t k = kk[u];
                 if (COLS) {
                     if ((seen[k >> 5] >> (k & 31)) & 1u) continue;
-                    atomicOr(&fresh[k >> 5], 1u << (k & 31));
-                    atomicMin(&mn[k], (unsigned int)pidx);      // (a batch holds fewer than 2^32 products: checked by the host)
+                    if (mn[k] > (unsigned int)pidx) atomicMin(&mn[k], (unsigned int)pidx);      // (a batch holds fewer than 2^32 products: checked by the host)
                     continue;
                 }
                 int32_t lo = 0, hi = nc;             // first position with column >= k
@@ -177,20 +167,27 @@ __global__ __launch_bounds__(SO_THREADS) void so_discover_kernel(const PA *__res
         }
         if (COLS) {
             __syncthreads();
+            int32_t found = 0;
             for (int32_t w = tid; w < words; w += SO_THREADS) {      // the batch's discoveries are final
-                unsigned int f = fresh[w];
-                if (!f) continue;
-                seen[w] |= f;
-                fresh[w] = 0u;
-                while (f) {
-                    const int32_t k = 32 * w + __builtin_ctz(f);
-                    f &= f - 1;
-                    key[c0 + pos[k]] = (unsigned long long)(base + (int64_t)mn[k]);
+                unsigned int open = ~seen[w], f = 0u;
+                while (open) {
+                    const int b = __builtin_ctz(open);
+                    open &= open - 1;
+                    const unsigned int m = mn[32 * w + b];
+                    if (m == 0xffffffffu) continue;
+                    f |= 1u << b;
+                    key[c0 + pos[32 * w + b]] = (unsigned long long)(base + (int64_t)m);
+                }
+                if (f) {
+                    seen[w] |= f;
+                    found += __popc(f);
                 }
             }
+            if (found) atomicAdd(&s_found, found);
         }
         base += total;
         __syncthreads();
+        if (COLS && s_found == nc) break;            // (every thread reads it after the barrier, and the next write is two barriers on)
     }
 }
 
@@ -233,60 +230,167 @@ __global__ __launch_bounds__(256) void so_discover_short_kernel(const PA *__rest
     }
 }
 
-// the rows of more than SO_SHORT products, in any order (one atomic per workgroup of 256 rows)
-__global__ __launch_bounds__(256) void so_long_rows_kernel(const int64_t *__restrict__ tp, int32_t nrows, int32_t *__restrict__ list,
-                                                          int32_t *__restrict__ count)
+// The rows of more than SO_SHORT products, longest first: the workgroup kernels take a row each, and a 1.2 M-product row
+// started late is the kernel's whole tail (rows by the octave of their product count: `fill` false counts the octaves,
+// true places the rows behind the cursors the host made of the counts; inside an octave any order).
+constexpr int SO_OCTAVES = 64;
+__global__ __launch_bounds__(256) void so_long_rows_kernel(const int64_t *__restrict__ tp, int32_t nrows, bool fill,
+                                                          int32_t *__restrict__ cursor, int32_t *__restrict__ list)
 {
-    __shared__ int32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ int32_t s_n[SO_OCTAVES], s_base[SO_OCTAVES];
+    if (threadIdx.x < SO_OCTAVES) s_n[threadIdx.x] = 0;
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool is_long = r < nrows && tp[r] > SO_SHORT;
+    const int oct = is_long ? __clzll((long long)tp[r]) : 0;      // (longest rows: smallest count of leading zeros)
     int32_t at = 0;
-    if (is_long) at = atomicAdd(&s_n, 1);
+    if (is_long) at = atomicAdd(&s_n[oct], 1);
     __syncthreads();
-    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
+    if (threadIdx.x < SO_OCTAVES && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_n[threadIdx.x]);
+    if (!fill) return;
     __syncthreads();
-    if (is_long) list[s_base + at] = (int32_t)r;
+    if (is_long) list[s_base[oct] + at] = (int32_t)r;
 }
 
-// g[e] = products of the rows before e's row + (products of its row - 1 - key[e]): ascending g = rows in order, inside a
-// row the reference's order (last discovered first).  *bad is raised if an entry of C was never discovered.
-__global__ void so_sortkey_kernel(const unsigned long long *__restrict__ key, const int32_t *__restrict__ row_of,
-                                  const int64_t *__restrict__ pbase, int64_t n, unsigned long long *__restrict__ g,
-                                  unsigned int *__restrict__ bad)
+// Every entry's place from its key.  The keys of row i are distinct numbers in [0, tp[i]): one bit per product index in LDS,
+// SO_WIN of them at a time, each word's population count before it, and a key's rank among the row's keys is the count of
+// bits below its own.  The entry goes to row end - 1 - rank: the reference's order (last discovered first).  One workgroup
+// per listed row.  *bad is raised by a key outside the row's products (an entry never discovered) or two equal keys.
+constexpr int SO_WIN_WORDS = 16384;          // 2^19 product indices per window: 64 KB of bits + 64 KB of counts
+constexpr int SO_WIN = SO_WIN_WORDS * 32;
+constexpr int SO_OWN = SO_WIN_WORDS / SO_THREADS;      // words a thread counts
+__global__ __launch_bounds__(SO_THREADS) void so_place_kernel(const int32_t *__restrict__ c_rp, const int32_t *__restrict__ c_ci,
+                                                             const double *__restrict__ c_vs, const int64_t *__restrict__ tp,
+                                                             const int32_t *__restrict__ row_list,
+                                                             const unsigned long long *__restrict__ key,
+                                                             int32_t *__restrict__ oci, double *__restrict__ ovs,
+                                                             unsigned int *__restrict__ bad)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const unsigned long long k = key[e];
-    const int32_t r = row_of[e];
-    const int64_t t = pbase[r + 1] - pbase[r];
-    if (k == ~0ull || (int64_t)k >= t) {
-        atomicMax(bad, 1u);
-        g[e] = 0;
+    extern __shared__ unsigned int so_lds[];
+    unsigned int *bits = so_lds, *before = so_lds + SO_WIN_WORDS;
+    __shared__ int32_t s_wave[SO_THREADS / WAVE];
+    const int32_t i = row_list[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
+    const int64_t t = tp[i];
+    int32_t base = 0;                                // keys below the window
+    for (int64_t w0 = 0; w0 < t; w0 += SO_WIN) {
+        const int32_t used = (int32_t)(((t - w0 < SO_WIN ? t - w0 : (int64_t)SO_WIN) + 31) / 32);
+        for (int32_t w = tid; w < used; w += SO_THREADS) bits[w] = 0u;
+        __syncthreads();
+        for (int32_t q = tid; q < nc; q += SO_THREADS) {
+            const unsigned long long k = key[c0 + q];
+            if (k >= (unsigned long long)t) {
+                if (w0 == 0) atomicMax(bad, 1u);
+                continue;
+            }
+            if (k - (unsigned long long)w0 < (unsigned long long)SO_WIN) atomicOr(&bits[(k - w0) >> 5], 1u << ((k - w0) & 31));
+        }
+        __syncthreads();
+        // counts: a thread's SO_OWN consecutive words, then the threads of a wavefront, then the wavefronts
+        int32_t mine = 0;
+        const int32_t w_first = tid * SO_OWN;
+#pragma unroll
+        for (int u = 0; u < SO_OWN; u++)
+            if (w_first + u < used) mine += __popc(bits[w_first + u]);
+        int32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) s_wave[wv] = inc;
+        __syncthreads();
+        int32_t run = base + inc - mine;
+        int32_t all = 0;
+#pragma unroll
+        for (int v = 0; v < SO_THREADS / WAVE; v++) {
+            if (v < wv) run += s_wave[v];
+            all += s_wave[v];
+        }
+#pragma unroll
+        for (int u = 0; u < SO_OWN; u++)
+            if (w_first + u < used) {
+                before[w_first + u] = (unsigned int)run;
+                run += __popc(bits[w_first + u]);
+            }
+        __syncthreads();
+        for (int32_t q = tid; q < nc; q += SO_THREADS) {
+            const unsigned long long k = key[c0 + q];
+            if (k >= (unsigned long long)t || k - (unsigned long long)w0 >= (unsigned long long)SO_WIN) continue;
+            const unsigned int d = (unsigned int)(k - w0);
+            const int32_t rank = (int32_t)before[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
+            const int64_t to = (int64_t)c0 + (nc - 1 - rank);
+            oci[to] = c_ci[c0 + q];
+            ovs[to] = c_vs[c0 + q];
+        }
+        base += all;
+        __syncthreads();                             // (s_wave and the bitmap are written again)
+    }
+    if (tid == 0 && base != nc) atomicMax(bad, 1u);
+}
+
+// the rows of at most SO_SHORT products (and the rows of none: nothing to place): SO_SUB lanes per row, the whole bitmap of
+// a row (128 words at most) and its counts in the group's own kilobyte of LDS, no barrier -- a group's lanes are lanes of
+// one wavefront, whose LDS operations complete in program order
+__global__ __launch_bounds__(256) void so_place_short_kernel(const int32_t *__restrict__ c_rp, const int32_t *__restrict__ c_ci,
+                                                            const double *__restrict__ c_vs, const int64_t *__restrict__ tp,
+                                                            int32_t nrows, const unsigned long long *__restrict__ key,
+                                                            int32_t *__restrict__ oci, double *__restrict__ ovs,
+                                                            unsigned int *__restrict__ bad)
+{
+    constexpr int WORDS = SO_SHORT / 32, OWN = WORDS / SO_SUB;
+    __shared__ unsigned int s_bits[256 / SO_SUB][WORDS], s_before[256 / SO_SUB][WORDS];
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SO_SUB;
+    const int lane = threadIdx.x & (SO_SUB - 1), grp = threadIdx.x / SO_SUB;
+    if (i >= nrows) return;
+    const int64_t t = tp[i];
+    if (t > SO_SHORT) return;
+    const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
+    if (nc == 0) return;
+    unsigned int *bits = s_bits[grp], *before = s_before[grp];
+    const int32_t used = (int32_t)((t + 31) / 32);
+    for (int32_t w = lane; w < used; w += SO_SUB) bits[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int32_t q = lane; q < nc; q += SO_SUB) {
+        const unsigned long long k = key[c0 + q];
+        if (k >= (unsigned long long)t) {
+            atomicMax(bad, 1u);
+            continue;
+        }
+        atomicOr(&bits[k >> 5], 1u << (k & 31));
+    }
+    __builtin_amdgcn_wave_barrier();
+    int32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < OWN; u++)
+        if (lane * OWN + u < used) mine += __popc(bits[lane * OWN + u]);
+    int32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < SO_SUB; off <<= 1) {
+        const int32_t o = __shfl_up(inc, off, SO_SUB);
+        if (lane >= off) inc += o;
+    }
+    const int32_t all = __shfl(inc, SO_SUB - 1, SO_SUB);
+    int32_t run = inc - mine;
+#pragma unroll
+    for (int u = 0; u < OWN; u++)
+        if (lane * OWN + u < used) {
+            before[lane * OWN + u] = (unsigned int)run;
+            run += __popc(bits[lane * OWN + u]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (all != nc) {                                 // (two equal keys, or a key out of range)
+        if (lane == 0) atomicMax(bad, 1u);
         return;
     }
-    g[e] = (unsigned long long)(pbase[r] + (t - 1 - (int64_t)k));
-}
-
-// keys[q] = 30-bit digit `d` of g[perm[q]] (perm == nullptr: the identity); ident (optional) receives the identity
-__global__ void so_digit_kernel(const unsigned long long *__restrict__ g, const int32_t *__restrict__ perm, int64_t n, int d,
-                                int32_t *__restrict__ keys, int32_t *__restrict__ ident)
-{
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    keys[q] = (int32_t)((g[perm ? perm[q] : q] >> (30 * d)) & 0x3fffffffull);
-    if (ident) ident[q] = (int32_t)q;
-}
-
-__global__ void so_apply_kernel(const int32_t *__restrict__ perm, int64_t n, const int32_t *__restrict__ ci,
-                                const double *__restrict__ vs, int32_t *__restrict__ oci, double *__restrict__ ovs)
-{
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const int32_t e = perm[q];
-    oci[q] = ci[e];
-    ovs[q] = vs[e];
+    for (int32_t q = lane; q < nc; q += SO_SUB) {
+        const unsigned int d = (unsigned int)key[c0 + q];
+        const int32_t rank = (int32_t)before[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
+        const int64_t to = (int64_t)c0 + (nc - 1 - rank);
+        oci[to] = c_ci[c0 + q];
+        ovs[to] = c_vs[c0 + q];
+    }
 }
 
 // c = a b as the product kernels left it (ascending columns, int32 row pointers, float64 values): re-ordered in place
@@ -295,37 +399,35 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     const int64_t n = c->nnz;
     if (n <= 1 || c->nrows == 0 || a->nnz == 0) return CSRK_OK;
     CSRK_REQUIRE(!c->ptr64 && c->val_type == CSRK_VAL_F64, "product has an unexpected layout");
-    DevBuf key, g, tp, permA, permB, keys, flag, oci, ovs, c_row, long_rows, n_long_d;
+    DevBuf key, tp, flag, oci, ovs, long_rows, cursor;
     CSRK_TRY(key.alloc((size_t)n * 8));
-    CSRK_TRY(g.alloc((size_t)n * 8));
     CSRK_TRY(tp.alloc((size_t)(a->nrows + 1) * 8));
-    CSRK_TRY(permA.alloc((size_t)n * 4));
-    CSRK_TRY(permB.alloc((size_t)n * 4));
-    CSRK_TRY(keys.alloc((size_t)n * 4));
-    CSRK_TRY(c_row.alloc((size_t)n * 4));
     CSRK_TRY(flag.alloc(4));
     CSRK_TRY(long_rows.alloc((size_t)a->nrows * 4 + 4));
-    CSRK_TRY(n_long_d.alloc(4));
-    CSRK_HIP(hipMemsetAsync(n_long_d.p, 0, 4, nullptr));
+    CSRK_TRY(cursor.alloc(SO_OCTAVES * 4));
     CSRK_TRY(oci.alloc((size_t)n * 4));
     CSRK_TRY(ovs.alloc((size_t)n * 8));
+    CSRK_HIP(hipMemsetAsync(cursor.p, 0, SO_OCTAVES * 4, nullptr));
     CSRK_HIP(hipMemsetAsync(key.p, 0xff, (size_t)n * 8, nullptr));
     CSRK_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
-    so_row_of_kernel<int32_t><<<(unsigned)ceil_div((int64_t)c->nrows * WAVE, 256), 256>>>((const int32_t *)c->d_rowptrs, c->nrows,
-                                                                                         c_row.as<int32_t>());
-    CSRK_LAUNCH_CHECK();
-    // LDS of the discovery kernel (the device's own limit decides).  By column -- 6.25 B per column of C -- when that fits,
+    // LDS of the discovery kernel (the device's own limit decides).  By column -- 6.125 B per column of C -- when that fits,
     // every row of C has fewer than 65536 entries (16-bit positions; a row has at most ncols) and no 32 rows of B hold 2^32
     // entries between them (32-bit indices inside a batch); else that row of C's columns, as many as fit.
     int lds_max = 0, dev = 0;
     CSRK_HIP(hipGetDevice(&dev));
     CSRK_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
     const int64_t budget = std::min<int64_t>(SO_LDS_BYTES, (int64_t)lds_max - 1024);
-    const int64_t by_col = ((int64_t)c->ncols + 31) / 32 * 8 + (int64_t)c->ncols * 6 + 64;
+    const int64_t by_col = ((int64_t)c->ncols + 31) / 32 * 4 + (int64_t)c->ncols * 6 + 64;
     const bool cols_mode = c->ncols < 65536 && by_col <= budget && b->nnz < (1ll << 32) / SO_BATCH;
     const int32_t cols_cap = cols_mode ? 0 : (int32_t)std::max<int64_t>(0, budget / 4);
     const size_t lds = cols_mode ? (size_t)by_col : (size_t)cols_cap * 4;
+    const size_t lds_place = (size_t)SO_WIN_WORDS * 8;
+    CSRK_REQUIRE((int64_t)lds_place + 1024 <= lds_max, "device has too little LDS for the ordering pass");
     const unsigned ga = (unsigned)ceil_div((int64_t)a->nrows * WAVE, 256);
+    const unsigned gr = (unsigned)ceil_div(a->nrows, 256);
+    const unsigned gs = (unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256);
+    int32_t n_long = 0;
+    int32_t octaves[SO_OCTAVES];
 #define DISCOVER_GO(PA, PB, COLS)                                                                                      \
     do {                                                                                                               \
         CSRK_HIP(hipFuncSetAttribute((const void *)so_discover_kernel<PA, PB, COLS>,                                   \
@@ -340,22 +442,28 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
         so_row_products_kernel<PA, PB><<<ga, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                  \
                                                     (const PB *)b->d_rowptrs, tp.as<int64_t>());                       \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        so_long_rows_kernel<<<(unsigned)ceil_div(a->nrows, 256), 256>>>(tp.as<int64_t>(), a->nrows, long_rows.as<int32_t>(), \
-                                                                      n_long_d.as<int32_t>());                        \
+        so_long_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, false, cursor.as<int32_t>(), nullptr);            \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        so_discover_short_kernel<PA, PB><<<(unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256), 256>>>(               \
-                                                      (const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
+        so_discover_short_kernel<PA, PB><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
                                                       (const PB *)b->d_rowptrs, b->d_colinds, (const int32_t *)c->d_rowptrs, \
                                                       c->d_colinds, tp.as<int64_t>(), key.as<unsigned long long>());   \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        CSRK_HIP(hipMemcpy(&n_long, n_long_d.p, 4, hipMemcpyDeviceToHost));                                            \
+        CSRK_HIP(hipMemcpy(octaves, cursor.p, sizeof octaves, hipMemcpyDeviceToHost));                                 \
+        for (int o = 0; o < SO_OCTAVES; o++) {                                                                         \
+            const int32_t cnt = octaves[o];                                                                            \
+            octaves[o] = n_long;                                                                                       \
+            n_long += cnt;                                                                                             \
+        }                                                                                                              \
         if (n_long > 0) {                                                                                              \
+            CSRK_HIP(hipMemcpyAsync(cursor.p, octaves, sizeof octaves, hipMemcpyHostToDevice, nullptr));               \
+            so_long_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, true, cursor.as<int32_t>(),                   \
+                                             long_rows.as<int32_t>());                                                 \
+            CSRK_LAUNCH_CHECK();                                                                                       \
             if (cols_mode) DISCOVER_GO(PA, PB, true);                                                                  \
             else DISCOVER_GO(PA, PB, false);                                                                           \
             CSRK_LAUNCH_CHECK();                                                                                       \
         }                                                                                                              \
     } while (0)
-    int32_t n_long = 0;
     if (a->ptr64) {
         if (b->ptr64) DISCOVER(int64_t, int64_t);
         else DISCOVER(int64_t, int32_t);
@@ -365,33 +473,22 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     }
 #undef DISCOVER
 #undef DISCOVER_GO
-    CSRK_TRY(exclusive_scan_i64(tp.as<int64_t>(), tp.as<int64_t>(), a->nrows, nullptr));
-    const unsigned gn = (unsigned)ceil_div(n, 256);
-    so_sortkey_kernel<<<gn, 256>>>(key.as<unsigned long long>(), c_row.as<int32_t>(), tp.as<int64_t>(), n,
-                                   g.as<unsigned long long>(), flag.as<unsigned int>());
+    // every entry to its place (rows of no entries or no products: nothing to move)
+    so_place_short_kernel<<<gs, 256>>>((const int32_t *)c->d_rowptrs, c->d_colinds, (const double *)c->d_values, tp.as<int64_t>(),
+                                       a->nrows, key.as<unsigned long long>(), oci.as<int32_t>(), ovs.as<double>(),
+                                       flag.as<unsigned int>());
     CSRK_LAUNCH_CHECK();
-    int64_t total = 0;
-    unsigned int bad = 0;
-    CSRK_HIP(hipMemcpy(&total, tp.as<int64_t>() + a->nrows, 8, hipMemcpyDeviceToHost));
-    CSRK_HIP(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
-    CSRK_REQUIRE(bad == 0, "an entry of the product has no product landing on it (internal error)");
-    // one stable sort of an index permutation per 30-bit digit of the sort key, least significant first (a block of
-    // 4 * 10^8 products: one digit)
-    int32_t *perm = nullptr;
-    for (int d = 0; d == 0 || (total - 1) >> (30 * d) > 0; d++) {
-        const int64_t top = (total - 1) >> (30 * d);                 // largest value of this and the higher digits
-        const int32_t range = (int32_t)(top >= (1ll << 30) ? (1ll << 30) : top + 1);
-        int32_t *ident = perm ? nullptr : permB.as<int32_t>();
-        so_digit_kernel<<<gn, 256>>>(g.as<unsigned long long>(), perm, n, d, keys.as<int32_t>(), ident);
+    if (n_long > 0) {
+        CSRK_HIP(hipFuncSetAttribute((const void *)so_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
+        so_place_kernel<<<(unsigned)n_long, SO_THREADS, lds_place>>>((const int32_t *)c->d_rowptrs, c->d_colinds,
+                                                                     (const double *)c->d_values, tp.as<int64_t>(),
+                                                                     long_rows.as<int32_t>(), key.as<unsigned long long>(),
+                                                                     oci.as<int32_t>(), ovs.as<double>(), flag.as<unsigned int>());
         CSRK_LAUNCH_CHECK();
-        const int32_t *src = perm ? perm : permB.as<int32_t>();
-        int32_t *dst = src == permA.as<int32_t>() ? permB.as<int32_t>() : permA.as<int32_t>();
-        CSRK_TRY(stable_sort_payload_by_key(keys.as<int32_t>(), src, n, range, n, dst, nullptr));
-        perm = dst;
     }
-    so_apply_kernel<<<gn, 256>>>(perm, n, c->d_colinds, (const double *)c->d_values, oci.as<int32_t>(), ovs.as<double>());
-    CSRK_LAUNCH_CHECK();
-    CSRK_HIP(hipDeviceSynchronize());
+    unsigned int bad = 0;
+    CSRK_HIP(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));      // (waits for the kernels)
+    CSRK_REQUIRE(bad == 0, "an entry of the product has no product landing on it (internal error)");
     // the re-ordered arrays become the product's own (pool blocks both: the old ones go back with the DevBufs)
     if (c->owns) {
         void *old_ci = c->d_colinds, *old_vs = c->d_values;
