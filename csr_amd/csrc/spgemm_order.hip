@@ -34,32 +34,44 @@ bool spgemm_reference_order_wanted()
     return e && (e[0] == 'r' || e[0] == 'R' || e[0] == '1');
 }
 
-// products of every row of A B: tp[i] = sum over the entries (i, j) of A of |B_j| (one wavefront per row)
-template <class PA, class PB>
+// products of every row of A B: tp[i] = sum over the entries (i, j) of A of |B_j| (SUB lanes per row: sixteen when A's rows
+// are short, as most rows of a sparse matrix are; a wavefront for a ratings matrix's)
+template <class PA, class PB, int SUB>
 __global__ __launch_bounds__(256) void so_row_products_kernel(const PA *__restrict__ a_rp, const int32_t *__restrict__ a_ci,
                                                              int32_t a_nrows, const PB *__restrict__ b_rp, int64_t *__restrict__ tp)
 {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+    const int lane = threadIdx.x & (SUB - 1);
     if (i >= a_nrows) return;
     int64_t n = 0;
-    for (int64_t e = (int64_t)a_rp[i] + lane; e < (int64_t)a_rp[i + 1]; e += WAVE) {
+    for (int64_t e = (int64_t)a_rp[i] + lane; e < (int64_t)a_rp[i + 1]; e += SUB) {
         const int32_t j = a_ci[e];
         n += (int64_t)b_rp[j + 1] - (int64_t)b_rp[j];
     }
-    for (int off = WAVE / 2; off; off >>= 1) n += __shfl_down(n, off, WAVE);
+    for (int off = SUB / 2; off; off >>= 1) n += __shfl_down(n, off, SUB);
     if (lane == 0) tp[i] = n;
 }
 
-constexpr int SO_TINY = 256;                 // rows of fewer products: SO_SUB lanes each
+constexpr int SO_LEAST = 64;                 // (2^6) rows of fewer products: SO_SUB lanes each, straight from the row number
+constexpr int SO_TINY = 256;                 // (2^8) rows of fewer products: SO_SUB lanes each, from the list
 constexpr int SO_MID = 4096;                 // (2^12) rows of fewer products: a 256-thread workgroup each; the others 1024 threads
 constexpr int SO_SUB = 16;
-constexpr int SO_BATCH = 32;                 // entries of A's row walked between two barriers (<= WAVE)
-constexpr int SO_UNROLL = 4;                 // products a thread has in flight
+constexpr int SO_UNROLL = 8;                 // products a thread has in flight
+constexpr int SO_CHUNK = WAVE * SO_UNROLL;     // consecutive products a wavefront takes at a time
+constexpr int SO_PLACE_UNROLL = 8;           // entries a thread has in flight when they are placed
 constexpr int SO_LDS_BYTES = 150 * 1024;
 constexpr unsigned int SO_NONE = 0xffffffffu;
 
-// The rows of at least SO_TINY products, longest first: the workgroup kernels take a row each, and a 1.2 M-product row
+// Diagnostic build only (-DCSRK_SO_STAMPS): clocks of thread 0 of every so_walk_kernel workgroup, summed per phase
+// (0 tables, 1 batch tables, 2 walk, 3 a batch's discoveries, 4 places: bitmap, 5 counts, 6 moves; 7 workgroups)
+#ifdef CSRK_SO_STAMPS
+__device__ unsigned long long g_so_stamps[8];
+#define SO_STAMP(I) { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_so_stamps[I], now_ - st_last); st_last = now_; } }
+#else
+#define SO_STAMP(I)
+#endif
+
+// The rows of at least SO_LEAST products, longest first: the workgroup kernels take a row each, and a 1.2 M-product row
 // started late is the kernel's whole tail (rows by the octave of their product count: `fill` false counts the octaves,
 // true places the rows behind the cursors the host made of the counts; inside an octave any order).
 constexpr int SO_OCTAVES = 64;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void so_list_rows_kernel(const int64_t *__rest
     if (threadIdx.x < SO_OCTAVES) s_n[threadIdx.x] = 0;
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool listed = r < nrows && tp[r] >= SO_TINY;
+    const bool listed = r < nrows && tp[r] >= SO_LEAST;
     const int oct = listed ? __clzll((long long)tp[r]) : 0;      // (longest rows: fewest leading zeros)
     int32_t at = 0;
     if (listed) at = atomicAdd(&s_n[oct], 1);
@@ -95,51 +107,78 @@ __device__ __forceinline__ int32_t so_find(const T *cols, int32_t n, int32_t k)
 }
 
 // The rows of fewer than SO_TINY products -- 99 % of the rows of a sparse product: SO_SUB lanes per row (four rows per
-// wavefront: the walk is a chain of dependent loads -- entry of A, extent of the row of B, its columns -- and only rows in
-// flight hide it), the row of C's columns, a minimum per entry and the bitmap over its product indices in the group's own
-// 2 KB of LDS: A's entries one after the other, the row of B over the lanes, bisection and an LDS atomic min; then the
-// ranks and the entries to their places.  No barrier: a group's lanes are lanes of one wavefront, whose LDS operations
-// complete in program order.  Nothing goes through memory but the product itself.
-template <class PA, class PB>
+// wavefront), the row of C's columns, a minimum per entry and the bitmap over its product indices in the group's own LDS
+// (CAPT products at most: the kernel runs once for the rows of [1, SO_LEAST) products -- 95 % of the rows, half a kilobyte
+// each, a full complement of wavefronts -- and once for the listed rows of [SO_LEAST, SO_TINY)).  The walk is a chain of dependent loads -- entry of A,
+// extent of the row of B, its columns -- so sixteen entries of A are taken at a time, one per lane, and their products
+// flattened over the lanes: every load of a step is in flight together.  A product finds its entry by bisection and takes
+// an LDS atomic min; then the ranks, and the entries to their places.  No barrier: a group's lanes are lanes of one
+// wavefront, whose LDS operations complete in program order.  Nothing goes through memory but the product itself.
+template <class PA, class PB, int CAPT>
 __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_rp, const int32_t *__restrict__ a_ci,
                                                      int32_t a_nrows, const PB *__restrict__ b_rp,
                                                      const int32_t *__restrict__ b_ci, const int32_t *__restrict__ c_rp,
                                                      const int32_t *__restrict__ c_ci, const double *__restrict__ c_vs,
-                                                     const int64_t *__restrict__ tp, int32_t *__restrict__ oci,
-                                                     double *__restrict__ ovs, unsigned int *__restrict__ bad)
+                                                     const int64_t *__restrict__ tp, const int32_t *__restrict__ row_list,
+                                                     int32_t n_list, int32_t *__restrict__ oci, double *__restrict__ ovs,
+                                                     unsigned int *__restrict__ bad)
 {
-    constexpr int GROUPS = 256 / SO_SUB, WORDS = SO_TINY / 32;
-    __shared__ int32_t s_cols[GROUPS][SO_TINY];
-    __shared__ unsigned int s_mn[GROUPS][SO_TINY], s_bits[GROUPS][WORDS], s_before[GROUPS][WORDS];
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SO_SUB;
+    constexpr int GROUPS = 256 / SO_SUB, WORDS = CAPT / 32;
+    static_assert(WORDS >= 1 && WORDS <= SO_SUB, "a lane counts one word of the bitmap");
+    __shared__ int32_t s_cols[GROUPS][CAPT];
+    __shared__ unsigned int s_mn[GROUPS][CAPT], s_bits[GROUPS][WORDS], s_before[GROUPS][WORDS];
+    __shared__ int32_t s_end[GROUPS][SO_SUB];        // products up to and including each entry of the step
+    __shared__ int64_t s_bs[GROUPS][SO_SUB];
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SO_SUB;
     const int lane = threadIdx.x & (SO_SUB - 1), grp = threadIdx.x / SO_SUB;
-    if (i >= a_nrows) return;
+    if (g >= (row_list ? n_list : a_nrows)) return;
+    const int64_t i = row_list ? row_list[g] : g;    // (no list: every row, the kernel takes those of [1, CAPT) products)
     const int64_t t = tp[i];
-    if (t >= SO_TINY || t == 0) return;
+    if (t >= CAPT || t == 0) return;
     const int32_t c0 = c_rp[i], nc = c_rp[i + 1] - c0;
     if (nc == 0 || nc > t) {
         if (lane == 0) atomicMax(bad, 1u);           // (products and no entry, or more entries than products)
         return;
     }
-    int32_t *cols = s_cols[grp];
+    int32_t *cols = s_cols[grp], *ends = s_end[grp];
     unsigned int *mn = s_mn[grp], *bits = s_bits[grp], *before = s_before[grp];
     for (int32_t q = lane; q < nc; q += SO_SUB) {
         cols[q] = c_ci[c0 + q];
         mn[q] = SO_NONE;
     }
     if (lane < WORDS) bits[lane] = 0u;
-    __builtin_amdgcn_wave_barrier();
     int32_t base = 0;
-    for (int64_t e = a_rp[i]; e < (int64_t)a_rp[i + 1]; e++) {
-        const int32_t j = a_ci[e];
-        const int64_t bs = b_rp[j];
-        const int32_t len = (int32_t)((int64_t)b_rp[j + 1] - bs);
-        for (int32_t tt = lane; tt < len; tt += SO_SUB) {
-            const int32_t lo = so_find(cols, nc, b_ci[bs + tt]);
-            const unsigned int cand = (unsigned int)(base + tt);
+    const int64_t a1 = a_rp[i + 1];
+    for (int64_t e0 = a_rp[i]; e0 < a1; e0 += SO_SUB) {
+        int64_t bs = 0;
+        int32_t len = 0;
+        if (e0 + lane < a1) {
+            const int32_t j = a_ci[e0 + lane];
+            bs = b_rp[j];
+            len = (int32_t)((int64_t)b_rp[j + 1] - bs);
+        }
+        int32_t inc = len;
+#pragma unroll
+        for (int off = 1; off < SO_SUB; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off, SO_SUB);
+            if (lane >= off) inc += o;
+        }
+        const int32_t total = __shfl(inc, SO_SUB - 1, SO_SUB);
+        __builtin_amdgcn_wave_barrier();             // (the step before has read ends[] and s_bs[])
+        ends[lane] = inc;
+        s_bs[grp][lane] = bs;
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t p = lane; p < total; p += SO_SUB) {
+            int q = 0;                               // first entry whose products end after p
+#pragma unroll
+            for (int step = SO_SUB / 2; step; step >>= 1)
+                if (ends[q + step - 1] <= p) q += step;
+            const int32_t first = q ? ends[q - 1] : 0;
+            const int32_t lo = so_find(cols, nc, b_ci[s_bs[grp][q] + (p - first)]);
+            const unsigned int cand = (unsigned int)(base + p);
             if (mn[lo] > cand) atomicMin(&mn[lo], cand);
         }
-        base += len;
+        base += total;
     }
     __builtin_amdgcn_wave_barrier();
     for (int32_t q = lane; q < nc; q += SO_SUB) {
@@ -171,10 +210,10 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
 }
 
 // The other rows: one workgroup per row of A walks that row's products IN ORDER (entries of A's row in order, for each the
-// row of B in order: multiply.py:69-83), SO_BATCH entries of A at a time, their products flattened over the threads (a
+// row of B in order: multiply.py:69-83), a batch of one entry of A per thread at a time, their products flattened over the threads (a
 // 20 000-entry row of B next to fifteen short ones costs every thread the same), and finds for every entry of the row of C
 // its KEY: the index in that walk of the first product that lands on it -- the product that discovers its column.
-//   COLS (the product has few enough columns for 6 B of LDS each): a bit per COLUMN of C says "discovered by an earlier
+//   COLS (the product has few enough columns for 4 B of LDS each): a bit per COLUMN of C says "discovered by an earlier
 //   batch" -- such a product, nearly all of them, ends at the bit test; the others take an LDS atomic min of their index
 //   inside the batch (an integer minimum: any order gives the same result; a read first, so that a column's later products
 //   in the batch skip the atomic).  After the batch the columns with a minimum and no bit are final: each is discovered
@@ -199,16 +238,18 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
                                                          double *__restrict__ ovs, unsigned int *__restrict__ bad)
 {
     extern __shared__ unsigned int so_lds[];
-    // COLS: [seen: words][mn: ncols u32][pos: ncols u16]; else [cols: cap int32][mn: cap u32]; then [bits][before]: win_words each
+    // COLS: [seen: words][mn: ncols u32]; else [cols: cap int32][mn: cap u32]; then [bits][before]: win_words each; COLS: [spre: words]
     const int32_t words = COLS ? (ncols + 31) / 32 : 0;
     unsigned int *seen = so_lds;
     unsigned int *mn = COLS ? seen + words : so_lds + cap;
     int32_t *cols = (int32_t *)so_lds;
-    unsigned short *pos = (unsigned short *)(mn + ncols);
-    unsigned int *bits = COLS ? mn + ncols + (ncols + 1) / 2 : mn + cap;
+    unsigned int *bits = COLS ? mn + ncols : mn + cap;
     unsigned int *before = bits + win_words;
-    __shared__ int64_t s_bs[SO_BATCH];
-    __shared__ int64_t s_off[SO_BATCH + 1];          // (32 rows of B can hold more than 2^31 entries between them)
+    unsigned int *spre = before + win_words;         // COLS: entries of the row before each word of `seen`
+    __shared__ int64_t s_bs[THREADS];                // the batch: where each entry's row of B starts,
+    __shared__ int64_t s_off[THREADS + 1];           // and the products before it
+    __shared__ int64_t s_wave64[THREADS / WAVE];
+    __shared__ int32_t s_take;                       // entries of the batch (fewer than 2^32 products between them)
     __shared__ int32_t s_found;                      // COLS: entries of the row that have their key
     __shared__ int32_t s_wave[THREADS / WAVE];
     const int32_t i = row_list[blockIdx.x];
@@ -227,56 +268,103 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
         for (int32_t q = tid; q < nc; q += THREADS) krow[q] = ~0ull;
     } else if (COLS) {
         if (tid == 0) s_found = 0;
-        for (int32_t q = tid; q < words; q += THREADS) seen[q] = q * 32 + 32 <= ncols ? 0u : ~0u << (ncols & 31);   // (no column past the last)
+        for (int32_t q = tid; q < words; q += THREADS) seen[q] = 0u;
         for (int32_t q = tid; q < ncols; q += THREADS) mn[q] = SO_NONE;
-        for (int32_t q = tid; q < nc; q += THREADS) pos[crow[q]] = (unsigned short)q;
     } else {
         for (int32_t q = tid; q < nc; q += THREADS) {
             cols[q] = crow[q];
             mn[q] = SO_NONE;
         }
     }
-    __syncthreads();
+#ifdef CSRK_SO_STAMPS
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    if (tid == 0) atomicAdd(&g_so_stamps[7], 1ull);
+#endif
     int64_t base = 0;                                // products before this batch
-    for (int64_t e0 = a0; e0 < a1; e0 += SO_BATCH) {
-        if (tid < SO_BATCH) {
-            const int64_t e = e0 + tid;
-            int64_t bs = 0, len = 0;
-            if (e < a1) {
-                const int32_t j = a_ci[e];
-                bs = b_rp[j];
-                len = (int64_t)b_rp[j + 1] - bs;
-            }
-            s_bs[tid] = bs;
-            int64_t inc = len;                       // inclusive scan of the lengths over the first SO_BATCH lanes
-#pragma unroll
-            for (int off = 1; off < SO_BATCH; off <<= 1) {
-                const int64_t o = __shfl_up(inc, off, WAVE);
-                if (tid >= off) inc += o;
-            }
-            s_off[tid + 1] = inc;
-            if (tid == 0) s_off[0] = 0;
+    int64_t e0 = a0;
+    while (e0 < a1) {
+        // the batch: up to THREADS entries of A, one per thread, and the running count of their products (a batch ends
+        // before the entry that would take it to 2^32: indices inside a batch are 32-bit)
+        if (tid == 0) s_take = THREADS;
+        int64_t bs = 0, len = 0;
+        if (e0 + tid < a1) {
+            const int32_t j = a_ci[e0 + tid];
+            bs = b_rp[j];
+            len = (int64_t)b_rp[j + 1] - bs;
         }
-        __syncthreads();
-        const int64_t total = s_off[SO_BATCH];
-        // SO_UNROLL products per thread in flight: the walk is a chain of dependent loads (column of B -> bitmap word), and
-        // one at a time the kernel waits out a memory latency per product
-        int q = 0;                                   // entry of the batch the thread's product belongs to: only ever grows
-        for (int64_t p0 = tid; p0 < total; p0 += (int64_t)SO_UNROLL * THREADS) {
-            int32_t kk[SO_UNROLL];
+        s_bs[tid] = bs;
+        int64_t inc = len;
 #pragma unroll
-            for (int u = 0; u < SO_UNROLL; u++) {
-                const int64_t pidx = p0 + (int64_t)u * THREADS;
-                kk[u] = 0;
-                if (pidx < total) {
-                    while (s_off[q + 1] <= pidx) q++;
-                    kk[u] = b_ci[s_bs[q] + (pidx - s_off[q])];
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) s_wave64[wv] = inc;
+        __syncthreads();                             // (also: the tables of the row are ready, the batch before is done with s_off)
+#pragma unroll
+        for (int v = 0; v < THREADS / WAVE; v++)
+            if (v < wv) inc += s_wave64[v];
+        s_off[tid + 1] = inc;
+        if (tid == 0) s_off[0] = 0;
+        if (!in_memory && inc >= 0xffffffffll) atomicMin(&s_take, tid);      // (in memory: 64-bit indices, no limit)
+        __syncthreads();
+        const int32_t take = (int32_t)(a1 - e0 < s_take ? a1 - e0 : s_take);
+        if (take == 0) {                             // (cannot be: a row of B of 2^32 entries gives this row as many products)
+            if (tid == 0) atomicMax(bad, 1u);
+            return;
+        }
+        const int64_t total = s_off[take];
+        SO_STAMP(1)
+        // A wavefront takes SO_CHUNK = 64 * SO_UNROLL consecutive positions of the batch at a time, SO_UNROLL loads per lane
+        // in flight (the walk is a chain of dependent loads -- column of B -> bitmap word -- and one at a time the kernel waits
+        // out a memory latency per product).  The entry of the chunk's first position is looked for ONCE, by scalars; when
+        // the whole chunk lies in that one row of B -- long rows: nearly always -- the lanes compute no address but base +
+        // lane.  (Searching lane by lane, product by product, the walk of a ratings block was bound by the LDS round trips
+        // of the search: 164 of a row's 270 k clocks.)
+        auto seek = [&](int from, int64_t pidx) {    // the entry that holds pidx, from `from` on: gallop, then bisect
+            if (s_off[from + 1] > pidx) return from;
+            int lo = from + 1, step = 1;             // s_off[lo] <= pidx
+            while (lo + step < take && s_off[lo + step] <= pidx) {
+                lo += step;
+                step <<= 1;
+            }
+            int hi = lo + step < take ? lo + step : take;      // s_off[hi] > pidx
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= pidx) lo = mid;
+                else hi = mid;
+            }
+            return lo;
+        };
+        int qw = 0;                                  // entry of the chunk's first position: only ever grows
+        const int wave_u = __builtin_amdgcn_readfirstlane(wv);
+        constexpr int64_t STRIDE = (int64_t)SO_CHUNK * (THREADS / WAVE);
+        auto fetch = [&](int64_t pf, int32_t (&kk)[SO_UNROLL]) {
+            qw = __builtin_amdgcn_readfirstlane(seek(qw, pf));
+            const int64_t last = pf + SO_CHUNK - 1 < total ? pf + SO_CHUNK - 1 : total - 1;
+            if (s_off[qw + 1] > last) {
+                const int32_t *row = b_ci + (s_bs[qw] + (pf - s_off[qw])) + lane;
+#pragma unroll
+                for (int u = 0; u < SO_UNROLL; u++) kk[u] = pf + u * WAVE + lane <= last ? row[u * WAVE] : 0;
+            } else {
+                int q = qw;
+#pragma unroll
+                for (int u = 0; u < SO_UNROLL; u++) {
+                    const int64_t pidx = pf + u * WAVE + lane;
+                    kk[u] = 0;
+                    if (pidx <= last) {
+                        q = seek(q, pidx);
+                        kk[u] = b_ci[s_bs[q] + (pidx - s_off[q])];
+                    }
                 }
             }
+        };
+        auto apply = [&](int64_t pf, const int32_t (&kk)[SO_UNROLL]) {
+            const int64_t last = pf + SO_CHUNK - 1 < total ? pf + SO_CHUNK - 1 : total - 1;
 #pragma unroll
             for (int u = 0; u < SO_UNROLL; u++) {
-                const int64_t pidx = p0 + (int64_t)u * THREADS;
-                if (pidx >= total) break;
+                const int64_t pidx = pf + u * WAVE + lane;
+                if (pidx > last) break;
                 const int32_t k = kk[u];
                 if (in_memory) {
                     const int32_t lo = so_find(crow, nc, k);
@@ -284,57 +372,61 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
                     if (krow[lo] > cand) atomicMin(&krow[lo], cand);      // (a read as a filter before the atomic)
                 } else if (COLS) {
                     if ((seen[k >> 5] >> (k & 31)) & 1u) continue;
-                    if (mn[k] > (unsigned int)pidx) atomicMin(&mn[k], (unsigned int)pidx);      // (a batch holds fewer than 2^32 products: checked by the host)
+                    if (mn[k] > (unsigned int)pidx) atomicMin(&mn[k], (unsigned int)pidx);
                 } else {
                     const int32_t lo = so_find(cols, nc, k);
                     const unsigned int cand = (unsigned int)(base + pidx);
                     if (mn[lo] > cand) atomicMin(&mn[lo], cand);
                 }
             }
+        };
+        // the next chunk's columns are requested before this one's are used
+        int32_t cur[SO_UNROLL], nxt[SO_UNROLL];
+        int64_t pf = (int64_t)wave_u * SO_CHUNK;
+        if (pf < total) fetch(pf, cur);
+        while (pf < total) {
+            const int64_t pn = pf + STRIDE;
+            if (pn < total) fetch(pn, nxt);
+            apply(pf, cur);
+#pragma unroll
+            for (int u = 0; u < SO_UNROLL; u++) cur[u] = nxt[u];
+            pf = pn;
         }
         if (COLS && !in_memory) {
             __syncthreads();
+            SO_STAMP(2)
+            // the batch's discoveries are final: the columns with a minimum and no bit (a thread per column, a wavefront
+            // 64 columns from a multiple of 64: their two words of `seen` are its own)
             int32_t found = 0;
-            for (int32_t w = tid; w < words; w += THREADS) {      // the batch's discoveries are final
-                unsigned int open = ~seen[w], f = 0u;
-                while (open) {
-                    const int b = __builtin_ctz(open);
-                    open &= open - 1;
-                    const unsigned int m = mn[32 * w + b];
-                    if (m == SO_NONE) continue;
-                    f |= 1u << b;
-                    mn[32 * w + b] = (unsigned int)(base + (int64_t)m);      // (its index in the whole walk)
-                }
-                if (f) {
-                    seen[w] |= f;
-                    found += __popc(f);
-                }
+            for (int32_t k0 = 0; k0 < ncols; k0 += THREADS) {
+                const int32_t k = k0 + tid;
+                unsigned int m = SO_NONE;
+                if (k < ncols && !((seen[k >> 5] >> (k & 31)) & 1u)) m = mn[k];
+                const bool fresh = m != SO_NONE;
+                const unsigned long long f = __ballot(fresh);
+                if (fresh) mn[k] = (unsigned int)(base + (int64_t)m);      // (its index in the whole walk)
+                if (lane == 0 && (unsigned int)f) seen[k >> 5] |= (unsigned int)f;
+                if (lane == 32 && (unsigned int)(f >> 32)) seen[k >> 5] |= (unsigned int)(f >> 32);
+                if (lane == 0) found += __popcll(f);
             }
             if (found) atomicAdd(&s_found, found);
         }
         base += total;
+        e0 += take;
         __syncthreads();
+        SO_STAMP(3)
         if (COLS && !in_memory && s_found == nc) break;      // (every thread reads it after the barrier, and the next write is two barriers on)
     }
     if (in_memory) return;
     // ---- the places
-    const int64_t win = (int64_t)win_words * 32;
-    const int own = (win_words + THREADS - 1) / THREADS;      // words a thread counts
-    int32_t placed = 0;                              // keys below the window
-    for (int64_t w0 = 0; w0 < t; w0 += win) {
-        const int32_t used = (int32_t)(((t - w0 < win ? t - w0 : win) + 31) / 32);
-        for (int32_t w = tid; w < used; w += THREADS) bits[w] = 0u;
-        __syncthreads();
-        for (int32_t q = tid; q < nc; q += THREADS) {
-            const unsigned int k = COLS ? mn[crow[q]] : mn[q];
-            if ((int64_t)k - w0 >= 0 && (int64_t)k - w0 < win && (int64_t)k < t) atomicOr(&bits[(k - w0) >> 5], 1u << ((k - w0) & 31));
-        }
-        __syncthreads();
-        // counts: a thread's `own` consecutive words, then the threads of a wavefront, then the wavefronts
-        int32_t mine = 0;
+    // population counts before each of n words: a thread's consecutive words, then the threads of a wavefront, then the
+    // wavefronts; returns the count of them all (two barriers, the second after dst is written)
+    auto counts_before = [&](const unsigned int *src, int32_t n, unsigned int *dst, int32_t start) {
+        const int own = (n + THREADS - 1) / THREADS;
         const int32_t w_first = tid * own;
+        int32_t mine = 0;
         for (int u = 0; u < own; u++)
-            if (w_first + u < used) mine += __popc(bits[w_first + u]);
+            if (w_first + u < n) mine += __popc(src[w_first + u]);
         int32_t inc = mine;
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) {
@@ -343,7 +435,7 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
         }
         if (lane == WAVE - 1) s_wave[wv] = inc;
         __syncthreads();
-        int32_t run = placed + inc - mine;
+        int32_t run = start + inc - mine;
         int32_t all = 0;
 #pragma unroll
         for (int v = 0; v < THREADS / WAVE; v++) {
@@ -351,24 +443,63 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
             all += s_wave[v];
         }
         for (int u = 0; u < own; u++)
-            if (w_first + u < used) {
-                before[w_first + u] = (unsigned int)run;
-                run += __popc(bits[w_first + u]);
+            if (w_first + u < n) {
+                dst[w_first + u] = (unsigned int)run;
+                run += __popc(src[w_first + u]);
             }
         __syncthreads();
-        for (int32_t q = tid; q < nc; q += THREADS) {
-            const int32_t col = crow[q];
-            const unsigned int k = COLS ? mn[col] : mn[q];
-            if ((int64_t)k - w0 < 0 || (int64_t)k - w0 >= win || (int64_t)k >= t) continue;
-            const unsigned int d = (unsigned int)(k - w0);
-            const int32_t rank = (int32_t)before[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
-            const int64_t to = (int64_t)c0 + (nc - 1 - rank);
-            oci[to] = col;
-            ovs[to] = c_vs[c0 + q];
+        return all;
+    };
+    // COLS: the bits of `seen` are the row's columns, so an entry's position in the (ascending) row of C is the count of
+    // bits before its column's -- the keys are walked by COLUMN, in LDS, and the row's columns are not read again
+    if (COLS && counts_before(seen, words, spre, 0) != nc) {
+        if (tid == 0) atomicMax(bad, 1u);            // (an entry no product lands on)
+        return;
+    }
+    const int32_t span = COLS ? ncols : nc;          // keys: mn[column] or mn[entry]
+    const int64_t win = (int64_t)win_words * 32;
+    int32_t placed = 0;                              // keys below the window
+    for (int64_t w0 = 0; w0 < t; w0 += win) {
+        const int32_t used = (int32_t)(((t - w0 < win ? t - w0 : win) + 31) / 32);
+        for (int32_t w = tid; w < used; w += THREADS) bits[w] = 0u;
+        __syncthreads();
+        for (int32_t x = tid; x < span; x += THREADS) {
+            const int64_t d = (int64_t)mn[x] - w0;   // (no key: 2^32 - 1, past every window of a row of fewer products)
+            if (d >= 0 && d < win && d + w0 < t) atomicOr(&bits[d >> 5], 1u << (d & 31));
+        }
+        __syncthreads();
+        SO_STAMP(4)
+        const int32_t all = counts_before(bits, used, before, placed);
+        SO_STAMP(5)
+        for (int32_t x0 = tid; x0 < span; x0 += SO_PLACE_UNROLL * THREADS) {      // (the loads of a round in flight together)
+            int32_t dd[SO_PLACE_UNROLL], cc[SO_PLACE_UNROLL];
+            double vv[SO_PLACE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) {
+                const int32_t x = x0 + u * THREADS;
+                dd[u] = -1;
+                if (x >= span) continue;
+                const int64_t d = (int64_t)mn[x] - w0;
+                if (d < 0 || d >= win || d + w0 >= t) continue;
+                const int32_t q = COLS ? (int32_t)spre[x >> 5] + __popc(seen[x >> 5] & ((1u << (x & 31)) - 1u)) : x;
+                dd[u] = (int32_t)d;
+                cc[u] = COLS ? x : cols[x];
+                vv[u] = c_vs[c0 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) {
+                if (dd[u] < 0) continue;
+                const unsigned int d = (unsigned int)dd[u];
+                const int32_t rank = (int32_t)before[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
+                const int64_t to = (int64_t)c0 + (nc - 1 - rank);
+                oci[to] = cc[u];
+                ovs[to] = vv[u];
+            }
         }
         placed += all;
+        SO_STAMP(6)
         if (placed >= nc) break;                     // (the same for every thread)
-        __syncthreads();                             // (s_wave and the bitmap are written again)
+        __syncthreads();                             // (the bitmap is written again)
     }
     if (tid == 0 && placed != nc) atomicMax(bad, 1u);      // (an entry no product lands on)
 }
@@ -469,22 +600,22 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     CSRK_TRY(ovs.alloc((size_t)n * 8));
     CSRK_HIP(hipMemsetAsync(cursor.p, 0, SO_OCTAVES * 4, nullptr));
     CSRK_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
-    // LDS of the 1024-thread walk (the device's own limit decides).  By column -- 6 B per column of C and a bit -- when that
-    // leaves a window of 2^15 product indices at least, every row of C has fewer than 65536 entries (16-bit positions; a row
-    // has at most ncols) and no 32 rows of B hold 2^32 entries between them (32-bit indices inside a batch); else by entry,
-    // 8 B each, with a window of 2^16.  The 256-thread walk: rows of fewer than SO_MID products (and entries), by entry.
+    // LDS of the 1024-thread walk (the device's own limit decides; 18 KB of it are the kernel's batch tables).  By column --
+    // 4 B per column of C and a bit -- when that leaves a window of 2^15 product indices at least and no row of B can hold
+    // 2^32 entries (32-bit indices inside a batch); else by entry, 8 B each, with a window of 2^16.  The 256-thread walk:
+    // rows of fewer than SO_MID products (and entries), by entry.
     int lds_max = 0, dev = 0;
     CSRK_HIP(hipGetDevice(&dev));
     CSRK_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-    const int64_t budget = std::min<int64_t>(SO_LDS_BYTES, (int64_t)lds_max - 2048);
-    const int64_t by_col = (((int64_t)c->ncols + 31) / 32 + c->ncols + ((int64_t)c->ncols + 1) / 2) * 4;
+    const int64_t budget = std::min<int64_t>(SO_LDS_BYTES, (int64_t)lds_max - 18 * 1024);
+    const int64_t by_col = (((int64_t)c->ncols + 31) / 32 * 2 + c->ncols) * 4;
     int32_t win_cols = 0;
     for (int32_t w = 16384; w >= 1024; w >>= 1)
         if (by_col + (int64_t)w * 8 <= budget) {
             win_cols = w;
             break;
         }
-    const bool cols_mode = c->ncols < 65536 && win_cols > 0 && b->nnz < (1ll << 32) / SO_BATCH;
+    const bool cols_mode = win_cols > 0 && b->nnz < 0xffffffffll;
     const int32_t win_long = cols_mode ? win_cols : 2048;
     const int32_t cap_long = cols_mode ? INT32_MAX : (int32_t)std::max<int64_t>(0, (budget - (int64_t)win_long * 8) / 8);
     const size_t lds_long = cols_mode ? (size_t)(by_col + (int64_t)win_long * 8) : (size_t)cap_long * 8 + (size_t)win_long * 8;
@@ -492,10 +623,9 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     const size_t lds_mid = (size_t)cap_mid * 8 + (size_t)win_mid * 8;
     const size_t lds_place = (size_t)SO_WIN_WORDS * 8;
     CSRK_REQUIRE((int64_t)lds_place + 2048 <= lds_max && cap_long >= SO_MID, "device has too little LDS for the ordering pass");
-    const unsigned ga = (unsigned)ceil_div((int64_t)a->nrows * WAVE, 256);
     const unsigned gr = (unsigned)ceil_div(a->nrows, 256);
     const unsigned gs = (unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256);
-    int32_t n_long = 0, n_mid = 0;                   // listed rows of at least SO_MID products (first in the list), of fewer
+    int32_t n_long = 0, n_mid = 0, n_small = 0;      // listed rows of at least SO_MID products (first in the list), SO_TINY, SO_LEAST
     int32_t octaves[SO_OCTAVES];
     unsigned long long *const key_p = key.as<unsigned long long>();
     int32_t *const oci_p = oci.as<int32_t>();
@@ -514,13 +644,18 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     } while (0)
 #define ORDER(PA, PB)                                                                                                  \
     do {                                                                                                               \
-        so_row_products_kernel<PA, PB><<<ga, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                  \
-                                                    (const PB *)b->d_rowptrs, tp.as<int64_t>());                       \
+        if (a->nnz / a->nrows >= 32)                                                                                   \
+            so_row_products_kernel<PA, PB, WAVE><<<(unsigned)ceil_div((int64_t)a->nrows * WAVE, 256), 256>>>(          \
+                (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, tp.as<int64_t>());         \
+        else                                                                                                           \
+            so_row_products_kernel<PA, PB, 16><<<(unsigned)ceil_div((int64_t)a->nrows * 16, 256), 256>>>(              \
+                (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, tp.as<int64_t>());         \
         CSRK_LAUNCH_CHECK();                                                                                           \
         so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, false, cursor.as<int32_t>(), nullptr);            \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        so_tiny_kernel<PA, PB><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, \
-                                            b->d_colinds, c_rp, c->d_colinds, c_vs, tp.as<int64_t>(), oci_p, ovs_p, bad_p); \
+        so_tiny_kernel<PA, PB, SO_LEAST><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
+                                                      (const PB *)b->d_rowptrs, b->d_colinds, c_rp, c->d_colinds, c_vs, \
+                                                      tp.as<int64_t>(), nullptr, 0, oci_p, ovs_p, bad_p);              \
         CSRK_LAUNCH_CHECK();                                                                                           \
         CSRK_HIP(hipMemcpy(octaves, cursor.p, sizeof octaves, hipMemcpyDeviceToHost));                                 \
         int32_t listed = 0;                                                                                            \
@@ -529,8 +664,9 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
             octaves[o] = listed;                                                                                       \
             listed += cnt;                                                                                             \
             if (63 - o >= 12) n_long = listed;       /* (SO_MID = 2^12) */                                             \
+            if (63 - o >= 8) n_mid = listed - n_long; /* (SO_TINY = 2^8) */                                            \
         }                                                                                                              \
-        n_mid = listed - n_long;                                                                                       \
+        n_small = listed - n_long - n_mid;                                                                             \
         if (listed > 0) {                                                                                              \
             CSRK_HIP(hipMemcpyAsync(cursor.p, octaves, sizeof octaves, hipMemcpyHostToDevice, nullptr));               \
             so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, true, cursor.as<int32_t>(), rows.as<int32_t>()); \
@@ -541,6 +677,12 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
             else WALK_GO(PA, PB, 1024, false, n_long, lds_long, cap_long, win_long, rows.as<int32_t>());               \
         }                                                                                                              \
         if (n_mid > 0) WALK_GO(PA, PB, 256, false, n_mid, lds_mid, cap_mid, win_mid, rows.as<int32_t>() + n_long);     \
+        if (n_small > 0) {                                                                                             \
+            so_tiny_kernel<PA, PB, SO_TINY><<<(unsigned)ceil_div((int64_t)n_small * SO_SUB, 256), 256>>>(              \
+                (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, b->d_colinds, c_rp,        \
+                c->d_colinds, c_vs, tp.as<int64_t>(), rows.as<int32_t>() + n_long + n_mid, n_small, oci_p, ovs_p, bad_p); \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+        }                                                                                                              \
     } while (0)
     if (a->ptr64) {
         if (b->ptr64) ORDER(int64_t, int64_t);
@@ -577,6 +719,19 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
 }  // namespace csrk
 
 using namespace csrk;
+
+#ifdef CSRK_SO_STAMPS
+extern "C" CSRK_API int csrk_debug_so_stamps(unsigned long long *out, int reset)
+{
+    CSRK_HIP(hipDeviceSynchronize());
+    CSRK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_so_stamps), sizeof g_so_stamps));
+    if (reset) {
+        unsigned long long z[8] = {};
+        CSRK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_so_stamps), z, sizeof z));
+    }
+    return CSRK_OK;
+}
+#endif
 
 extern "C" int csrk_spgemm_set_order(int order)
 {
