@@ -200,6 +200,8 @@ def abt(dev, m=None, ra=2000, rb=20000, reps=3):
         if keep:
             return c
         check(lib.csrk_free(c))
+    order = C.c_int(0)
+    check(lib.csrk_spgemm_get_order(C.byref(order)))      # the library's default: the reference's column order (1) unless the environment asks for ascending
     ms, ms_min = _wall_ms(run, reps, warm=1)
     c = run(keep=True)
     nrc, ncc, nnzc = C.c_int32(), C.c_int32(), C.c_int64()
@@ -214,41 +216,51 @@ def abt(dev, m=None, ra=2000, rb=20000, reps=3):
         d.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (int(p.value), False), 'version': 2}
         return torch.as_tensor(d, device=dev)
     g_rp = dview(d_rp, ra + 1, '<i4', torch.int32)
-    g_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
-    g_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
     cnt_a = torch.bincount(m['colinds'][:ea].long(), minlength=nc).to(torch.float64)
     cnt_b = torch.bincount(m['colinds'][:eb].long(), minlength=nc).to(torch.float64)
     products = int(float((cnt_a * cnt_b).sum()))
-    # the oracle on the same block: transpose + mult_ab = the reference's mult_abt; its rows hold the same columns
-    # in reverse-discovery order: sort (row, column) keys on the card and compare values bit for bit
+    # the oracle on the same block: transpose + mult_ab = the reference's mult_abt, its rows' columns in reverse order of
+    # first discovery (multiply.py:79-82, 94-97)
     ci_h, vs_h = m['colinds'][:eb].cpu().numpy(), m['values'][:eb].cpu().numpy()
     t0 = time.perf_counter()
     tnr, tnc, trp, tci, tvs = O.transpose(rb, nc, rpb.cpu().numpy(), ci_h, vs_h)
     r = O.mult_ab((ra, nc, rpa.cpu().numpy(), ci_h[:ea], vs_h[:ea]), (tnr, tnc, trp, tci, tvs))
     t_cpu = time.perf_counter() - t0
     o_rp, o_ci, o_vs = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (r[2], r[3], r[4]))
-    ok = bool(o_ci.numel() == nnzc.value and torch.equal(o_rp.to(torch.int64), g_rp.to(torch.int64)))
-    if ok:
+
+    def same_raw(cc):        # row pointers, column indices and values bit for bit the oracle's raw arrays, no sorting on either side
+        check(lib.csrk_device_ptrs(cc, C.byref(d_rp), C.byref(d_ci), C.byref(d_vs)))
+        g_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
+        g_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
+        return bool(o_ci.numel() == nnzc.value and torch.equal(o_rp.to(torch.int64), g_rp.to(torch.int64))
+                    and torch.equal(g_ci, o_ci.to(torch.int32)) and torch.equal(g_vs.view(torch.int64), o_vs.view(torch.int64)))
+
+    def same_sorted(cc):     # ascending columns: (row, column) keys of the oracle's arrays sorted on the card, values bit for bit
+        check(lib.csrk_device_ptrs(cc, C.byref(d_rp), C.byref(d_ci), C.byref(d_vs)))
+        g_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
+        g_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
+        if not (o_ci.numel() == nnzc.value and torch.equal(o_rp.to(torch.int64), g_rp.to(torch.int64))):
+            return False
         rows = torch.repeat_interleave(torch.arange(ra, device=dev), (o_rp[1:] - o_rp[:-1]).long())
         key, perm = torch.sort(rows * int(rb) + o_ci.long())
-        ok = bool(torch.equal(key, rows * int(rb) + g_ci.long())
-                  and torch.equal(o_vs[perm].view(torch.int64), g_vs.view(torch.int64)))
+        return bool(torch.equal(key, rows * int(rb) + g_ci.long())
+                    and torch.equal(o_vs[perm].view(torch.int64), g_vs.view(torch.int64)))
+    ok = same_raw(c) if order.value == 1 else same_sorted(c)
     abc = (ea + eb) * 12 + (ra + rb + 2) * 4 + nnzc.value * 12 + (ra + 1) * 4
     check(lib.csrk_free(c))
-    # the reference's own column order inside rows (reverse discovery, multiply.py:79-82, 94-97): row pointers, column
-    # indices and values bit for bit equal to the oracle's raw arrays, no sorting on either side
-    check(lib.csrk_spgemm_set_order(1))
+    # the other column order (csrk_spgemm_set_order): ascending saves the ordering pass
+    check(lib.csrk_spgemm_set_order(1 - order.value))
     try:
-        ms_ref, _ = _wall_ms(run, 2, warm=1)
+        ms_other, _ = _wall_ms(run, 3, warm=1)
         c = run(keep=True)
-        check(lib.csrk_device_ptrs(c, C.byref(d_rp), C.byref(d_ci), C.byref(d_vs)))
-        r_ci = dview(d_ci, nnzc.value, '<i4', torch.int32)
-        r_vs = dview(d_vs, nnzc.value, '<f8', torch.float64)
-        ok_ref = bool(o_ci.numel() == nnzc.value and torch.equal(r_ci, o_ci.to(torch.int32))
-                      and torch.equal(r_vs.view(torch.int64), o_vs.view(torch.int64)))
+        g_rp = dview(d_rp, ra + 1, '<i4', torch.int32)
+        ok_other = same_sorted(c) if order.value == 1 else same_raw(c)
         check(lib.csrk_free(c))
     finally:
         check(lib.csrk_spgemm_set_order(-1))
+    names = {0: 'ascending', 1: 'reference (reverse of first discovery: the raw arrays of csr/kernels/numba/multiply.py)'}
+    ms_asc, ms_ref = (ms_other, ms) if order.value == 1 else (ms, ms_other)
+    ok_raw, ok_sorted = (ok, ok_other) if order.value == 1 else (ok_other, ok)
     check(lib.csrk_free(ha))
     check(lib.csrk_free(hb))
     return {'config': f'mult_abt ({ra} x {nc}) x ({rb} x {nc})^T, rows of the MovieLens-25M-shaped matrix', 'entry': 'csrk_spgemm_abt',
@@ -256,9 +268,9 @@ def abt(dev, m=None, ra=2000, rb=20000, reps=3):
             'products_per_s': round(products / ms * 1e3, -6), 'gflops_2_per_product': round(2.0 * products / ms / 1e6, 1),
             'product_nnz': int(nnzc.value), 'bound': 'data-dependent (no roofline stated: DESIGN.md section 6)',
             'a_bt_c_bytes': int(abc), 'a_bt_c_gbs': round(abc / ms / 1e6, 1),
-            'ms_reference_order': round(ms_ref, 3),
-            'parity': {'rowptrs_colsets_and_values_bit_exact_vs_oracle': ok,
-                       'reference_order_colinds_and_values_bit_exact_vs_oracle_raw': ok_ref, 'ok': bool(ok and ok_ref)},
+            'column_order': names[order.value], 'ms_reference_order': round(ms_ref, 3), 'ms_ascending_order': round(ms_asc, 3),
+            'parity': {'reference_order_rowptrs_colinds_and_values_bit_exact_vs_oracle_raw': ok_raw,
+                       'ascending_order_colinds_and_values_bit_exact_vs_oracle_sorted': ok_sorted, 'ok': bool(ok_raw and ok_sorted)},
             'cpu_baseline': {'value': round(2.0 * products / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'ms': round(t_cpu * 1e3, 1), 'cores': 1,
                              'kind': 'port', 'sample': 'the same block, one pass of orc_transpose + orc_mult_ab'}}
 

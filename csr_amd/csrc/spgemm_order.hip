@@ -1,11 +1,12 @@
-// The reference's column order inside the rows of a sparse product, on request.
+// The reference's column order inside the rows of a sparse product (the default since round 5).
 //
 // _sym_mm (csr/kernels/numba/multiply.py:60-100) walks row i of A entry by entry and, for each, row j of B entry by
 // entry; a column seen for the first time is pushed onto the FRONT of the row's linked list (:79-82), and the list is
 // copied out front to back (:94-97).  So a row of the reference's product holds its columns in REVERSE order of first
 // discovery.  libcsrk's SpGEMM kernels emit ascending columns; no test of the reference pins the
 // order (every one densifies or sorts), but its raw output is what a caller gets from from_handle before sort_rows().
-// With CSRK_SPGEMM_ORDER=reference (or csrk_spgemm_set_order(1)) this pass re-orders a finished product:
+// Unless CSRK_SPGEMM_ORDER=ascending (or csrk_spgemm_set_order(0)) asks for the kernels' own order, this pass re-orders a
+// finished product:
 //
 //   1. for every entry (i, k) of C its KEY: the index, in the reference's walk of row i's products, of the first product
 //      that lands on it -- the product that discovers k.
@@ -26,12 +27,14 @@ namespace csrk {
 
 static std::atomic<int> g_spgemm_order{-1};      // -1: follow CSRK_SPGEMM_ORDER; 0 ascending; 1 reference
 
+// the reference's order unless the caller (csrk_spgemm_set_order(0)) or the environment (CSRK_SPGEMM_ORDER=ascending) asks
+// for ascending columns
 bool spgemm_reference_order_wanted()
 {
     const int o = g_spgemm_order.load();
     if (o >= 0) return o == 1;
     const char *e = getenv("CSRK_SPGEMM_ORDER");
-    return e && (e[0] == 'r' || e[0] == 'R' || e[0] == '1');
+    return !(e && (e[0] == 'a' || e[0] == 'A' || e[0] == '0'));
 }
 
 // products of every row of A B: tp[i] = sum over the entries (i, j) of A of |B_j| (SUB lanes per row: sixteen when A's rows
@@ -737,5 +740,12 @@ extern "C" int csrk_spgemm_set_order(int order)
 {
     CSRK_REQUIRE(order >= -1 && order <= 1, "order must be -1 (environment), 0 (ascending) or 1 (reference)");
     g_spgemm_order.store(order);
+    return CSRK_OK;
+}
+
+extern "C" int csrk_spgemm_get_order(int *order)
+{
+    CSRK_REQUIRE(order, "order is NULL");
+    *order = spgemm_reference_order_wanted() ? 1 : 0;
     return CSRK_OK;
 }

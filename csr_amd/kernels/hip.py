@@ -591,12 +591,20 @@ def mult_dense(h, B):
 
 def set_spgemm_order(order):
     """
-    Column order inside the rows mult_ab / mult_abt return: 'ascending' (default), 'reference' -- reverse order of
-    first discovery, what csr/kernels/numba/multiply.py:79-82, 94-97 emit -- or None (follow CSRK_SPGEMM_ORDER).
-    Process-wide.  The values are the same bits either way.
+    Column order inside the rows mult_ab / mult_abt return: 'reference' (default) -- reverse order of first discovery,
+    what csr/kernels/numba/multiply.py:79-82, 94-97 emit --, 'ascending' (the product kernels' own: no ordering pass) or
+    None (follow CSRK_SPGEMM_ORDER: "ascending", else the reference's).  Process-wide.  The values are the same bits
+    either way.
     """
     code = {None: -1, 'ascending': 0, 'reference': 1}[order]
     check(lib.csrk_spgemm_set_order(code))
+
+
+def spgemm_order():
+    "the column order in force: 'reference' or 'ascending'"
+    o = C.c_int(0)
+    check(lib.csrk_spgemm_get_order(C.byref(o)))
+    return 'reference' if o.value else 'ascending'
 
 
 def set_spmv_algo(h, name):

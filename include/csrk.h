@@ -175,18 +175,20 @@ CSRK_API int csrk_spmv_profile_end4(csrk_handle_t h, int *n_records, float *mean
  * csr/kernels/numba/multiply.py:13-57; lk_mkl_spmab / lk_mkl_spmabt (mkl_ops.h:30-31).
  * The product is a NEW handle owned by the caller (rowptrs int32 as in multiply.py:28,
  * values float64).  Structural zeros produced by cancellation are KEPT (the caller
- * filters them, csr/csr.py:555).  Columns inside a product row are ascending (the
- * reference's order is an artefact of its linked list and pinned by no test).
+ * filters them, csr/csr.py:555).  Columns inside a product row come in the reference's
+ * order (reverse order of first discovery: csrk_spgemm_set_order below).
  * Both operands need values (multiply.py:115,120).  CSRK_ERR_OVERFLOW if the product
  * has more than INT32_MAX entries.                                                     */
 CSRK_API int csrk_spgemm_ab(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
 CSRK_API int csrk_spgemm_abt(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c);
-/* Column order inside the rows of a product: 0 = ascending (default: what the kernels emit), 1 = the reference's --
- * _sym_mm pushes a newly discovered column onto the front of the row's list (csr/kernels/numba/multiply.py:79-82) and
- * copies the list out front to back (:94-97): reverse order of first discovery --, -1 = follow the environment variable
- * CSRK_SPGEMM_ORDER ("reference" selects 1).  Process-wide; values are the same bits either way.  The reference order
- * costs a pass over the products and three stable sorts of the result (csrc/spgemm_order.hip). */
+/* Column order inside the rows of a product: 1 = the reference's (default) -- _sym_mm pushes a newly discovered column
+ * onto the front of the row's list (csr/kernels/numba/multiply.py:79-82) and copies the list out front to back (:94-97):
+ * reverse order of first discovery, so colinds and values are the reference's arrays bit for bit --, 0 = ascending (what
+ * the product kernels emit; saves the ordering pass: a second walk over the products, csrc/spgemm_order.hip), -1 = follow
+ * the environment variable CSRK_SPGEMM_ORDER ("ascending" selects 0; unset or anything else: 1).  Process-wide; every
+ * value has the same bits either way.  csrk_spgemm_get_order: the order in force (0 or 1). */
 CSRK_API int csrk_spgemm_set_order(int order);
+CSRK_API int csrk_spgemm_get_order(int *order);
 
 /* ---- dense-panel SpMM: C = A B, B dense row-major [ncols x k] --------------------------
  * Not a reference entry point (the reference's mult_ab is sparse x sparse only); serves

@@ -91,3 +91,14 @@ def sort_within_rows(rowptrs, colinds, values):
         if vs is not None:
             vs[s:e] = vs[s:e][o]
     return ci, vs
+
+
+def as_library_orders(rowptrs, colinds, values):
+    """
+    The oracle's raw product (columns in the reference's order, reverse of first discovery) in the column order libcsrk is
+    set to emit: as it is under the default, column-sorted under CSRK_SPGEMM_ORDER=ascending / set_spgemm_order('ascending').
+    """
+    from csr_amd.kernels import hip as K
+    if K.spgemm_order() == 'reference':
+        return np.asarray(colinds), (None if values is None else np.asarray(values))
+    return sort_within_rows(rowptrs, colinds, values)

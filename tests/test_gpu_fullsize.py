@@ -219,10 +219,10 @@ def test_mult_abt_config5_large_block():
     nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
     assert (Cm.nrows, Cm.ncols) == (6000, 20000) == (nr, nc)
     assert np.array_equal(Cm.rowptrs, crp)
-    rows = np.repeat(np.arange(nr, dtype=np.int64), np.diff(crp))
-    o = np.lexsort((cci, rows))
-    assert np.array_equal(Cm.colinds, cci[o])
-    assert np.array_equal(Cm.values.view(np.int64), cvs[o].view(np.int64))
+    # the reference's raw arrays, bit for bit: columns in its order (reverse of first discovery), the default
+    assert K.spgemm_order() == 'reference'
+    assert np.array_equal(Cm.colinds, cci)
+    assert np.array_equal(Cm.values.view(np.int64), cvs.view(np.int64))
     # column sums of C against B (A^T 1): sum_i C[i, k] = sum_j B[k, j] * (sum_i A[i, j])
     colsum_a = np.bincount(A.colinds, weights=A.values, minlength=A.ncols)
     want = np.add.reduceat(B.values * colsum_a[B.colinds], B.rowptrs[:-1].astype(np.int64))

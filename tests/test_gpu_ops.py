@@ -12,7 +12,7 @@ tests' own tolerance, tests/test_transform.py:128-149), 1e-5 for f4.
 import numpy as np
 import pytest
 
-from conftest import Mat, sort_within_rows
+from conftest import Mat, sort_within_rows, as_library_orders
 
 pytestmark = pytest.mark.gpu
 
@@ -229,7 +229,7 @@ def test_spgemm_golden(golden):
         # structure: same rowptrs and the same column SET per row as the reference (explicit
         # zeros kept); order inside a row is ascending here
         assert C.rowptrs.dtype == np.int32 and np.array_equal(C.rowptrs, raw.rowptrs), c
-        rci, rvs = sort_within_rows(raw.rowptrs, raw.colinds, raw.values)
+        rci, rvs = as_library_orders(raw.rowptrs, raw.colinds, raw.values)
         assert np.array_equal(C.colinds, rci), c
         assert np.all(np.abs(C.values - rvs) <= bound[np.repeat(np.arange(C.nrows), np.diff(C.rowptrs)), C.colinds]), c
         if _rows_hold_no_column_twice(B):
@@ -279,11 +279,11 @@ def test_spgemm_vs_oracle(case):
         K.release_handle(bh)
     nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values),
                                       (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values))
-    rci, rvs = sort_within_rows(crp, cci, cvs)
+    rci, rvs = as_library_orders(crp, cci, cvs)
     assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, rci)
     _, _, _, _, babs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values)),
                                  (B.nrows, B.ncols, B.rowptrs, B.colinds, np.abs(B.values)))
-    _, bsorted = sort_within_rows(crp, cci, babs)
+    _, bsorted = as_library_orders(crp, cci, babs)
     assert np.all(np.abs(C.values - rvs) <= 1e-6 * bsorted + 1e-300)
     assert np.all(np.abs(C.values - rvs) <= 1e-12 * bsorted + 1e-300)
     if _rows_hold_no_column_twice(B):
@@ -422,11 +422,11 @@ def test_mult_abt_movielens_shape_blocks():
         nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
         assert (Cm.nrows, Cm.ncols) == (A.nrows, B.nrows) == (nr, nc)
         assert Cm.rowptrs.dtype == np.int32 and np.array_equal(Cm.rowptrs, crp)
-        rci, rvs = sort_within_rows(crp, cci, cvs)
+        rci, rvs = as_library_orders(crp, cci, cvs)
         assert np.array_equal(Cm.colinds, rci)
         _, _, _, _, babs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values)),
                                      (bt[0], bt[1], bt[2], bt[3], np.abs(bt[4])))
-        _, bsorted = sort_within_rows(crp, cci, babs)
+        _, bsorted = as_library_orders(crp, cci, babs)
         assert np.all(np.abs(Cm.values - rvs) <= 1e-12 * bsorted + 1e-300)
         assert np.array_equal(Cm.values.view(np.int64), rvs.view(np.int64))      # same order of addition: same bits
         # the caller's path (csr/csr.py:524-567): same product after _filter_zeros
@@ -493,7 +493,7 @@ def test_spgemm_deterministic(paths, monkeypatch):
             assert np.array_equal(c.values.view(np.int64), outs[0].values.view(np.int64))      # bit for bit, run to run
         bt = O.transpose(B.nrows, B.ncols, B.rowptrs, B.colinds, B.values) if abt else (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values)
         nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), bt)
-        rci, rvs = sort_within_rows(crp, cci, cvs)
+        rci, rvs = as_library_orders(crp, cci, cvs)
         assert np.array_equal(outs[0].rowptrs, crp) and np.array_equal(outs[0].colinds, rci)
         assert np.array_equal(outs[0].values.view(np.int64), rvs.view(np.int64))                  # = the sequential loop's bits
 
@@ -976,7 +976,7 @@ def test_spgemm_unsorted_b_rows():
         K.release_handle(ah)
         K.release_handle(bh)
     nr, nc, crp, cci, cvs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), (B.nrows, B.ncols, B.rowptrs, B.colinds, B.values))
-    rci, rvs = sort_within_rows(crp, cci, cvs)
+    rci, rvs = as_library_orders(crp, cci, cvs)
     assert np.array_equal(C.rowptrs, crp) and np.array_equal(C.colinds, rci)
     assert np.array_equal(C.values.view(np.int64), rvs.view(np.int64))
 

@@ -69,8 +69,10 @@ for case in range(n_cases):
     Cm = export(hc)
     t_gpu = time.time() - t0
     ref_order_ok = True
-    if os.environ.get('CSRK_SPGEMM_ORDER', '').lower().startswith('r'):
-        # the reference's own column order: bit for bit the oracle's raw arrays; then sorted for the SciPy comparison
+    order = C.c_int(0)
+    check(lib.csrk_spgemm_get_order(C.byref(order)))
+    if order.value == 1:
+        # the reference's own column order (the default): bit for bit the oracle's raw arrays; then sorted for the SciPy comparison
         from oracle import oracle as O
         Bo = Bm.tocsr()
         _, _, orp, oci, _ = O.mult_ab((A.shape[0], A.shape[1], A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data),
