@@ -8,7 +8,7 @@ def newest(pattern):
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = f'gpurun_out/{tag}cfg'
-keep = ('csrk::spmm', 'csrk::mm_', 'csrk::rx_', 'csrk::rowptr_from', 'csrk::sg_', 'csrk::row_')
+keep = ('csrk::spmm', 'csrk::mm_', 'csrk::rx_', 'csrk::rowptr_from', 'csrk::sg_', 'csrk::so_', 'csrk::row_')
 with open(f'profiles/{tag}_configs.json', 'w') as f:      # the plain (unprofiled) run's lines
     for ln in open(f'{src}/plain.log'):
         if ln.startswith('{'):
