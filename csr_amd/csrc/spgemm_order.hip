@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace csrk {
 
@@ -362,39 +363,48 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
                 }
             }
         };
-        auto apply = [&](int64_t pf, const int32_t (&kk)[SO_UNROLL]) {
-            const int64_t last = pf + SO_CHUNK - 1 < total ? pf + SO_CHUNK - 1 : total - 1;
+        // MODE 0: by column (the LDS reads of a chunk's SO_UNROLL steps are issued together: step by step, each waited out its
+        // own LDS round trip); 1: by entry, bisection in LDS; 2: bisection and atomic min in memory
+        auto walk_chunks = [&](auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+            for (int64_t pf = (int64_t)wave_u * SO_CHUNK; pf < total; pf += STRIDE) {
+                int32_t kk[SO_UNROLL];
+                fetch(pf, kk);
+                const int64_t last = pf + SO_CHUNK - 1 < total ? pf + SO_CHUNK - 1 : total - 1;
+                if constexpr (MODE == 0) {
+                    const unsigned int p_first = (unsigned int)pf + lane, n_here = (unsigned int)(last - pf) + 1u;
+                    unsigned int word[SO_UNROLL], least[SO_UNROLL];
+                    bool open[SO_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SO_UNROLL; u++) {
-                const int64_t pidx = pf + u * WAVE + lane;
-                if (pidx > last) break;
-                const int32_t k = kk[u];
-                if (in_memory) {
-                    const int32_t lo = so_find(crow, nc, k);
-                    const unsigned long long cand = (unsigned long long)(base + pidx);
-                    if (krow[lo] > cand) atomicMin(&krow[lo], cand);      // (a read as a filter before the atomic)
-                } else if (COLS) {
-                    if ((seen[k >> 5] >> (k & 31)) & 1u) continue;
-                    if (mn[k] > (unsigned int)pidx) atomicMin(&mn[k], (unsigned int)pidx);
+                    for (int u = 0; u < SO_UNROLL; u++) word[u] = seen[kk[u] >> 5];
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++)
+                        open[u] = (unsigned int)(u * WAVE + lane) < n_here && !((word[u] >> (kk[u] & 31)) & 1u);
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++) least[u] = open[u] ? mn[kk[u]] : 0u;
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++)
+                        if (open[u] && least[u] > p_first + u * WAVE) atomicMin(&mn[kk[u]], p_first + u * WAVE);
                 } else {
-                    const int32_t lo = so_find(cols, nc, k);
-                    const unsigned int cand = (unsigned int)(base + pidx);
-                    if (mn[lo] > cand) atomicMin(&mn[lo], cand);
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++) {
+                        const int64_t pidx = pf + u * WAVE + lane;
+                        if (pidx > last) break;
+                        if constexpr (MODE == 2) {
+                            const int32_t lo = so_find(crow, nc, kk[u]);
+                            const unsigned long long cand = (unsigned long long)(base + pidx);
+                            if (krow[lo] > cand) atomicMin(&krow[lo], cand);      // (a read as a filter before the atomic)
+                        } else {
+                            const int32_t lo = so_find(cols, nc, kk[u]);
+                            const unsigned int cand = (unsigned int)(base + pidx);
+                            if (mn[lo] > cand) atomicMin(&mn[lo], cand);
+                        }
+                    }
                 }
             }
         };
-        // the next chunk's columns are requested before this one's are used
-        int32_t cur[SO_UNROLL], nxt[SO_UNROLL];
-        int64_t pf = (int64_t)wave_u * SO_CHUNK;
-        if (pf < total) fetch(pf, cur);
-        while (pf < total) {
-            const int64_t pn = pf + STRIDE;
-            if (pn < total) fetch(pn, nxt);
-            apply(pf, cur);
-#pragma unroll
-            for (int u = 0; u < SO_UNROLL; u++) cur[u] = nxt[u];
-            pf = pn;
-        }
+        if (in_memory) walk_chunks(std::integral_constant<int, 2>{});
+        else walk_chunks(std::integral_constant<int, COLS ? 0 : 1>{});
         if (COLS && !in_memory) {
             __syncthreads();
             SO_STAMP(2)
@@ -466,34 +476,57 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
         const int32_t used = (int32_t)(((t - w0 < win ? t - w0 : win) + 31) / 32);
         for (int32_t w = tid; w < used; w += THREADS) bits[w] = 0u;
         __syncthreads();
-        for (int32_t x = tid; x < span; x += THREADS) {
-            const int64_t d = (int64_t)mn[x] - w0;   // (no key: 2^32 - 1, past every window of a row of fewer products)
-            if (d >= 0 && d < win && d + w0 < t) atomicOr(&bits[d >> 5], 1u << (d & 31));
+        // (here and below: the LDS reads and the loads of SO_PLACE_UNROLL keys are issued together, then used -- one at a
+        // time each waited out its own round trip)
+        for (int32_t x0 = tid; x0 < span; x0 += SO_PLACE_UNROLL * THREADS) {
+            unsigned int mm[SO_PLACE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) mm[u] = x0 + u * THREADS < span ? mn[x0 + u * THREADS] : SO_NONE;
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) {
+                const int64_t d = (int64_t)mm[u] - w0;      // (no key: 2^32 - 1, past every window of a row of fewer products)
+                if (d >= 0 && d < win && d + w0 < t) atomicOr(&bits[d >> 5], 1u << (d & 31));
+            }
         }
         __syncthreads();
         SO_STAMP(4)
         const int32_t all = counts_before(bits, used, before, placed);
         SO_STAMP(5)
-        for (int32_t x0 = tid; x0 < span; x0 += SO_PLACE_UNROLL * THREADS) {      // (the loads of a round in flight together)
-            int32_t dd[SO_PLACE_UNROLL], cc[SO_PLACE_UNROLL];
+        for (int32_t x0 = tid; x0 < span; x0 += SO_PLACE_UNROLL * THREADS) {
+            unsigned int mm[SO_PLACE_UNROLL], sp[SO_PLACE_UNROLL], sw[SO_PLACE_UNROLL], bf[SO_PLACE_UNROLL], bw[SO_PLACE_UNROLL];
+            int32_t cc[SO_PLACE_UNROLL];
             double vv[SO_PLACE_UNROLL];
+            bool here[SO_PLACE_UNROLL];
 #pragma unroll
             for (int u = 0; u < SO_PLACE_UNROLL; u++) {
-                const int32_t x = x0 + u * THREADS;
-                dd[u] = -1;
-                if (x >= span) continue;
-                const int64_t d = (int64_t)mn[x] - w0;
-                if (d < 0 || d >= win || d + w0 >= t) continue;
-                const int32_t q = COLS ? (int32_t)spre[x >> 5] + __popc(seen[x >> 5] & ((1u << (x & 31)) - 1u)) : x;
-                dd[u] = (int32_t)d;
-                cc[u] = COLS ? x : cols[x];
-                vv[u] = c_vs[c0 + q];
+                const int32_t x = x0 + u * THREADS < span ? x0 + u * THREADS : span - 1;      // (clamped: the reads stay unconditional)
+                mm[u] = mn[x];
+                if (COLS) {
+                    sp[u] = spre[x >> 5];
+                    sw[u] = seen[x >> 5];
+                    cc[u] = x;
+                } else {
+                    cc[u] = cols[x];
+                }
             }
 #pragma unroll
             for (int u = 0; u < SO_PLACE_UNROLL; u++) {
-                if (dd[u] < 0) continue;
-                const unsigned int d = (unsigned int)dd[u];
-                const int32_t rank = (int32_t)before[d >> 5] + __popc(bits[d >> 5] & ((1u << (d & 31)) - 1u));
+                const int32_t x = x0 + u * THREADS;
+                const int64_t d = (int64_t)mm[u] - w0;
+                here[u] = x < span && d >= 0 && d < win && d + w0 < t;
+                mm[u] = here[u] ? (unsigned int)d : 0u;
+                const int32_t q = COLS ? (int32_t)sp[u] + __popc(sw[u] & ((1u << (x & 31)) - 1u)) : x;
+                vv[u] = here[u] ? c_vs[c0 + q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) {
+                bf[u] = before[mm[u] >> 5];
+                bw[u] = bits[mm[u] >> 5];
+            }
+#pragma unroll
+            for (int u = 0; u < SO_PLACE_UNROLL; u++) {
+                if (!here[u]) continue;
+                const int32_t rank = (int32_t)bf[u] + __popc(bw[u] & ((1u << (mm[u] & 31)) - 1u));
                 const int64_t to = (int64_t)c0 + (nc - 1 - rank);
                 oci[to] = cc[u];
                 ovs[to] = vv[u];
