@@ -58,6 +58,13 @@ void set_error(const char *fmt, ...);
 hipError_t pool_alloc(void **p, size_t n);
 void pool_free(void *p);
 
+// Tables between the host and the card go through one pinned staging buffer (grown on demand, shared by the process, one
+// copy at a time) that a small kernel reads or writes over the bus: the first hipMemcpy a process makes between the card
+// and the host costs 6 ms whatever its size, and the plan of the first matrix a process multiplies paid it (a fifth of the
+// plan's cost).  Both wait for the copy (and for what the stream held before it); copies of a few words go straight through.
+int stage_d2h(void *host_dst, const void *dev_src, size_t n, hipStream_t s);
+int stage_h2d(void *dev_dst, const void *host_src, size_t n, hipStream_t s);
+
 // ---- device buffer with RAII -----------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;

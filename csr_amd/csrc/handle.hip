@@ -4,6 +4,9 @@
 // row_extent / row_nnzs (csr/_rows.py:9-13, csr/csr.py:432-441).
 #include "common.h"
 
+#include <cstring>
+#include <ctime>
+
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
@@ -69,7 +72,15 @@ hipError_t pool_alloc(void **out, size_t n)
         }
     }
     void *q = nullptr;
+    static const bool trace = getenv("CSRK_PLAN_TRACE") != nullptr;      // (with the plan builders' laps: what the driver's allocations cost)
+    timespec t0{}, t1{};
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
     e = hipMalloc(&q, n);
+    if (trace) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "[csrk pool] hipMalloc %10.3f MB %8.3f ms\n", n / 1048576.0,
+                (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+    }
     if (e != hipSuccess) {                                  // out of memory: give the cache back and retry
         (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -97,6 +108,79 @@ void pool_free(void *p)
     g_pool_free.emplace(b.bytes, b);
     g_pool_cached += b.bytes;
     if (g_pool_cached > POOL_CAP) pool_trim_locked(POOL_CAP / 2);
+}
+
+namespace {
+std::mutex g_stage_mu;
+void *g_stage = nullptr;
+size_t g_stage_bytes = 0;
+constexpr size_t STAGE_DIRECT = 1024;          // copies of at most this many bytes: the runtime's own path
+
+int stage_room_locked(size_t n)
+{
+    if (g_stage_bytes >= n) return CSRK_OK;
+    if (g_stage) (void)hipHostFree(g_stage);
+    g_stage = nullptr;
+    g_stage_bytes = 0;
+    size_t want = 1u << 20;
+    while (want < n) want <<= 1;
+    CSRK_HIP(hipHostMalloc(&g_stage, want, hipHostMallocPortable | hipHostMallocMapped));
+    g_stage_bytes = want;
+    return CSRK_OK;
+}
+
+// the bytes move by a kernel that reads or writes the pinned buffer over the bus (the first hipMemcpy of a process between
+// the card and the host costs 6 ms whatever its size -- the runtime sets its copy engine up --, and the plan of the first
+// matrix a process multiplies paid it)
+__global__ void stage_copy_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, size_t n, bool words)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (words) {
+        if (i < n / 4) ((uint32_t *)dst)[i] = ((const uint32_t *)src)[i];
+    } else if (i < n) {
+        dst[i] = src[i];
+    }
+}
+
+int stage_copy(const void *src, void *dst, size_t n, hipStream_t s)
+{
+    const bool words = n % 4 == 0 && (uintptr_t)src % 4 == 0 && (uintptr_t)dst % 4 == 0;
+    const size_t items = words ? n / 4 : n;
+    stage_copy_kernel<<<(unsigned)((items + 255) / 256), 256, 0, s>>>((const unsigned char *)src, (unsigned char *)dst, n, words);
+    CSRK_LAUNCH_CHECK();
+    CSRK_HIP(hipStreamSynchronize(s));
+    return CSRK_OK;
+}
+}  // namespace
+
+int stage_d2h(void *host_dst, const void *dev_src, size_t n, hipStream_t s)
+{
+    if (n == 0) return CSRK_OK;
+    if (n <= STAGE_DIRECT) {
+        CSRK_HIP(hipMemcpyAsync(host_dst, dev_src, n, hipMemcpyDeviceToHost, s));
+        CSRK_HIP(hipStreamSynchronize(s));
+        return CSRK_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    CSRK_TRY(stage_room_locked(n));
+    CSRK_TRY(stage_copy(dev_src, g_stage, n, s));
+    memcpy(host_dst, g_stage, n);
+    return CSRK_OK;
+}
+
+int stage_h2d(void *dev_dst, const void *host_src, size_t n, hipStream_t s)
+{
+    if (n == 0) return CSRK_OK;
+    if (n <= STAGE_DIRECT) {
+        CSRK_HIP(hipMemcpyAsync(dev_dst, host_src, n, hipMemcpyHostToDevice, s));
+        CSRK_HIP(hipStreamSynchronize(s));       // (the caller's buffer may go out of scope)
+        return CSRK_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    CSRK_TRY(stage_room_locked(n));
+    memcpy(g_stage, host_src, n);
+    CSRK_TRY(stage_copy(g_stage, dev_dst, n, s));      // (waits: the staging buffer is the next copy's)
+    return CSRK_OK;
 }
 
 void set_error(const char *fmt, ...)

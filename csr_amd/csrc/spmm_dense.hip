@@ -546,8 +546,8 @@ static int build_mm_plan(Matrix *m, SpmmPlan *p, hipStream_t s)
     CSRK_TRY(exclusive_scan_i64(p->seg_off.as<int64_t>(), p->seg_off.as<int64_t>(), m->nrows, s));
     CSRK_TRY(exclusive_scan_i64(p->part_off.as<int64_t>(), p->part_off.as<int64_t>(), m->nrows, s));
     int64_t n = 0, nm = 0;
-    CSRK_HIP(hipMemcpyAsync(&n, p->seg_off.as<int64_t>() + m->nrows, 8, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(&nm, p->part_off.as<int64_t>() + m->nrows, 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(&n, p->seg_off.as<int64_t>() + m->nrows, 8, s));
+    CSRK_TRY(stage_d2h(&nm, p->part_off.as<int64_t>() + m->nrows, 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
     p->n_segs = n;
     p->n_multi = nm;
@@ -559,7 +559,7 @@ static int build_mm_plan(Matrix *m, SpmmPlan *p, hipStream_t s)
         mm_list_split_kernel<<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(p->seg_off.as<int64_t>(), m->nrows,
                                                                               p->split_rows.as<int32_t>(), cnt.as<int32_t>());
         CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(&p->n_split, cnt.p, 4, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(&p->n_split, cnt.p, 4, s));
         CSRK_HIP(hipStreamSynchronize(s));
     }
     CSRK_TRY(p->seg.alloc((size_t)n * sizeof(SegDesc)));
@@ -590,7 +590,7 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
         CSRK_TRY(dlen.alloc((size_t)m->nrows * 8));
         hr_len_kernel<P><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>((const P *)m->d_rowptrs, m->nrows, dlen.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(len.data(), dlen.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(len.data(), dlen.p, (size_t)m->nrows * 8, s));
         CSRK_HIP(hipStreamSynchronize(s));
     }
     std::vector<int32_t> cand;
@@ -671,9 +671,9 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
     CSRK_TRY(p->hr_vals.alloc((size_t)(nnz_h + HR_PAD) * 8));
     CSRK_HIP(hipMemsetAsync(p->hr_idx.as<uint32_t>() + nnz_h, 0, HR_PAD * 4, s));      // (the batches of four read a little past a bucket)
     CSRK_HIP(hipMemsetAsync(p->hr_vals.as<double>() + nnz_h, 0, HR_PAD * 8, s));
-    CSRK_HIP(hipMemcpyAsync(p->hr_rows.p, cand.data(), n * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(p->hr_code.p, code.data(), n * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(doff.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(p->hr_rows.p, cand.data(), n * 4, s));
+    CSRK_TRY(stage_h2d(p->hr_code.p, code.data(), n * 4, s));
+    CSRK_TRY(stage_h2d(doff.p, off.data(), (n + 1) * 8, s));
 #define EMIT(VT)                                                                                                       \
     hr_emit_kernel<P, VT><<<(unsigned)n, 256, 0, s>>>((const P *)m->d_rowptrs, m->d_colinds, m->d_values, p->hr_rows.as<int32_t>(), \
                                                       p->hr_code.as<int32_t>(), doff.as<int64_t>(), G, key.as<int32_t>(),  \
@@ -693,7 +693,7 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
         hr_tile_totals_kernel<<<(unsigned)ceil_div(n_tiles + 1, 256), 256, 0, s>>>(p->hr_bp.as<int64_t>(), (int32_t)n_tiles, G * HR_WAVES,
                                                                                  dt.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(tot.data(), dt.p, (size_t)(n_tiles + 1) * 8, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(tot.data(), dt.p, (size_t)(n_tiles + 1) * 8, s));
         CSRK_HIP(hipStreamSynchronize(s));
     }
     const int64_t tile_cost = 200 * (int64_t)G;
@@ -713,7 +713,7 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
     }
     range[(size_t)R] = (int32_t)n_tiles;
     CSRK_TRY(p->hr_range.alloc(((size_t)R + 1) * 4));
-    CSRK_HIP(hipMemcpyAsync(p->hr_range.p, range.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(p->hr_range.p, range.data(), ((size_t)R + 1) * 4, s));
     CSRK_TRY(p->hr_part.alloc((size_t)R * G * HR_ROWS * HR_KC * 8));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmm_hrows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HR_LDS));
     CSRK_HIP(hipFuncSetAttribute((const void *)spmm_hrows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HR_LDS));

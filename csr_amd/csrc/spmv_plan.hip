@@ -609,7 +609,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, cb);
     const int64_t pairs = (int64_t)n * nb;
     CSRK_TRY(pn->row_list.alloc((size_t)n * 4));
-    CSRK_HIP(hipMemcpyAsync(pn->row_list.p, rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(pn->row_list.p, rows.data(), (size_t)n * 4, s));
     DevBuf off, bends;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
     const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
@@ -634,12 +634,12 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
-    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(be.data(), bends.p, (size_t)(nb + 1) * 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
     t0[0] = 0;
     for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n + be[b + 1] - be[b], MERGE_ITEMS);
     const int64_t n_tiles = t0[nb];
-    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(bends.p, t0.data(), (size_t)(nb + 1) * 8, s));
     CSRK_TRY(pn->tile.alloc((size_t)n_tiles * sizeof(PanelTile)));
     if (pn->p64)
         panel_plan_kernel<int64_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
@@ -678,7 +678,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     // the tiles' carries per long row (a tile's carry belongs to the pair holding its last, unfinished row end: static)
     {
         std::vector<PanelTile> ht((size_t)n_tiles);
-        CSRK_HIP(hipMemcpy(ht.data(), pn->tile.p, (size_t)n_tiles * sizeof(PanelTile), hipMemcpyDeviceToHost));
+        CSRK_TRY(stage_d2h(ht.data(), pn->tile.p, (size_t)n_tiles * sizeof(PanelTile), nullptr));
         std::vector<int32_t> crp((size_t)n + 1, 0), cidx;
         for (int64_t t = 0; t < n_tiles; t++)
             if ((int64_t)ht[(size_t)t].i1 < pairs) crp[(size_t)(ht[(size_t)t].i1 % n) + 1]++;
@@ -689,12 +689,12 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
             if ((int64_t)ht[(size_t)t].i1 < pairs) cidx[(size_t)cur[(size_t)(ht[(size_t)t].i1 % n)]++] = (int32_t)t;
         CSRK_TRY(pn->crp.alloc(crp.size() * 4));
         CSRK_TRY(pn->cidx.alloc(cidx.size() * 4));
-        CSRK_HIP(hipMemcpy(pn->crp.p, crp.data(), crp.size() * 4, hipMemcpyHostToDevice));
-        CSRK_HIP(hipMemcpy(pn->cidx.p, cidx.data(), cidx.size() * 4, hipMemcpyHostToDevice));
+        CSRK_TRY(stage_h2d(pn->crp.p, crp.data(), crp.size() * 4, nullptr));
+        CSRK_TRY(stage_h2d(pn->cidx.p, cidx.data(), cidx.size() * 4, nullptr));
     }
     pn->groups = (int64_t)groups.size();
     CSRK_TRY(pn->group.alloc(groups.size() * sizeof(PanelGroup)));
-    CSRK_HIP(hipMemcpyAsync(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), s));
     CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
     CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
@@ -719,7 +719,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
     const int64_t pairs = (int64_t)n * nb;
     CSRK_TRY(ap->row_list.alloc((size_t)n * 4));
-    CSRK_HIP(hipMemcpyAsync(ap->row_list.p, rows, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(ap->row_list.p, rows, (size_t)n * 4, s));
     DevBuf off, bends, pstart, d_trow, d_tpiece;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
     // block starts inside every row (one pass over the rows' entries), then the pair counts
@@ -733,8 +733,8 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     CSRK_TRY(pstart.alloc((size_t)(pairs + n) * 4));
     CSRK_TRY(d_trow.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
     CSRK_TRY(d_tpiece.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
-    CSRK_HIP(hipMemcpyAsync(d_trow.p, trow.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(d_tpiece.p, tpiece.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(d_trow.p, trow.data(), (size_t)n_tasks * 4, s));
+    CSRK_TRY(stage_h2d(d_tpiece.p, tpiece.data(), (size_t)n_tasks * 4, s));
     acc_pairstart_kernel<P><<<(unsigned)ceil_div(n_tasks * WAVE, 256), 256, 0, s>>>(
         rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, d_trow.as<int32_t>(), d_tpiece.as<int32_t>(), n_tasks,
         pstart.as<int32_t>());
@@ -750,12 +750,12 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     panel_blockends_kernel<<<(unsigned)ceil_div(nb + 1, 256), 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     std::vector<int64_t> be((size_t)nb + 1), t0((size_t)nb + 1);
-    CSRK_HIP(hipMemcpyAsync(be.data(), bends.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(be.data(), bends.p, (size_t)(nb + 1) * 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
     t0[0] = 0;
     for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div(be[b + 1] - be[b], ACC_TILE);
     const int64_t n_tiles = t0[nb];
-    CSRK_HIP(hipMemcpyAsync(bends.p, t0.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(bends.p, t0.data(), (size_t)(nb + 1) * 8, s));
     // persistent workgroups: one per CU, equal shares of the tiles (stored interleaved: acc_phys_tile), cut into one-block
     // segments
     int cus = 0;
@@ -770,7 +770,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     const int64_t n_phys = share_max * n_wg;      // stored tiles (the last sweep has holes where a share is one tile shorter)
     DevBuf d_wg_t0;
     CSRK_TRY(d_wg_t0.alloc((size_t)(n_wg + 1) * 8));
-    CSRK_HIP(hipMemcpyAsync(d_wg_t0.p, wg_t0.data(), (size_t)(n_wg + 1) * 8, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(d_wg_t0.p, wg_t0.data(), (size_t)(n_wg + 1) * 8, s));
     CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * 8));
     CSRK_TRY(ap->idx.alloc((size_t)n_phys * ACC_TILE * 2));
     CSRK_TRY(ap->tile_row0.alloc((size_t)(n_tiles ? n_tiles : 1) * 4));
@@ -805,8 +805,8 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     wg_seg[(size_t)n_wg] = (int32_t)segs.size();
     CSRK_TRY(ap->segs.alloc(segs.size() * sizeof(AccSeg)));
     CSRK_TRY(ap->wg_seg.alloc(wg_seg.size() * 4));
-    CSRK_HIP(hipMemcpyAsync(ap->segs.p, segs.data(), segs.size() * sizeof(AccSeg), hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(ap->wg_seg.p, wg_seg.data(), wg_seg.size() * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(ap->segs.p, segs.data(), segs.size() * sizeof(AccSeg), s));
+    CSRK_TRY(stage_h2d(ap->wg_seg.p, wg_seg.data(), wg_seg.size() * 4, s));
     CSRK_TRY(ap->partial.alloc((size_t)n_wg * n * 8));
     ap->lds = (size_t)(ACC_CB + 2) * 8 + (size_t)((n + 1) & ~1) * 8 + (size_t)ACC_SEG_TILES * 12;
     CSRK_TRY(spmv_kernel_attributes());
@@ -821,6 +821,32 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
 }
 
 // Cut the long rows out of the merge path and build their panel tiers.
+struct PlanTrace {
+    bool on;
+    double t0;
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
+    {
+        if (on) {
+            (void)hipDeviceSynchronize();
+            t0 = now();
+        }
+    }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
+        t0 = t;
+    }
+};
+
 template <class P>
 static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_tier1 = true)
 {
@@ -842,6 +868,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nr = m->nrows;
     const unsigned g1 = (unsigned)ceil_div((int64_t)nr + 1, 256);
+    PlanTrace tr;
     DevBuf flag, hlen, bad, clen;
     CSRK_TRY(flag.alloc((size_t)(nr + 2) * 4));
     CSRK_TRY(hlen.alloc((size_t)(nr + 2) * 8));
@@ -851,9 +878,10 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     CSRK_TRY(exclusive_scan_i64(hlen.as<int64_t>(), hlen.as<int64_t>(), nr, s));      // -> cut entries before
     int32_t n_cut = 0;
     int64_t nnz_cut = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_cut, flag.as<int32_t>() + nr, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(&nnz_cut, hlen.as<int64_t>() + nr, 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(&n_cut, flag.as<int32_t>() + nr, 4, s));
+    CSRK_TRY(stage_d2h(&nnz_cut, hlen.as<int64_t>() + nr, 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
+    tr.lap("  split: flags + scans");
     if (n_cut == 0) return CSRK_OK;
 
     CSRK_TRY(p->rp_light.alloc((size_t)(nr + 1) * sizeof(P)));
@@ -870,13 +898,16 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     heavy_sorted_kernel<P><<<(unsigned)n_cut, 1024, 0, s>>>(rp, m->d_colinds, p->heavy_row.as<int32_t>(), n_cut,
                                                          bad.as<int32_t>());
     CSRK_LAUNCH_CHECK();
+    tr.lap("  split: view + sorted kernels");
     int32_t is_bad = 0;
     std::vector<int32_t> rows((size_t)n_cut);
     std::vector<int64_t> lens((size_t)n_cut);
-    CSRK_HIP(hipMemcpyAsync(&is_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(rows.data(), p->heavy_row.p, (size_t)n_cut * 4, hipMemcpyDeviceToHost, s));
-    CSRK_HIP(hipMemcpyAsync(lens.data(), clen.p, (size_t)n_cut * 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(&is_bad, bad.p, 4, s));
+    CSRK_TRY(stage_d2h(rows.data(), p->heavy_row.p, (size_t)n_cut * 4, s));
+    CSRK_TRY(stage_d2h(lens.data(), clen.p, (size_t)n_cut * 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
+    if (tr.on) fprintf(stderr, "[csrk plan]   n_cut %d\n", n_cut);
+    tr.lap("  split: copies to the host");
     if (is_bad) return CSRK_OK;      // unsorted columns in a long row: column blocking needs order
 
     // tier 0: accumulator form (groups of <= ACC_MAXROWS rows).  The accumulator form costs 1.8 ps per entry against 4.8 for tier 1 (measured, headline matrix), and
@@ -922,6 +953,7 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     p->t0_lens = len0;
     p->t1_rows = r1;
     p->t1_nnz = nnz1;
+    tr.lap("  split: host lists");
     return CSRK_OK;
 }
 
@@ -987,7 +1019,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
         row_stride, cnt.as<int32_t>(), census.as<unsigned long long>());
     CSRK_LAUNCH_CHECK();
     unsigned long long n_samples_u = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_samples_u, census.p, 8, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(&n_samples_u, census.p, 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
     const int64_t n_samples = (int64_t)n_samples_u;
     if (n_samples == 0) return CSRK_OK;
@@ -996,7 +1028,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
         CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
         hot_census_kernel<<<1024, 256, 0, s>>>(cnt.as<int32_t>(), nc, thr, census.as<unsigned long long>());
         CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(out, census.p, 16, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(out, census.p, 16, s));
         CSRK_HIP(hipStreamSynchronize(s));
         return CSRK_OK;
     };
@@ -1012,7 +1044,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
                                              hist.as<unsigned long long>() + (HOT_HIST + 1));
         CSRK_LAUNCH_CHECK();
         std::vector<unsigned long long> hh((size_t)2 * (HOT_HIST + 1));
-        CSRK_HIP(hipMemcpyAsync(hh.data(), hist.p, hh.size() * 8, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(hh.data(), hist.p, hh.size() * 8, s));
         CSRK_HIP(hipStreamSynchronize(s));
         const unsigned long long *hn = hh.data(), *hs = hh.data() + (HOT_HIST + 1);
         if (hn[HOT_HIST] <= (unsigned long long)HOT_SLOTS) {
@@ -1065,8 +1097,8 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_LAUNCH_CHECK();
     {
         std::vector<int32_t> hc((size_t)n_hot), hn((size_t)n_hot), ord((size_t)n_hot), sorted((size_t)n_hot);
-        CSRK_HIP(hipMemcpyAsync(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
-        CSRK_HIP(hipMemcpyAsync(hn.data(), hcnt.p, (size_t)n_hot * 4, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, s));
+        CSRK_TRY(stage_d2h(hn.data(), hcnt.p, (size_t)n_hot * 4, s));
         CSRK_HIP(hipStreamSynchronize(s));
         // stable, count descending: two 16-bit LSD radix passes over the complemented count (a comparison sort of
         // 4 * 10^5 indices through a lambda took tens of ms of the plan)
@@ -1087,7 +1119,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
             }
         }
         for (int32_t i = 0; i < n_hot; i++) sorted[(size_t)i] = hc[(size_t)ord[(size_t)i]];
-        CSRK_HIP(hipMemcpyAsync(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, hipMemcpyHostToDevice, s));
+        CSRK_TRY(stage_h2d(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, s));
         CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
     }
     // column -> slot map (-1: not packed); the light stream's fill reads it, as does the renumbered colinds copy
@@ -1122,7 +1154,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i32(ridx.as<int32_t>(), ridx.as<int32_t>(), nrows_view, s));
     int32_t n_runs = 0;
-    CSRK_HIP(hipMemcpyAsync(&n_runs, ridx.as<int32_t>() + nrows_view, 4, hipMemcpyDeviceToHost, s));
+    CSRK_TRY(stage_d2h(&n_runs, ridx.as<int32_t>() + nrows_view, 4, s));
     CSRK_HIP(hipStreamSynchronize(s));
     if (n_runs < 1) return CSRK_OK;
     if (!ls->dense) {
@@ -1319,7 +1351,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         nround = nround_ls + 1;      // + the virtual round of the packed columns
         nb = nround * nblk;
         if (nb > nb_max) return CSRK_ERR_INVALID;      // (cannot happen: a round holds at least LS_STAGE_TILES or NW tiles)
-        CSRK_HIP(hipMemcpyAsync(d_rt0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
+        CSRK_TRY(stage_h2d(d_rt0.p, h_rt0.data(), h_rt0.size() * 4, s));
         ls_tile_round_kernel<<<(unsigned)ceil_div(ls->n_tiles, 256), 256, 0, s>>>(d_rt0.as<int32_t>(), (int32_t)nround_ls, ls->n_tiles,
                                                                                 tile_round.as<int32_t>());
         CSRK_LAUNCH_CHECK();
@@ -1335,7 +1367,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         ls_round_total_kernel<<<(unsigned)ceil_div(nround_ls + 1, 256), 256, 0, s>>>(tot.as<int64_t>(), (int32_t)nround_ls, (int32_t)nblk,
                                                                                    drs.as<int64_t>());
         CSRK_LAUNCH_CHECK();
-        CSRK_HIP(hipMemcpyAsync(rs.data(), drs.p, (size_t)(nround_ls + 1) * 8, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(rs.data(), drs.p, (size_t)(nround_ls + 1) * 8, s));
         CSRK_HIP(hipStreamSynchronize(s));
         n_cold = rs[(size_t)nround_ls];
         *max_round = 0;
@@ -1383,8 +1415,8 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->round_tile0.alloc(h_rt0.size() * 4));
     CSRK_TRY(ls->wg_round0.alloc(h_wr0.size() * 4));
-    CSRK_HIP(hipMemcpyAsync(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, hipMemcpyHostToDevice, s));
-    CSRK_HIP(hipMemcpyAsync(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, hipMemcpyHostToDevice, s));
+    CSRK_TRY(stage_h2d(ls->round_tile0.p, h_rt0.data(), h_rt0.size() * 4, s));
+    CSRK_TRY(stage_h2d(ls->wg_round0.p, h_wr0.data(), h_wr0.size() * 4, s));
     ls_cold_place_kernel<<<gw, 256, 0, s>>>(ls->idx.as<uint32_t>(), n_words, (int32_t)nround, (int32_t)nblk, (int32_t)W,
                                            tile_round.as<int32_t>(), 1, cnt.as<int32_t>(), cntT.as<int32_t>(), off.as<int32_t>(),
                                            ls->a_col.as<uint16_t>(), ls->a_dst.as<int32_t>());
@@ -1444,7 +1476,7 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
         CSRK_LAUNCH_CHECK();
         CSRK_TRY(exclusive_scan_i32(nz.as<int32_t>(), nz.as<int32_t>(), m->nrows, s));
         int32_t n_nonempty = 0;
-        CSRK_HIP(hipMemcpyAsync(&n_nonempty, nz.as<int32_t>() + m->nrows, 4, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(&n_nonempty, nz.as<int32_t>() + m->nrows, 4, s));
         CSRK_HIP(hipStreamSynchronize(s));
         const int64_t n_pad = (int64_t)m->nrows - n_nonempty;
         const bool fits = sizeof(P) == 8 || n_view + n_pad <= (int64_t)INT32_MAX;
@@ -1468,32 +1500,6 @@ static int build_light_stream(Matrix *m, SpmvPlan *p, hipStream_t s)
     }
     return CSRK_OK;
 }
-
-struct PlanTrace {
-    bool on;
-    double t0;
-    static double now()
-    {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-    }
-    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
-    {
-        if (on) {
-            (void)hipDeviceSynchronize();
-            t0 = now();
-        }
-    }
-    void lap(const char *what)
-    {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const double t = now();
-        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
-        t0 = t;
-    }
-};
 
 template <class P>
 static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
@@ -1548,7 +1554,7 @@ static int build_plan(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_split)
         }
         CSRK_TRY(exclusive_scan_i64(p->seg_off.as<int64_t>(), p->seg_off.as<int64_t>(), m->nrows, s));
         int64_t n_segs = 0;
-        CSRK_HIP(hipMemcpyAsync(&n_segs, p->seg_off.as<int64_t>() + m->nrows, 8, hipMemcpyDeviceToHost, s));
+        CSRK_TRY(stage_d2h(&n_segs, p->seg_off.as<int64_t>() + m->nrows, 8, s));
         CSRK_HIP(hipStreamSynchronize(s));
         p->n_segs = n_segs;
         CSRK_TRY(p->seg_row.alloc((size_t)n_segs * 4));
