@@ -430,45 +430,74 @@ __device__ __forceinline__ int64_t acc_phys_tile(int64_t t, const int64_t *__res
     return (t - wg_t0[lo]) * n_wg + lo;
 }
 
-// one thread per (block, heavy row) pair: copies the pair's entries into the tiled stream (after the padding
-// entries that bridge a long step)
+// One wavefront per 64 consecutive (block, heavy row) pairs of ONE block: their slots are one contiguous range of the
+// block's logical stream, walked 64 slots at a time -- a slot finds its pair by bisection in the wavefront's own table of
+// pair starts, a padding slot (the first ones of a pair whose row lies more than ACC_MAXSTEP rows after the previous one)
+// writes (0.0, zero slot, step 7), the others copy the pair's entries -- so the stream is written by consecutive lanes and
+// every lane works.  (A thread per pair walking its 3.6 entries one after the other wrote and read 64 scattered lines
+// per instruction: 6.9 ms of the headline matrix's plan, its largest item; this form 2.7.)
 template <class P, int VT>
-__global__ void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks, int32_t cb,
-                                const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
-                                const int32_t *__restrict__ pstart, const int32_t *__restrict__ gap,
-                                double *__restrict__ pvals, uint16_t *__restrict__ pidx, int32_t *__restrict__ tile_row0,
-                                const int64_t *__restrict__ wg_t0, int32_t n_wg)
+__global__ __launch_bounds__(256) void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                      const void *__restrict__ vs, const int32_t *__restrict__ heavy_row,
+                                                      int32_t n_heavy, int32_t n_blocks, int32_t cb,
+                                                      const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
+                                                      const int32_t *__restrict__ pstart, const int32_t *__restrict__ gap,
+                                                      double *__restrict__ pvals, uint16_t *__restrict__ pidx,
+                                                      int32_t *__restrict__ tile_row0, const int64_t *__restrict__ wg_t0,
+                                                      int32_t n_wg, int32_t waves_per_block)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
-    const int64_t n_all = off[i + 1] - off[i];
-    if (n_all == 0) return;
-    const int32_t g = gap[i];
-    const int32_t npad = g > ACC_MAXSTEP ? (g - 1) / ACC_MAXSTEP : 0;
-    const int64_t n = n_all - npad;
-    const int32_t r = heavy_row[c];
-    const int64_t lo = (int64_t)rp[r] + pstart[i];
-    int64_t L = blk_tile0[b] * ACC_TILE + (off[i] - off[(int64_t)b * n_heavy]);      // logical position
-    int64_t t_of = -1, pt = 0;                                 // the logical tile last looked up and where it is stored
-    for (int32_t k = 1; k <= npad; k++, L++) {                 // padding entry k stands on heavy row c - g + 7k
-        const int64_t t = L / ACC_TILE;
-        const int el = (int)(L % ACC_TILE);
-        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
-        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
-        if (el == 0) tile_row0[t] = c - g + ACC_MAXSTEP * k;
+    __shared__ int32_t s_start[256 / WAVE][WAVE];
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int32_t b = (int32_t)(w / waves_per_block);
+    if (b >= n_blocks) return;
+    const int32_t c0 = (int32_t)(w % waves_per_block) * WAVE, c = c0 + lane;
+    const bool valid = c < n_heavy;
+    const int64_t i = (int64_t)b * n_heavy + (valid ? c : c0);
+    const int64_t off_i = off[i];
+    int32_t n_all = 0, g = 0;
+    int64_t lo = 0;
+    if (valid) {
+        n_all = (int32_t)(off[i + 1] - off_i);
+        g = gap[i];
+        lo = (int64_t)rp[heavy_row[c]] + pstart[i];
     }
-    int32_t step = g - ACC_MAXSTEP * npad;                     // first entry: from the previous row (or padding) to c
-    for (int64_t k = lo; k < lo + n; k++, L++) {
+    const int32_t npad = g > ACC_MAXSTEP ? (g - 1) / ACC_MAXSTEP : 0;
+    const int32_t start = wave_exscan_i32(n_all, lane);
+    const int32_t total = __builtin_amdgcn_readlane(start + n_all, WAVE - 1);
+    if (total == 0) return;
+    // logical position of the wavefront's first slot (lane 0's pair: c0 < n_heavy)
+    const int64_t L0 = blk_tile0[b] * ACC_TILE + (__shfl(off_i, 0, WAVE) - off[(int64_t)b * n_heavy]);
+    int32_t *starts = s_start[wv];
+    starts[lane] = start;
+    __builtin_amdgcn_wave_barrier();
+    for (int32_t d0 = 0; d0 < total; d0 += WAVE) {
+        const int32_t d = d0 + lane;
+        const bool in = d < total;
+        int p = 0;                                   // the last pair that starts at or before slot d (an empty pair shares its
+#pragma unroll                                       // start with the next one: the last of them is the one with entries)
+        for (int step = WAVE / 2; step; step >>= 1)
+            if (in && starts[p + step] <= d) p += step;
+        const int32_t at = d - __shfl(start, p, WAVE);      // slot inside the pair
+        const int32_t npad_p = __shfl(npad, p, WAVE), g_p = __shfl(g, p, WAVE);
+        const int64_t lo_p = __shfl(lo, p, WAVE);
+        if (!in) continue;
+        const int64_t L = L0 + d;
         const int64_t t = L / ACC_TILE;
         const int el = (int)(L % ACC_TILE);
-        if (t != t_of) pt = acc_phys_tile(t_of = t, wg_t0, n_wg);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
-        pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? (uint32_t)step : 0u) << ACC_ROW_SHIFT));
-        if (el == 0) tile_row0[t] = c;
-        step = 0;
+        const int64_t pt = acc_phys_tile(t, wg_t0, n_wg);
+        if (at < npad_p) {                           // padding entry k = at + 1 stands on heavy row c - g + 7k
+            pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
+            pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
+            if (el == 0) tile_row0[t] = c0 + p - g_p + ACC_MAXSTEP * (at + 1);
+        } else {
+            const int64_t k = lo_p + (at - npad_p);
+            // the pair's first entry: the step from the previous row (or the last padding entry) to this row
+            const uint32_t step_in = at == npad_p ? (uint32_t)(g_p - ACC_MAXSTEP * npad_p) : 0u;
+            pvals[pt * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
+            pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? step_in : 0u) << ACC_ROW_SHIFT));
+            if (el == 0) tile_row0[t] = c0 + p;
+        }
     }
 }
 
@@ -774,10 +803,11 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * 8));
     CSRK_TRY(ap->idx.alloc((size_t)n_phys * ACC_TILE * 2));
     CSRK_TRY(ap->tile_row0.alloc((size_t)(n_tiles ? n_tiles : 1) * 4));
-    acc_fill_kernel<P, VT><<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(
+    const int32_t fill_waves = (int32_t)ceil_div(n, WAVE);      // wavefronts per block: 64 pairs each
+    acc_fill_kernel<P, VT><<<(unsigned)ceil_div((int64_t)nb * fill_waves * WAVE, 256), 256, 0, s>>>(
         rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
         pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(),
-        d_wg_t0.as<int64_t>(), (int32_t)n_wg);
+        d_wg_t0.as<int64_t>(), (int32_t)n_wg, fill_waves);
     CSRK_LAUNCH_CHECK();
     acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
                                                ap->idx.as<uint16_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg);
