@@ -37,34 +37,58 @@ __global__ void merge_plan_kernel(const P *__restrict__ rp, int32_t nrows, int64
 // only need dword alignment, so two consecutive colinds / values are fetched with one
 // dwordx2 / dwordx4 load per lane (512 B / 1 KiB per wave-instruction).
 // ---- hot-column cache: plan-time kernels ------------------------------------------------------------
-// Column reference counts over the rows the tile kernel serves, from every `row_stride`-th row and at
-// most 128 entries of it (a sample is enough to rank popularity); total[0] = entries counted.
+// Column reference counts over the rows the tile kernel serves, from every `row_stride`-th GROUP of 64 consecutive rows
+// and at most 128 entries of a row (a sample is enough to rank popularity); total[0] = entries counted.  One wavefront per
+// group: the rows' kept entries are one run of colinds (but for the rows cut out to the tiers), walked 64 at a time by
+// consecutive lanes -- an entry finds its row by bisection in the wavefront's table of row starts.  (A thread per row
+// walking its entries one after the other waited out a memory round trip per entry with two workgroups on a CU: 2.8 ms of
+// the headline matrix's plan, its largest item.)
 // Popular columns collect millions of these increments: as global atomics they serialise (14 ms for the 4*10^7
 // sampled entries of the headline matrix).  Each persistent workgroup therefore counts into an LDS hash table
 // first (a column that finds a slot within HOT_PROBE probes stays there; the others go straight to memory) and
 // flushes its <= HOT_TABLE distinct columns once at the end.
 constexpr int HOT_TABLE = 8192, HOT_PROBE = 4;
+constexpr int HOT_THREADS = 512;
 template <class P>
-__global__ __launch_bounds__(256) void hot_count_kernel(const P *__restrict__ rp, const P *__restrict__ rp_light,
-                                                       const int32_t *__restrict__ ci, int32_t nrows, int64_t row_stride,
-                                                       int32_t *__restrict__ cnt, unsigned long long *__restrict__ total)
+__global__ __launch_bounds__(HOT_THREADS) void hot_count_kernel(const P *__restrict__ rp, const P *__restrict__ rp_light,
+                                                               const int32_t *__restrict__ ci, int32_t nrows, int64_t row_stride,
+                                                               int32_t *__restrict__ cnt, unsigned long long *__restrict__ total)
 {
     __shared__ int32_t s_key[HOT_TABLE];
     __shared__ int32_t s_cnt[HOT_TABLE];
-    for (int k = threadIdx.x; k < HOT_TABLE; k += 256) {
+    __shared__ int32_t s_start[HOT_THREADS / WAVE][WAVE];
+    for (int k = threadIdx.x; k < HOT_TABLE; k += HOT_THREADS) {
         s_key[k] = -1;
         s_cnt[k] = 0;
     }
     __syncthreads();
-    const int64_t n_sampled = (nrows + row_stride - 1) / row_stride;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    int32_t *starts = s_start[wv];
+    const int64_t n_groups = ((int64_t)nrows + WAVE * row_stride - 1) / (WAVE * row_stride);
     unsigned long long n = 0;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_sampled; q += (int64_t)gridDim.x * 256) {
-        const int64_t r = q * row_stride;
-        if (rp_light && rp_light[r + 1] == rp_light[r]) continue;      // a row cut out to the tiers
-        const int64_t s = rp[r];
-        int64_t e = rp[r + 1];
-        e = e - s > 128 ? s + 128 : e;
-        for (int64_t k = s; k < e; k++) {
+    for (int64_t q = (int64_t)blockIdx.x * (HOT_THREADS / WAVE) + wv; q < n_groups; q += (int64_t)gridDim.x * (HOT_THREADS / WAVE)) {
+        const int64_t r = q * WAVE * row_stride + lane;
+        int64_t s = 0;
+        int32_t len = 0;
+        if (r < nrows && !(rp_light && rp_light[r + 1] == rp_light[r])) {      // (not a row cut out to the tiers)
+            s = rp[r];
+            const int64_t l = (int64_t)rp[r + 1] - s;
+            len = (int32_t)(l > 128 ? 128 : l);
+        }
+        const int32_t start = wave_exscan_i32(len, lane);
+        const int32_t all = __builtin_amdgcn_readlane(start + len, WAVE - 1);
+        __builtin_amdgcn_wave_barrier();             // (the group before has read its starts)
+        starts[lane] = start;
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t d0 = 0; d0 < all; d0 += WAVE) {
+            const int32_t d = d0 + lane;
+            const bool in = d < all;
+            int p = 0;                               // the last row that starts at or before d (the one with entries there)
+#pragma unroll
+            for (int step = WAVE / 2; step; step >>= 1)
+                if (in && starts[p + step] <= d) p += step;
+            const int64_t k = __shfl(s, p, WAVE) + (d - __shfl(start, p, WAVE));
+            if (!in) continue;
             const int32_t c = ci[k];
             uint32_t slot = ((uint32_t)c * 2654435761u) >> 19;      // 13 bits
             bool done = false;
@@ -79,10 +103,10 @@ __global__ __launch_bounds__(256) void hot_count_kernel(const P *__restrict__ rp
             }
             if (!done) atomicAdd(&cnt[c], 1);
         }
-        n += (unsigned long long)(e - s);
+        if (lane == 0) n += (unsigned long long)all;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < HOT_TABLE; k += 256)
+    for (int k = threadIdx.x; k < HOT_TABLE; k += HOT_THREADS)
         if (s_key[k] >= 0) atomicAdd(&cnt[s_key[k]], s_cnt[k]);
     for (int off = WAVE / 2; off; off >>= 1) n += __shfl_down(n, off, WAVE);
     if ((threadIdx.x & (WAVE - 1)) == 0 && n) atomicAdd(total, n);
@@ -1043,8 +1067,8 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(nc + 1) * 4, s));
     CSRK_HIP(hipMemsetAsync(census.p, 0, 16, s));
     const int64_t row_stride = p->nnz_light > (1ll << 25) ? p->nnz_light >> 25 : 1;
-    const int64_t hc_need = ceil_div(ceil_div(m->nrows, row_stride), 256);
-    hot_count_kernel<P><<<(unsigned)(hc_need < 2048 ? hc_need : 2048), 256, 0, s>>>(
+    const int64_t hc_need = ceil_div(ceil_div(m->nrows, WAVE * row_stride), HOT_THREADS / WAVE);
+    hot_count_kernel<P><<<(unsigned)(hc_need < 1024 ? hc_need : 1024), HOT_THREADS, 0, s>>>(
         (const P *)m->d_rowptrs, p->n_heavy ? p->rp_light.as<P>() : (const P *)nullptr, m->d_colinds, m->nrows,
         row_stride, cnt.as<int32_t>(), census.as<unsigned long long>());
     CSRK_LAUNCH_CHECK();
