@@ -470,8 +470,48 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #undef PANEL_LOAD_TILE
 }
 
-template <int CB, int PT, bool R32 = false>
-__global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__ pvals, const uint16_t *__restrict__ pidx,
+// a lane's eight values of a tile: float64 four 16-B loads, float32 (a float32 matrix's stream) two, widened on use
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <class SV> struct AccVals;
+template <> struct AccVals<double> {
+    f64x2_t v[4];
+    __device__ __forceinline__ void load(const double *tile, int lane)
+    {
+        const f64x2_t *vp = (const f64x2_t *)tile;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+    }
+    __device__ __forceinline__ void get(double (&a)[ACC_K]) const
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a[2 * q] = v[q].x;
+            a[2 * q + 1] = v[q].y;
+        }
+    }
+};
+template <> struct AccVals<float> {
+    f32x4_t v[2];
+    __device__ __forceinline__ void load(const float *tile, int lane)
+    {
+        const f32x4_t *vp = (const f32x4_t *)tile;
+#pragma unroll
+        for (int q = 0; q < 2; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+    }
+    __device__ __forceinline__ void get(double (&a)[ACC_K]) const
+    {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            a[4 * q] = (double)v[q].x;
+            a[4 * q + 1] = (double)v[q].y;
+            a[4 * q + 2] = (double)v[q].z;
+            a[4 * q + 3] = (double)v[q].w;
+        }
+    }
+};
+
+template <int CB, int PT, bool R32 = false, class SV = double>
+__global__ __launch_bounds__(PT) void spmv_acc_kernel(const SV *__restrict__ pvals, const uint16_t *__restrict__ pidx,
                                                      const int32_t *__restrict__ tile_row0,
                                                      const double *__restrict__ x, int32_t ncols,
                                                      const AccSeg *__restrict__ segs, const int32_t *__restrict__ wg_seg,
@@ -514,32 +554,29 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
         __syncthreads();      // A: window stored; heads of the previous segment folded in; accumulators zeroed
 
         const int nt = sg.ntiles;
-        f64x2_t v[4], vn[4];
+        AccVals<SV> v, vn;
         u32x4_t ix, ixn;                  // eight 16-bit index words per lane
         int32_t tr0 = 0, tr0n = 0;        // heavy-row index of the tile's first entry
         int t = wv;
         const int64_t pstep = (int64_t)gridDim.x;      // the workgroups' tiles are interleaved (acc_phys_tile)
         if (t < nt) {
-            const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.ptile0 + t * pstep) * ACC_TILE);
             const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.ptile0 + t * pstep) * ACC_TILE);
-#pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+            v.load(pvals + (sg.ptile0 + t * pstep) * ACC_TILE, lane);
             ix = __builtin_nontemporal_load(ip + lane);
             tr0 = tile_row0[sg.tile0 + t];
         }
         for (; t < nt; t += NW) {
             const bool more = t + NW < nt;
             if (more) {      // next tile's loads are in flight while this one is reduced
-                const f64x2_t *vp = (const f64x2_t *)(pvals + (sg.ptile0 + (t + NW) * pstep) * ACC_TILE);
                 const u32x4_t *ip = (const u32x4_t *)(pidx + (sg.ptile0 + (t + NW) * pstep) * ACC_TILE);
-#pragma unroll
-                for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+                vn.load(pvals + (sg.ptile0 + (t + NW) * pstep) * ACC_TILE, lane);
                 ixn = __builtin_nontemporal_load(ip + lane);
                 tr0n = tile_row0[sg.tile0 + t + NW];
             }
             const uint32_t e[ACC_K] = {ix.x & 0xffffu, ix.x >> 16, ix.y & 0xffffu, ix.y >> 16,
                                        ix.z & 0xffffu, ix.z >> 16, ix.w & 0xffffu, ix.w >> 16};
-            const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+            double a[ACC_K];
+            v.get(a);
             double xv[ACC_K];
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) xv[j] = s_x[e[j] & ACC_COL_MASK];
@@ -609,8 +646,7 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const double *__restrict__
                 }
             }
             if (more) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = vn[q];
+                v = vn;
                 ix = ixn;
                 tr0 = tr0n;
             }
@@ -716,9 +752,9 @@ __global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs
 // the round's range is read by gathers).  Two workgroup barriers per round.
 // DENSE: run k is row k (LightStream::dense): row ids are not loaded and there are no gaps between runs to clear.
 constexpr int LS_PLAIN = 0, LS_RND = 2;
-template <int MODE, bool DENSE = false, bool R32 = false>
+template <int MODE, bool DENSE = false, bool R32 = false, class SV = double>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
-    const double *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
+    const SV *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
     const int32_t *__restrict__ tile_base, const double *__restrict__ x,
     const double *__restrict__ xh, int32_t n_lds, int64_t n_tiles, int32_t n_runs, int32_t nrows,
     double *__restrict__ y, int32_t *__restrict__ carry_row, double *__restrict__ carry_val,
@@ -753,7 +789,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         return (R_ + 1) * NW < n_tiles ? (R_ + 1) * NW : n_tiles;
     };
     const int64_t wave0 = R_begin < R_end ? round_t0(R_begin) + wv : n_tiles;
-    f64x2_t v[4], vn[4];
+    AccVals<SV> v, vn;
     u32x4_t ix[2], ixn[2];
     int32_t tb = 0, tbn = 0;
     constexpr int RQ = LS_RND_CAP / 2 / LS_THREADS;      // RND: 16-B loads per thread that cover a round's staged values
@@ -772,10 +808,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     if (RND && R_begin < R_end) round_request(R_begin);
     int64_t t = wave0;
     if (R_begin < R_end && t < round_t1(R_begin)) {
-        const f64x2_t *vp = (const f64x2_t *)(svals + t * ACC_TILE);
         const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+        v.load(svals + t * ACC_TILE, lane);
 #pragma unroll
         for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
         tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
@@ -801,7 +835,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             }
         }
         const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
-        const double a[ACC_K] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+        double a[ACC_K];
+        v.get(a);
         // Issue order matters: vmcnt retires loads in issue order, so whatever is requested BEFORE the loads this tile
         // waits for is waited for too.  This tile's own loads (staged values / gathers, row ids) therefore go first and
         // the next tile's stream loads -- HBM latency -- are requested after them and stay in flight across the whole
@@ -846,13 +881,11 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             // last tile re-requests itself): behind an `if (more)` the compiler cannot count the loads in flight at the
             // join and waits for all of them (s_waitcnt vmcnt(0)) before this tile's first multiply.
             const int64_t tn = t_next;
-            const f64x2_t *vp = (const f64x2_t *)(svals + tn * ACC_TILE);
             const u32x4_t *ip = (const u32x4_t *)(sidx + tn * ACC_TILE);
             // (index words first: the next tile's gathers need them at its very top, the values only at its multiplies)
 #pragma unroll
             for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
-#pragma unroll
-            for (int q = 0; q < 4; q++) vn[q] = __builtin_nontemporal_load(vp + q * WAVE + lane);
+            vn.load(svals + tn * ACC_TILE, lane);
             tbn = tile_base[tn];
         }
         asm volatile("" ::: "memory");
@@ -988,8 +1021,7 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         if (!DENSE && total >= 1 && tb - 1 + total == n_runs - 1) {       // the matrix's last run: the rows after it are this tile's too
             for (int64_t q = (int64_t)rowids[n_runs - 1] + 1 + lane; q < nrows; q += WAVE) y[q] = 0.0;
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = vn[q];
+        v = vn;
 #pragma unroll
         for (int q = 0; q < 2; q++) ix[q] = ixn[q];
         tb = __builtin_amdgcn_readfirstlane(tbn);
@@ -1146,7 +1178,13 @@ int spmv_kernel_attributes()
                           (const void *)spmv_lstream_kernel<LS_RND>, (const void *)spmv_lstream_kernel<LS_PLAIN, true>,
                           (const void *)spmv_lstream_kernel<LS_RND, true>, (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true>,
                           (const void *)spmv_lstream_kernel<LS_PLAIN, false, true>, (const void *)spmv_lstream_kernel<LS_RND, false, true>,
-                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true>, (const void *)spmv_lstream_kernel<LS_RND, true, true>})
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true>, (const void *)spmv_lstream_kernel<LS_RND, true, true>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, false, float>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true, float>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, false, false, float>, (const void *)spmv_lstream_kernel<LS_RND, false, false, float>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, false, float>, (const void *)spmv_lstream_kernel<LS_RND, true, false, float>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, false, true, float>, (const void *)spmv_lstream_kernel<LS_RND, false, true, float>,
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true, float>, (const void *)spmv_lstream_kernel<LS_RND, true, true, float>})
         CSRK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
     return CSRK_OK;
@@ -1276,9 +1314,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
-                spmv_acc_kernel<ACC_CB, ACC_THREADS, R32><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
-                    ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols, ap->segs.as<AccSeg>(),
-                    ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
+                if (ap->f32)
+                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32, float><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
+                        ap->vals.as<float>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols,
+                        ap->segs.as<AccSeg>(), ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
+                else
+                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
+                        ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols,
+                        ap->segs.as<AccSeg>(), ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
                 CSRK_LAUNCH_CHECK();
             }
             kh.stop();
@@ -1315,22 +1358,28 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                     x_cold = p->ls.xg.as<double>();
                     x_pack = x_cold + p->ls.n_cold;
                 }
-#define LS_ARGS                                                                                                       \
-    p->ls.vals.as<double>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),      \
+#define LS_ARGS(SV)                                                                                                   \
+    p->ls.vals.as<SV>(), p->ls.idx.as<uint32_t>(), p->ls.rowids.as<int32_t>(), p->ls.tile_base.as<int32_t>(),          \
         x_cold, x_pack, p->n_hot_lds, p->ls.n_tiles, p->ls.n_runs, p->ls.n_out, d_y,         \
         p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>()
                 constexpr size_t rnd_lds = ((size_t)LS_RND_HOT + LS_RND_CAP + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
                 const int32_t *nil = nullptr;
-#define LS_GO(D)                                                                                                       \
+#define LS_GO(D, SV)                                                                                                   \
     do {                                                                                                               \
         if (p->ls.n_cold && p->ls.round_start.p)                                                                       \
-            spmv_lstream_kernel<LS_RND, D, R32><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                                    \
-                LS_ARGS, p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(), p->ls.wg_round0.as<int32_t>()); \
+            spmv_lstream_kernel<LS_RND, D, R32, SV><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                           \
+                LS_ARGS(SV), p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(),                         \
+                p->ls.wg_round0.as<int32_t>());                                                                        \
         else                                                                                                           \
-            spmv_lstream_kernel<LS_PLAIN, D, R32><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS, nil, nil, nil);           \
+            spmv_lstream_kernel<LS_PLAIN, D, R32, SV><<<p->ls.grid, LS_THREADS, ls_lds, s>>>(LS_ARGS(SV), nil, nil, nil); \
     } while (0)
-                if (p->ls.dense) LS_GO(true);
-                else LS_GO(false);
+                if (p->ls.f32) {
+                    if (p->ls.dense) LS_GO(true, float);
+                    else LS_GO(false, float);
+                } else {
+                    if (p->ls.dense) LS_GO(true, double);
+                    else LS_GO(false, double);
+                }
 #undef LS_GO
 #undef LS_ARGS
                 kl.stop();

@@ -73,6 +73,7 @@ struct AccPanel {
     int64_t tiles = 0, nnz = 0, n_segs = 0;
     size_t lds = 0;
     DevBuf row_list, vals, idx, tile_row0, segs, wg_seg, partial;      // idx: 16-bit words (column, row step)
+    bool f32 = false;      // vals holds float32 (a float32 matrix: 6 B per entry instead of 10; widening them in the kernel is exact)
 };
 
 // A light stream (see "short rows: the light stream"): a private tiled copy of a set of rows ("runs") plus
@@ -83,6 +84,7 @@ struct LightStream {
     int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
     unsigned grid = 0;
     DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
+    bool f32 = false;      // vals holds float32 (a float32 matrix: 8 B per entry instead of 12)
     // dense rows (build_light_stream): EVERY row of the view has a run -- a row without entries holds one padding entry --
     // so run k is row k: no row-id table (`rowids` stays empty), no gaps to clear
     bool dense = false;
@@ -267,6 +269,11 @@ __host__ __device__ __forceinline__ int acc_idx_slot(int e)
 {
     const int lane = e >> 3, j = e & 7;
     return (j >> 2) * (4 * WAVE) + lane * 4 + (j & 3);        // two 16-B loads per lane
+}
+// the same for a tile of values of type SV: float64 four 16-B loads per lane, float32 two
+template <class SV> __host__ __device__ __forceinline__ int acc_slot_of(int e)
+{
+    return sizeof(SV) == 8 ? acc_val_slot(e) : acc_idx_slot(e);
 }
 
 // The merge-path tile kernel spends ~600 vector instructions per wavefront-tile on index arithmetic (clamped

@@ -460,13 +460,13 @@ __device__ __forceinline__ int64_t acc_phys_tile(int64_t t, const int64_t *__res
 // writes (0.0, zero slot, step 7), the others copy the pair's entries -- so the stream is written by consecutive lanes and
 // every lane works.  (A thread per pair walking its 3.6 entries one after the other wrote and read 64 scattered lines
 // per instruction: 6.9 ms of the headline matrix's plan, its largest item; this form 2.7.)
-template <class P, int VT>
+template <class P, int VT, class SV>
 __global__ __launch_bounds__(256) void acc_fill_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                                       const void *__restrict__ vs, const int32_t *__restrict__ heavy_row,
                                                       int32_t n_heavy, int32_t n_blocks, int32_t cb,
                                                       const int64_t *__restrict__ off, const int64_t *__restrict__ blk_tile0,
                                                       const int32_t *__restrict__ pstart, const int32_t *__restrict__ gap,
-                                                      double *__restrict__ pvals, uint16_t *__restrict__ pidx,
+                                                      SV *__restrict__ pvals, uint16_t *__restrict__ pidx,
                                                       int32_t *__restrict__ tile_row0, const int64_t *__restrict__ wg_t0,
                                                       int32_t n_wg, int32_t waves_per_block)
 {
@@ -511,14 +511,14 @@ __global__ __launch_bounds__(256) void acc_fill_kernel(const P *__restrict__ rp,
         const int el = (int)(L % ACC_TILE);
         const int64_t pt = acc_phys_tile(t, wg_t0, n_wg);
         if (at < npad_p) {                           // padding entry k = at + 1 stands on heavy row c - g + 7k
-            pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
+            pvals[pt * ACC_TILE + acc_slot_of<SV>(el)] = (SV)0.0;
             pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)cb | ((el ? (uint32_t)ACC_MAXSTEP : 0u) << ACC_ROW_SHIFT));
             if (el == 0) tile_row0[t] = c0 + p - g_p + ACC_MAXSTEP * (at + 1);
         } else {
             const int64_t k = lo_p + (at - npad_p);
             // the pair's first entry: the step from the previous row (or the last padding entry) to this row
             const uint32_t step_in = at == npad_p ? (uint32_t)(g_p - ACC_MAXSTEP * npad_p) : 0u;
-            pvals[pt * ACC_TILE + acc_val_slot(el)] = ValLoad<VT>::at(vs, k);
+            pvals[pt * ACC_TILE + acc_slot_of<SV>(el)] = (SV)ValLoad<VT>::at(vs, k);
             pidx[pt * ACC_TILE + el] = (uint16_t)((uint32_t)(ci[k] - b * cb) | ((el ? step_in : 0u) << ACC_ROW_SHIFT));
             if (el == 0) tile_row0[t] = c0 + p;
         }
@@ -527,8 +527,9 @@ __global__ __launch_bounds__(256) void acc_fill_kernel(const P *__restrict__ rp,
 
 // one workgroup per block: pads the block's last tile with (0.0, column slot ACC_CB (a zero in LDS), step 0 = the
 // block's last heavy row) -- a padding entry adds 0.0 * 0.0 to an accumulator
+template <class SV>
 __global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
-                                                     const int64_t *__restrict__ blk_tile0, double *__restrict__ pvals,
+                                                     const int64_t *__restrict__ blk_tile0, SV *__restrict__ pvals,
                                                      uint16_t *__restrict__ pidx, const int64_t *__restrict__ wg_t0, int32_t n_wg)
 {
     const int32_t b = blockIdx.x;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void acc_pad_kernel(const int64_t *__restrict_
     for (int64_t L = L0 + threadIdx.x; L < L1; L += blockDim.x) {      // (the tail of the block's last tile: one tile)
         const int64_t pt = acc_phys_tile(L / ACC_TILE, wg_t0, n_wg);
         const int el = (int)(L % ACC_TILE);
-        pvals[pt * ACC_TILE + acc_val_slot(el)] = 0.0;
+        pvals[pt * ACC_TILE + acc_slot_of<SV>(el)] = (SV)0.0;
         pidx[pt * ACC_TILE + el] = (uint16_t)ACC_CB;
     }
 }
@@ -586,10 +587,10 @@ __global__ void ls_rowids_kernel(const P *__restrict__ rpv, int32_t nrows, const
 
 // One thread per slot of the stream (n_ent entries, then padding to a whole tile): view entry L of view row r is the
 // source entry src[r] + (L - rpv[r]) (a view row is a whole row of the source or empty).
-template <class P, int VT>
+template <class P, int VT, class SV>
 __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
                                                      const int32_t *__restrict__ ci, const void *__restrict__ vs,
-                                                     int64_t n_ent, int64_t n_slots, const int32_t *__restrict__ slot_map, double *__restrict__ svals,
+                                                     int64_t n_ent, int64_t n_slots, const int32_t *__restrict__ slot_map, SV *__restrict__ svals,
                                                      uint32_t *__restrict__ sidx, const P *__restrict__ rp_len)
 {
     // rp_len (dense rows): the view's own row pointers; rpv then gives every row at least one slot, and a row that is
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
             if (L == first) ix |= LS_START_BIT;
         }
     }
-    svals[t * ACC_TILE + acc_val_slot(el)] = v;
+    svals[t * ACC_TILE + acc_slot_of<SV>(el)] = (SV)v;
     sidx[t * ACC_TILE + acc_idx_slot(el)] = ix;
 }
 
@@ -824,18 +825,26 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     DevBuf d_wg_t0;
     CSRK_TRY(d_wg_t0.alloc((size_t)(n_wg + 1) * 8));
     CSRK_TRY(stage_h2d(d_wg_t0.p, wg_t0.data(), (size_t)(n_wg + 1) * 8, s));
-    CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * 8));
+    // a float32 matrix keeps float32 values in the stream (6 B per entry; widened in the kernel, exactly)
+    ap->f32 = VT == CSRK_VAL_F32;
+    CSRK_TRY(ap->vals.alloc((size_t)n_phys * ACC_TILE * (ap->f32 ? 4 : 8)));
     CSRK_TRY(ap->idx.alloc((size_t)n_phys * ACC_TILE * 2));
     CSRK_TRY(ap->tile_row0.alloc((size_t)(n_tiles ? n_tiles : 1) * 4));
     const int32_t fill_waves = (int32_t)ceil_div(n, WAVE);      // wavefronts per block: 64 pairs each
-    acc_fill_kernel<P, VT><<<(unsigned)ceil_div((int64_t)nb * fill_waves * WAVE, 256), 256, 0, s>>>(
-        rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(), bends.as<int64_t>(),
-        pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(),
-        d_wg_t0.as<int64_t>(), (int32_t)n_wg, fill_waves);
-    CSRK_LAUNCH_CHECK();
-    acc_pad_kernel<<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<double>(),
-                                               ap->idx.as<uint16_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg);
-    CSRK_LAUNCH_CHECK();
+#define ACC_FILL(SV)                                                                                                   \
+    do {                                                                                                               \
+        acc_fill_kernel<P, VT, SV><<<(unsigned)ceil_div((int64_t)nb * fill_waves * WAVE, 256), 256, 0, s>>>(           \
+            rp, m->d_colinds, m->d_values, ap->row_list.as<int32_t>(), n, nb, ACC_CB, off.as<int64_t>(),               \
+            bends.as<int64_t>(), pstart.as<int32_t>(), gap.as<int32_t>(), ap->vals.as<SV>(), ap->idx.as<uint16_t>(),   \
+            ap->tile_row0.as<int32_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg, fill_waves);                            \
+        CSRK_LAUNCH_CHECK();                                                                                           \
+        acc_pad_kernel<SV><<<(unsigned)nb, 256, 0, s>>>(off.as<int64_t>(), n, nb, bends.as<int64_t>(), ap->vals.as<SV>(), \
+                                                        ap->idx.as<uint16_t>(), d_wg_t0.as<int64_t>(), (int32_t)n_wg); \
+        CSRK_LAUNCH_CHECK();                                                                                           \
+    } while (0)
+    if (ap->f32) ACC_FILL(float);
+    else ACC_FILL(double);
+#undef ACC_FILL
     std::vector<AccSeg> segs;
     std::vector<int32_t> wg_seg((size_t)n_wg + 1);
     int32_t b = 0;
@@ -1216,10 +1225,15 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
         ls_rowids_kernel<P><<<gr, 256, 0, s>>>(rpv, nrows_view, ridx.as<int32_t>(), ls->rowids.as<int32_t>());
         CSRK_LAUNCH_CHECK();
     }
-    CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * 8));
+    ls->f32 = VT == CSRK_VAL_F32;      // a float32 matrix keeps float32 values in the stream (widened in the kernel, exactly)
+    CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * (ls->f32 ? 4 : 8)));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
-    ls_fill_kernel<P, VT><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-        src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len);
+    if (ls->f32)
+        ls_fill_kernel<P, VT, float><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
+            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<float>(), ls->idx.as<uint32_t>(), rp_len);
+    else
+        ls_fill_kernel<P, VT, double><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
+            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len);
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
     ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(

@@ -555,3 +555,39 @@ def test_spmv_float32_vector(vals):
         # and it is NOT the float64 product: the two differ by ~1e-8 of the terms
         ref64 = O.mult_vec(m.nrows, m.ncols, m.rowptrs, m.colinds, m.values, x.astype(np.float64))
         assert np.max(np.abs(ref64 - ref)) > 1e-10
+
+
+def test_float32_matrix_keeps_float32_streams(split_mode):
+    """
+    A float32 matrix's plan stores float32 values in the tier-0 and light streams (6 and 8 bytes per entry instead of 10 and
+    12) and widens them in the kernels: the product with a float64 vector is bit for bit the product of the same matrix
+    with its values widened beforehand, and the plan is smaller.
+    """
+    if 'forced_split' not in split_mode:
+        pytest.skip('x of this small matrix fits in L2: no split unless forced')
+    import ctypes as C
+    from csr_amd._lib import lib, check
+    from csr_amd.kernels import hip as K
+    from csr_amd import CSR
+    rng = np.random.default_rng(2026)
+    lens = rng.integers(0, 25, size=5000)
+    lens[[3, 1500, 4100]] = [6000, 900, 2300]
+    m = _random_csr(rng, 5000, 50000, lens, dtype=np.float32, sort=True)
+    x = rng.uniform(-1, 1, size=m.ncols)
+    ys, bytes_tier0, bytes_light = [], [], []
+    for vals in (m.values, m.values.astype(np.float64)):
+        h = K.to_handle(CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, vals, _cast=False))
+        try:
+            K.mult_vec(h, x)
+            ys.append(K.mult_vec(h, x).copy())             # (the planned product)
+            st = (C.c_int64 * 34)()
+            check(lib.csrk_spmv_plan_stats(h.H, st, 34))
+            assert st[10] > 0                              # tier 0 holds entries
+            bytes_tier0.append(st[29])
+            bytes_light.append(st[31])
+        finally:
+            K.release_handle(h)
+    assert np.array_equal(ys[0].view(np.int64), ys[1].view(np.int64))
+    assert bytes_tier0[0] < 0.75 * bytes_tier0[1]
+    if 'nostream' not in split_mode:
+        assert 0 < bytes_light[0] < 0.8 * bytes_light[1]
