@@ -77,9 +77,12 @@ __device__ unsigned long long g_so_stamps[8];
 
 // The rows of at least SO_LEAST products, longest first: the workgroup kernels take a row each, and a 1.2 M-product row
 // started late is the kernel's whole tail (rows by the octave of their product count: `fill` false counts the octaves,
-// true places the rows behind the cursors the host made of the counts; inside an octave any order).
+// true places the rows behind the cursors the host made of the counts; inside an octave any order).  The count also
+// raises cursor[SO_OCTAVES] if some row will need its keys in memory (more than `cap` entries, or 2^32 products: only then
+// does the host allocate the key array).
 constexpr int SO_OCTAVES = 64;
 __global__ __launch_bounds__(256) void so_list_rows_kernel(const int64_t *__restrict__ tp, int32_t nrows, bool fill,
+                                                          const int32_t *__restrict__ c_rp, int32_t cap,
                                                           int32_t *__restrict__ cursor, int32_t *__restrict__ list)
 {
     __shared__ int32_t s_n[SO_OCTAVES], s_base[SO_OCTAVES];
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void so_list_rows_kernel(const int64_t *__rest
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool listed = r < nrows && tp[r] >= SO_LEAST;
     const int oct = listed ? __clzll((long long)tp[r]) : 0;      // (longest rows: fewest leading zeros)
+    if (!fill && listed && (tp[r] >= 0xffffffffll || c_rp[r + 1] - c_rp[r] > cap)) cursor[SO_OCTAVES] = 1;
     int32_t at = 0;
     if (listed) at = atomicAdd(&s_n[oct], 1);
     __syncthreads();
@@ -627,14 +631,13 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     if (n <= 1 || c->nrows == 0 || a->nnz == 0) return CSRK_OK;
     CSRK_REQUIRE(!c->ptr64 && c->val_type == CSRK_VAL_F64, "product has an unexpected layout");
     DevBuf key, tp, flag, oci, ovs, rows, cursor;
-    CSRK_TRY(key.alloc((size_t)n * 8));              // (written only by the rows that do not fit LDS)
     CSRK_TRY(tp.alloc((size_t)(a->nrows + 1) * 8));
     CSRK_TRY(flag.alloc(4));
     CSRK_TRY(rows.alloc((size_t)a->nrows * 4 + 4));
-    CSRK_TRY(cursor.alloc(SO_OCTAVES * 4));
+    CSRK_TRY(cursor.alloc((SO_OCTAVES + 1) * 4));
     CSRK_TRY(oci.alloc((size_t)n * 4));
     CSRK_TRY(ovs.alloc((size_t)n * 8));
-    CSRK_HIP(hipMemsetAsync(cursor.p, 0, SO_OCTAVES * 4, nullptr));
+    CSRK_HIP(hipMemsetAsync(cursor.p, 0, (SO_OCTAVES + 1) * 4, nullptr));
     CSRK_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
     // LDS of the 1024-thread walk (the device's own limit decides; 18 KB of it are the kernel's batch tables).  By column --
     // 4 B per column of C and a bit -- when that leaves a window of 2^15 product indices at least and no row of B can hold
@@ -662,8 +665,8 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     const unsigned gr = (unsigned)ceil_div(a->nrows, 256);
     const unsigned gs = (unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256);
     int32_t n_long = 0, n_mid = 0, n_small = 0;      // listed rows of at least SO_MID products (first in the list), SO_TINY, SO_LEAST
-    int32_t octaves[SO_OCTAVES];
-    unsigned long long *const key_p = key.as<unsigned long long>();
+    int32_t octaves[SO_OCTAVES + 1];                 // ([SO_OCTAVES]: some row needs its keys in memory)
+    unsigned long long *key_p = nullptr;
     int32_t *const oci_p = oci.as<int32_t>();
     double *const ovs_p = ovs.as<double>();
     unsigned int *const bad_p = flag.as<unsigned int>();
@@ -687,7 +690,7 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
             so_row_products_kernel<PA, PB, 16><<<(unsigned)ceil_div((int64_t)a->nrows * 16, 256), 256>>>(              \
                 (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, tp.as<int64_t>());         \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, false, cursor.as<int32_t>(), nullptr);            \
+        so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, false, c_rp, cap_long, cursor.as<int32_t>(), nullptr); \
         CSRK_LAUNCH_CHECK();                                                                                           \
         so_tiny_kernel<PA, PB, SO_LEAST><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
                                                       (const PB *)b->d_rowptrs, b->d_colinds, c_rp, c->d_colinds, c_vs, \
@@ -703,9 +706,14 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
             if (63 - o >= 8) n_mid = listed - n_long; /* (SO_TINY = 2^8) */                                            \
         }                                                                                                              \
         n_small = listed - n_long - n_mid;                                                                             \
+        if (octaves[SO_OCTAVES]) {                   /* (8 B per entry of C: only for the rows that do not fit LDS) */  \
+            CSRK_TRY(key.alloc((size_t)n * 8));                                                                        \
+            key_p = key.as<unsigned long long>();                                                                      \
+        }                                                                                                              \
         if (listed > 0) {                                                                                              \
             CSRK_HIP(hipMemcpyAsync(cursor.p, octaves, sizeof octaves, hipMemcpyHostToDevice, nullptr));               \
-            so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, true, cursor.as<int32_t>(), rows.as<int32_t>()); \
+            so_list_rows_kernel<<<gr, 256>>>(tp.as<int64_t>(), a->nrows, true, c_rp, cap_long, cursor.as<int32_t>(),   \
+                                             rows.as<int32_t>());                                                      \
             CSRK_LAUNCH_CHECK();                                                                                       \
         }                                                                                                              \
         if (n_long > 0) {                                                                                              \
@@ -729,7 +737,7 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c)
     }
 #undef ORDER
 #undef WALK_GO
-    if (n_long > 0) {                                // (the rows the walk left in key[]: the others leave at once)
+    if (n_long > 0 && key_p) {                       // (the rows the walk left in key[]: the others leave at once)
         CSRK_HIP(hipFuncSetAttribute((const void *)so_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
         so_place_kernel<<<(unsigned)n_long, SO_PLACE_THREADS, lds_place>>>(c_rp, c->d_colinds, c_vs, tp.as<int64_t>(),
                                                                            rows.as<int32_t>(), cap_long, key_p, oci_p, ovs_p, bad_p);
