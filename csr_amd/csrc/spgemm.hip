@@ -40,7 +40,7 @@ namespace csrk {
 
 int transpose_matrix(Matrix *a, int with_values, Matrix **out, hipStream_t s);   // transpose.hip
 bool spgemm_reference_order_wanted();                                            // spgemm_order.hip
-int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c);
+int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c, const DevBuf *products);
 
 struct MatView {
     const void *rp;
@@ -1575,7 +1575,7 @@ __global__ void sg_split_large(const int32_t *__restrict__ list, int32_t n_large
 }
 
 template <bool FAST>
-static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
+static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend, DevBuf *products)
 {
     CSRK_REQUIRE(a->ncols == b->nrows, "mult_ab: A is %d x %d but B is %d x %d", a->nrows, a->ncols, b->nrows, b->ncols);
     CSRK_REQUIRE(a->val_type != CSRK_VAL_NONE && b->val_type != CSRK_VAL_NONE,
@@ -1998,6 +1998,11 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
         return rc;
     }
     *out = c;
+    if (products) {                                  // the rows' product counts: the ordering pass needs them too
+        products->release();
+        products->bytes = ub.bytes;
+        products->p = ub.take();
+    }
     return CSRK_OK;
 }
 
@@ -2006,9 +2011,12 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 {
     const bool fast = !a->ptr64 && !b->ptr64 && a->val_type == CSRK_VAL_F64 && b->val_type == CSRK_VAL_F64;
-    CSRK_TRY(fast ? spgemm_run<true>(a, b, out, b_rows_ascend) : spgemm_run<false>(a, b, out, b_rows_ascend));
-    if (spgemm_reference_order_wanted()) {      // columns in the reference's reverse-discovery order (spgemm_order.hip)
-        const int rc = spgemm_apply_reference_order(a, b, *out);
+    const bool ordered = spgemm_reference_order_wanted();
+    DevBuf products;                            // products of every row of A B (int64), when the product kernels counted them
+    CSRK_TRY(fast ? spgemm_run<true>(a, b, out, b_rows_ascend, ordered ? &products : nullptr)
+                  : spgemm_run<false>(a, b, out, b_rows_ascend, ordered ? &products : nullptr));
+    if (ordered) {                              // columns in the reference's reverse-discovery order (spgemm_order.hip)
+        const int rc = spgemm_apply_reference_order(a, b, *out, &products);
         if (rc != CSRK_OK) {
             delete *out;
             *out = nullptr;
