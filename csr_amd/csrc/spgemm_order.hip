@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void so_row_products_kernel(const PA *__restri
 
 constexpr int SO_LEAST = 64;                 // (2^6) rows of fewer products: SO_SUB lanes each, straight from the row number
 constexpr int SO_TINY = 256;                 // (2^8) rows of fewer products: SO_SUB lanes each, from the list
+constexpr int SO_WAVE = 1024;                // (2^10) rows of fewer products: a wavefront each, from the list
 constexpr int SO_MID = 4096;                 // (2^12) rows of fewer products: a 256-thread workgroup each; the others 1024 threads
 constexpr int SO_SUB = 16;
 constexpr int SO_UNROLL = 8;                 // products a thread has in flight
@@ -119,15 +120,16 @@ __device__ __forceinline__ int32_t so_find(const T *cols, int32_t n, int32_t k)
     return lo;
 }
 
-// The rows of fewer than SO_TINY products -- 99 % of the rows of a sparse product: SO_SUB lanes per row (four rows per
-// wavefront), the row of C's columns, a minimum per entry and the bitmap over its product indices in the group's own LDS
+// The rows of fewer than SO_WAVE products -- 99.6 % of the rows of a sparse product: SUB lanes per row (sixteen: four rows per
+// wavefront; rows of SO_TINY products and more a wavefront each), the row of C's columns, a minimum per entry and the bitmap over its product indices in the group's own LDS
 // (CAPT products at most: the kernel runs once for the rows of [1, SO_LEAST) products -- 95 % of the rows, half a kilobyte
-// each, a full complement of wavefronts -- and once for the listed rows of [SO_LEAST, SO_TINY)).  The walk is a chain of dependent loads -- entry of A,
-// extent of the row of B, its columns -- so sixteen entries of A are taken at a time, one per lane, and their products
+// each, a full complement of wavefronts --, once for the listed rows of [SO_LEAST, SO_TINY) and once, a wavefront per row, for
+// those of [SO_TINY, SO_WAVE): a workgroup per row left four such rows in flight on a CU, each waiting out its own barriers).  The walk is a chain of dependent loads -- entry of A,
+// extent of the row of B, its columns -- so SUB entries of A are taken at a time, one per lane, and their products
 // flattened over the lanes: every load of a step is in flight together.  A product finds its entry by bisection and takes
 // an LDS atomic min; then the ranks, and the entries to their places.  No barrier: a group's lanes are lanes of one
 // wavefront, whose LDS operations complete in program order.  Nothing goes through memory but the product itself.
-template <class PA, class PB, int CAPT>
+template <class PA, class PB, int CAPT, int SUB>
 __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_rp, const int32_t *__restrict__ a_ci,
                                                      int32_t a_nrows, const PB *__restrict__ b_rp,
                                                      const int32_t *__restrict__ b_ci, const int32_t *__restrict__ c_rp,
@@ -136,14 +138,14 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
                                                      int32_t n_list, int32_t *__restrict__ oci, double *__restrict__ ovs,
                                                      unsigned int *__restrict__ bad)
 {
-    constexpr int GROUPS = 256 / SO_SUB, WORDS = CAPT / 32;
-    static_assert(WORDS >= 1 && WORDS <= SO_SUB, "a lane counts one word of the bitmap");
+    constexpr int GROUPS = 256 / SUB, WORDS = CAPT / 32;
+    static_assert(WORDS >= 1 && WORDS <= SUB, "a lane counts one word of the bitmap");
     __shared__ int32_t s_cols[GROUPS][CAPT];
     __shared__ unsigned int s_mn[GROUPS][CAPT], s_bits[GROUPS][WORDS], s_before[GROUPS][WORDS];
-    __shared__ int32_t s_end[GROUPS][SO_SUB];        // products up to and including each entry of the step
-    __shared__ int64_t s_bs[GROUPS][SO_SUB];
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SO_SUB;
-    const int lane = threadIdx.x & (SO_SUB - 1), grp = threadIdx.x / SO_SUB;
+    __shared__ int32_t s_end[GROUPS][SUB];        // products up to and including each entry of the step
+    __shared__ int64_t s_bs[GROUPS][SUB];
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+    const int lane = threadIdx.x & (SUB - 1), grp = threadIdx.x / SUB;
     if (g >= (row_list ? n_list : a_nrows)) return;
     const int64_t i = row_list ? row_list[g] : g;    // (no list: every row, the kernel takes those of [1, CAPT) products)
     const int64_t t = tp[i];
@@ -155,14 +157,14 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
     }
     int32_t *cols = s_cols[grp], *ends = s_end[grp];
     unsigned int *mn = s_mn[grp], *bits = s_bits[grp], *before = s_before[grp];
-    for (int32_t q = lane; q < nc; q += SO_SUB) {
+    for (int32_t q = lane; q < nc; q += SUB) {
         cols[q] = c_ci[c0 + q];
         mn[q] = SO_NONE;
     }
     if (lane < WORDS) bits[lane] = 0u;
     int32_t base = 0;
     const int64_t a1 = a_rp[i + 1];
-    for (int64_t e0 = a_rp[i]; e0 < a1; e0 += SO_SUB) {
+    for (int64_t e0 = a_rp[i]; e0 < a1; e0 += SUB) {
         int64_t bs = 0;
         int32_t len = 0;
         if (e0 + lane < a1) {
@@ -172,19 +174,19 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
         }
         int32_t inc = len;
 #pragma unroll
-        for (int off = 1; off < SO_SUB; off <<= 1) {
-            const int32_t o = __shfl_up(inc, off, SO_SUB);
+        for (int off = 1; off < SUB; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off, SUB);
             if (lane >= off) inc += o;
         }
-        const int32_t total = __shfl(inc, SO_SUB - 1, SO_SUB);
+        const int32_t total = __shfl(inc, SUB - 1, SUB);
         __builtin_amdgcn_wave_barrier();             // (the step before has read ends[] and s_bs[])
         ends[lane] = inc;
         s_bs[grp][lane] = bs;
         __builtin_amdgcn_wave_barrier();
-        for (int32_t p = lane; p < total; p += SO_SUB) {
+        for (int32_t p = lane; p < total; p += SUB) {
             int q = 0;                               // first entry whose products end after p
 #pragma unroll
-            for (int step = SO_SUB / 2; step; step >>= 1)
+            for (int step = SUB / 2; step; step >>= 1)
                 if (ends[q + step - 1] <= p) q += step;
             const int32_t first = q ? ends[q - 1] : 0;
             const int32_t lo = so_find(cols, nc, b_ci[s_bs[grp][q] + (p - first)]);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
         base += total;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int32_t q = lane; q < nc; q += SO_SUB) {
+    for (int32_t q = lane; q < nc; q += SUB) {
         const unsigned int m = mn[q];
         if (m < (unsigned int)t) atomicOr(&bits[m >> 5], 1u << (m & 31));
     }
@@ -202,18 +204,18 @@ __global__ __launch_bounds__(256) void so_tiny_kernel(const PA *__restrict__ a_r
     const int32_t mine = lane < WORDS ? __popc(bits[lane]) : 0;
     int32_t inc = mine;
 #pragma unroll
-    for (int off = 1; off < SO_SUB; off <<= 1) {
-        const int32_t o = __shfl_up(inc, off, SO_SUB);
+    for (int off = 1; off < SUB; off <<= 1) {
+        const int32_t o = __shfl_up(inc, off, SUB);
         if (lane >= off) inc += o;
     }
-    const int32_t all = __shfl(inc, SO_SUB - 1, SO_SUB);
+    const int32_t all = __shfl(inc, SUB - 1, SUB);
     if (lane < WORDS) before[lane] = (unsigned int)(inc - mine);
     __builtin_amdgcn_wave_barrier();
     if (all != nc) {                                 // (an entry no product lands on)
         if (lane == 0) atomicMax(bad, 1u);
         return;
     }
-    for (int32_t q = lane; q < nc; q += SO_SUB) {
+    for (int32_t q = lane; q < nc; q += SUB) {
         const unsigned int m = mn[q];
         const int32_t rank = (int32_t)before[m >> 5] + __popc(bits[m >> 5] & ((1u << (m & 31)) - 1u));
         const int64_t to = (int64_t)c0 + (nc - 1 - rank);
@@ -394,20 +396,43 @@ __global__ __launch_bounds__(THREADS) void so_walk_kernel(const PA *__restrict__
 #pragma unroll
                     for (int u = 0; u < SO_UNROLL; u++)
                         if (open[u] && least[u] > p_first + u * WAVE) atomicMin(&mn[kk[u]], p_first + u * WAVE);
+                } else if constexpr (MODE == 1) {
+                    // the chunk's SO_UNROLL bisections step together: each step's LDS reads are in flight at once (one
+                    // bisection after the other waited out fourteen round trips per product)
+                    int32_t lo[SO_UNROLL], hi[SO_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++) {
+                        lo[u] = 0;
+                        hi[u] = pf + u * WAVE + lane <= last ? nc : 0;
+                    }
+                    for (int32_t span = nc; span > 0; span >>= 1) {      // (the same count of steps for every lane: ceil(log2(nc + 1)))
+                        int32_t at[SO_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < SO_UNROLL; u++) at[u] = lo[u] < hi[u] ? cols[lo[u] + ((hi[u] - lo[u]) >> 1)] : 0;
+#pragma unroll
+                        for (int u = 0; u < SO_UNROLL; u++)
+                            if (lo[u] < hi[u]) {
+                                const int32_t mid = lo[u] + ((hi[u] - lo[u]) >> 1);
+                                if (at[u] < kk[u]) lo[u] = mid + 1;
+                                else hi[u] = mid;
+                            }
+                    }
+                    unsigned int least[SO_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++) least[u] = pf + u * WAVE + lane <= last ? mn[lo[u]] : 0u;
+#pragma unroll
+                    for (int u = 0; u < SO_UNROLL; u++) {
+                        const unsigned int cand = (unsigned int)(base + pf + u * WAVE + lane);
+                        if (pf + u * WAVE + lane <= last && least[u] > cand) atomicMin(&mn[lo[u]], cand);
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < SO_UNROLL; u++) {
                         const int64_t pidx = pf + u * WAVE + lane;
                         if (pidx > last) break;
-                        if constexpr (MODE == 2) {
-                            const int32_t lo = so_find(crow, nc, kk[u]);
-                            const unsigned long long cand = (unsigned long long)(base + pidx);
-                            if (krow[lo] > cand) atomicMin(&krow[lo], cand);      // (a read as a filter before the atomic)
-                        } else {
-                            const int32_t lo = so_find(cols, nc, kk[u]);
-                            const unsigned int cand = (unsigned int)(base + pidx);
-                            if (mn[lo] > cand) atomicMin(&mn[lo], cand);
-                        }
+                        const int32_t lo = so_find(crow, nc, kk[u]);
+                        const unsigned long long cand = (unsigned long long)(base + pidx);
+                        if (krow[lo] > cand) atomicMin(&krow[lo], cand);      // (a read as a filter before the atomic)
                     }
                 }
             }
@@ -672,7 +697,7 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c, const DevBuf *
     CSRK_REQUIRE((int64_t)lds_place + 2048 <= lds_max && cap_long >= SO_MID, "device has too little LDS for the ordering pass");
     const unsigned gr = (unsigned)ceil_div(a->nrows, 256);
     const unsigned gs = (unsigned)ceil_div((int64_t)a->nrows * SO_SUB, 256);
-    int32_t n_long = 0, n_mid = 0, n_small = 0;      // listed rows of at least SO_MID products (first in the list), SO_TINY, SO_LEAST
+    int32_t n_long = 0, n_mid = 0, n_wave = 0, n_small = 0;      // listed rows of at least SO_MID products (first in the list), SO_WAVE, SO_TINY, SO_LEAST
     int32_t octaves[SO_OCTAVES + 1];                 // ([SO_OCTAVES]: some row needs its keys in memory)
     unsigned long long *key_p = nullptr;
     int32_t *const oci_p = oci.as<int32_t>();
@@ -701,7 +726,7 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c, const DevBuf *
         CSRK_LAUNCH_CHECK();                                                                                           \
         so_list_rows_kernel<<<gr, 256>>>(tp_p, a->nrows, false, c_rp, cap_long, cursor.as<int32_t>(), nullptr); \
         CSRK_LAUNCH_CHECK();                                                                                           \
-        so_tiny_kernel<PA, PB, SO_LEAST><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
+        so_tiny_kernel<PA, PB, SO_LEAST, SO_SUB><<<gs, 256>>>((const PA *)a->d_rowptrs, a->d_colinds, a->nrows,                \
                                                       (const PB *)b->d_rowptrs, b->d_colinds, c_rp, c->d_colinds, c_vs, \
                                                       tp_p, nullptr, 0, oci_p, ovs_p, bad_p);              \
         CSRK_LAUNCH_CHECK();                                                                                           \
@@ -712,9 +737,10 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c, const DevBuf *
             octaves[o] = listed;                                                                                       \
             listed += cnt;                                                                                             \
             if (63 - o >= 12) n_long = listed;       /* (SO_MID = 2^12) */                                             \
-            if (63 - o >= 8) n_mid = listed - n_long; /* (SO_TINY = 2^8) */                                            \
+            if (63 - o >= 10) n_mid = listed - n_long; /* (SO_WAVE = 2^10) */                                          \
+            if (63 - o >= 8) n_wave = listed - n_long - n_mid; /* (SO_TINY = 2^8) */                                   \
         }                                                                                                              \
-        n_small = listed - n_long - n_mid;                                                                             \
+        n_small = listed - n_long - n_mid - n_wave;                                                                    \
         if (octaves[SO_OCTAVES]) {                   /* (8 B per entry of C: only for the rows that do not fit LDS) */  \
             CSRK_TRY(key.alloc((size_t)n * 8));                                                                        \
             key_p = key.as<unsigned long long>();                                                                      \
@@ -730,10 +756,16 @@ int spgemm_apply_reference_order(Matrix *a, Matrix *b, Matrix *c, const DevBuf *
             else WALK_GO(PA, PB, 1024, false, n_long, lds_long, cap_long, win_long, rows.as<int32_t>());               \
         }                                                                                                              \
         if (n_mid > 0) WALK_GO(PA, PB, 256, false, n_mid, lds_mid, cap_mid, win_mid, rows.as<int32_t>() + n_long);     \
-        if (n_small > 0) {                                                                                             \
-            so_tiny_kernel<PA, PB, SO_TINY><<<(unsigned)ceil_div((int64_t)n_small * SO_SUB, 256), 256>>>(              \
+        if (n_wave > 0) {                                                                                              \
+            so_tiny_kernel<PA, PB, SO_WAVE, WAVE><<<(unsigned)ceil_div((int64_t)n_wave * WAVE, 256), 256>>>(           \
                 (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, b->d_colinds, c_rp,        \
-                c->d_colinds, c_vs, tp_p, rows.as<int32_t>() + n_long + n_mid, n_small, oci_p, ovs_p, bad_p); \
+                c->d_colinds, c_vs, tp_p, rows.as<int32_t>() + n_long + n_mid, n_wave, oci_p, ovs_p, bad_p);           \
+            CSRK_LAUNCH_CHECK();                                                                                       \
+        }                                                                                                              \
+        if (n_small > 0) {                                                                                             \
+            so_tiny_kernel<PA, PB, SO_TINY, SO_SUB><<<(unsigned)ceil_div((int64_t)n_small * SO_SUB, 256), 256>>>(      \
+                (const PA *)a->d_rowptrs, a->d_colinds, a->nrows, (const PB *)b->d_rowptrs, b->d_colinds, c_rp,        \
+                c->d_colinds, c_vs, tp_p, rows.as<int32_t>() + n_long + n_mid + n_wave, n_small, oci_p, ovs_p, bad_p); \
             CSRK_LAUNCH_CHECK();                                                                                       \
         }                                                                                                              \
     } while (0)
