@@ -330,7 +330,7 @@ def test_spgemm_reference_order_golden(golden, reference_order):
     assert n_reordered > 0            # the fixtures do hold rows whose reference order is not ascending
 
 
-@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'unsorted_b', 'abt_block', 'wide', 'wider'])
+@pytest.mark.parametrize('case', ['sparse', 'heavy_rows', 'unsorted_b', 'abt_block', 'wide', 'wider', 'ptr64', 'ptr64_wide'])
 def test_spgemm_reference_order_vs_oracle(case, reference_order):
     "the same on products that take every accumulator path (hash, strips, expand-sort-compress), against the oracle's raw output"
     from oracle import oracle as O
@@ -351,6 +351,15 @@ def test_spgemm_reference_order_vs_oracle(case, reference_order):
     elif case == 'unsorted_b':        # discovery order follows B's STORAGE order, not its columns
         A = _rand(rng, 800, 600, rng.integers(0, 25, 800))
         B = _rand(rng, 600, 900, rng.integers(0, 40, 600))
+    elif case in ('ptr64', 'ptr64_wide'):      # int64 row pointers on both operands, rows for every tier of the ordering pass
+        nc = 2500 if case == 'ptr64' else 40000   # (by column / by entry)
+        la = rng.integers(0, 9, 700)
+        la[::45] = 300
+        la[::7] = 40
+        A = _rand(rng, 700, 500, la, ptr64=True)
+        lb = rng.integers(0, 30, 500)
+        lb[::25] = 1500
+        B = _rand(rng, 500, nc, lb, ptr64=True)
     elif case in ('wide', 'wider'):   # a product too wide for the discovery pass's per-column LDS tables (30 000 columns: the
         # rows of C still fit LDS for the bisection; 70 000: 16-bit positions do not reach, bisection in memory for long rows)
         nc = 30000 if case == 'wide' else 70000
