@@ -337,8 +337,10 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
-    double *__restrict__ carry_val, int64_t pnnz)
+    double *__restrict__ carry_val, int64_t pnnz, int32_t cb)
 {
+    // (a tile's entries are stored in column order; an index word = {column - block start | row-major position}: spmv_plan.h)
+    constexpr uint32_t POS_MASK = (1u << PANEL_POS_BITS) - 1;
     __shared__ double s_buf[MERGE_ITEMS + 1];
     __shared__ int32_t s_long[MERGE_MAXLONG];
     __shared__ int32_t s_nlong;
@@ -385,11 +387,17 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         if (more) nx = tiles[t + 1];
 
         __syncthreads();      // previous tile's LDS reads finished
+        const double *xw = x + (int64_t)pt.blk * cb;
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-            const double t0 = spmv_prod<R32>(p0[u], x[c0[u]]);
-            const double t1 = spmv_prod<R32>(p1[u], x[c1[u]]);
+#if defined(PANEL_DIAG) && PANEL_DIAG == 1
+            const double t0 = spmv_prod<R32>(p0[u], xw[((uint32_t)c0[u] >> PANEL_POS_BITS) & 1023]);
+            const double t1 = spmv_prod<R32>(p1[u], xw[((uint32_t)c1[u] >> PANEL_POS_BITS) & 1023]);
+#else
+            const double t0 = spmv_prod<R32>(p0[u], xw[(uint32_t)c0[u] >> PANEL_POS_BITS]);
+            const double t1 = spmv_prod<R32>(p1[u], xw[(uint32_t)c1[u] >> PANEL_POS_BITS]);
+#endif
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
             p1[u] = k + 1 < nn ? t1 : 0.0;
         }
@@ -419,8 +427,8 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-            if (k < nn) s_prod[k] = p0[u];
-            if (k + 1 < nn) s_prod[k + 1] = p1[u];
+            if (k < nn) s_prod[(uint32_t)c0[u] & POS_MASK] = p0[u];
+            if (k + 1 < nn) s_prod[(uint32_t)c1[u] & POS_MASK] = p1[u];
         }
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -1332,7 +1340,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
-        pn->carry_val.as<double>(), pn->nnz
+        pn->carry_val.as<double>(), pn->nnz, pn->cb
             const unsigned grid = (unsigned)pn->groups;
             if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
             else spmv_panel_kernel<int32_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));

@@ -204,6 +204,19 @@ constexpr int PANEL_CB1 = 262144;      // (2 MiB of x per block: half the (block
 #define PANEL_T1 256
 #endif
 
+// A tile's entries are stored in COLUMN order (panel_colsort_kernel): index word = {column - block start | position of
+// the entry in the tile's row-major order: PANEL_POS_BITS bits}; inside a whole chunk of 128 ranks the even slots hold
+// ranks 0..63, the odd slots ranks 64..127 (a lane's pair load then feeds two gathers of 64 consecutive ranks each).
+constexpr int PANEL_POS_BITS = 11;
+static_assert((1 << PANEL_POS_BITS) == MERGE_ITEMS, "a position inside a tile takes PANEL_POS_BITS bits");
+static_assert(((int64_t)PANEL_CB1 << PANEL_POS_BITS) <= (1ll << 32), "the index word is 32 bits");
+__host__ __device__ __forceinline__ int panel_slot_of_rank(int rank, int nn)
+{
+    const int chunk = rank >> 7, i = rank & 127;
+    if (((chunk + 1) << 7) > nn) return rank;      // the tile's last, partial chunk: plain order
+    return (chunk << 7) + (i < 64 ? 2 * i : 2 * (i - 64) + 1);
+}
+
 struct PanelTile {
     int64_t j0;      // first entry of the tile in M'
     int32_t i0, i1;  // rows of M' completed before the tile start / end

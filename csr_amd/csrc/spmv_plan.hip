@@ -367,6 +367,51 @@ __global__ void panel_plan_kernel(const PP *__restrict__ prp, int32_t n_heavy, i
     tiles[t] = pt;
 }
 
+// Column order inside a tile (tier 1).  A tile of M' holds ~250 (block, row) pairs of ~7 entries each; in row-major order
+// the repeats of a popular column are hundreds of gathers apart and L1 has dropped the line by then (0.83 line fills per
+// entry).  The tile's entries are therefore STORED sorted by column: the index word becomes {column - block start : 21
+// bits | position of the entry in the tile's row-major order : 11 bits}, the kernel gathers x[block start + column] with
+// neighbouring lanes on neighbouring (often the same) columns and puts each product back at its row-major position in
+// LDS, so the row sums see the very same addends in the very same order.  Inside a whole chunk of 128 ranks the even
+// slots hold ranks 0..63 and the odd slots ranks 64..127: a lane loads the pair (2q, 2q + 1), so each of its two gather
+// instructions then covers 64 CONSECUTIVE ranks.  One workgroup per tile: bitonic sort of the 2048 words in LDS.
+__global__ __launch_bounds__(256) void panel_colsort_kernel(const PanelTile *__restrict__ tiles, int32_t cb,
+                                                           int32_t *__restrict__ pci, double *__restrict__ pvs)
+{
+    __shared__ uint32_t s_key[MERGE_ITEMS];
+    __shared__ double s_val[MERGE_ITEMS];
+    const PanelTile pt = tiles[blockIdx.x];
+    const int nn = pt.nn;
+    const int64_t base = (int64_t)pt.blk * cb;
+    for (int k = threadIdx.x; k < MERGE_ITEMS; k += 256) {
+        uint32_t w = 0xffffffffu;
+        if (k < nn) {
+            w = ((uint32_t)((int64_t)pci[pt.j0 + k] - base) << PANEL_POS_BITS) | (uint32_t)k;
+            s_val[k] = pvs[pt.j0 + k];
+        }
+        s_key[k] = w;
+    }
+    __syncthreads();
+    for (int size = 2; size <= MERGE_ITEMS; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < MERGE_ITEMS / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) {
+                    s_key[lo] = b;
+                    s_key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int k = threadIdx.x; k < nn; k += 256) {
+        const uint32_t w = s_key[k];
+        pci[pt.j0 + panel_slot_of_rank(k, nn)] = (int32_t)w;
+        pvs[pt.j0 + panel_slot_of_rank(k, nn)] = s_val[w & ((1u << PANEL_POS_BITS) - 1)];
+    }
+}
+
 __global__ void panel_blockends_kernel(const int64_t *__restrict__ off, int32_t n_heavy, int32_t n_blocks,
                                        int64_t *__restrict__ out)
 {
@@ -702,6 +747,11 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
         panel_plan_kernel<int32_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
             pn->rp.as<int32_t>(), n, nb, bends.as<int64_t>(), n_tiles, MERGE_ITEMS, pn->tile.as<PanelTile>());
     CSRK_LAUNCH_CHECK();
+    CSRK_REQUIRE(((int64_t)cb << PANEL_POS_BITS) <= (1ll << 32), "column block too wide for the tile's index word");
+    if (n_tiles > 0) {
+        panel_colsort_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(pn->tile.as<PanelTile>(), cb, pn->ci.as<int32_t>(), pn->vs.as<double>());
+        CSRK_LAUNCH_CHECK();
+    }
 
     // workgroup list: `tpw` consecutive tiles of one block per workgroup
     std::vector<PanelGroup> groups;
