@@ -383,7 +383,11 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         const int nn = pt.nn;
         const int nr = i1 - i0;
         PanelTile nx = pt;
+#ifdef PANEL_NOPIPE
+        const bool more = false;
+#else
         const bool more = it + 1 < grp.nt;
+#endif
         if (more) nx = tiles[t + 1];
 
         __syncthreads();      // previous tile's LDS reads finished

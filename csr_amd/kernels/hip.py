@@ -42,6 +42,7 @@ where a stale copy cannot go unseen:
 """
 import ctypes as C
 import os
+import collections
 import threading
 import weakref
 
@@ -230,11 +231,16 @@ def _call(fn, *args):
 # CSRK_RESULT_POOL_BYTES idle, default 2 GiB; 0 = plain np.empty everywhere).  The caller sees an ordinary writable
 # ndarray that nobody else holds (`owndata` is False: its memory belongs to the lease).
 _POOL_MIN = 1 << 20
-_pool_lock = threading.Lock()
+_pool_lock = threading.RLock()
 _pool = []                      # idle blocks: uint8 arrays whose pages are mapped
 _pool_bytes = 0
 _leases = {}                    # id(lease) -> weak reference: the leases behind live result arrays (an array whose base
                                 # is one owns its memory alone)
+# Blocks whose lease has died, not yet back on the idle list.  A lease's finalizer can run inside ANY allocation -- the
+# cyclic collector frees a result array held in a reference cycle -- including allocations made while _pool_lock is held:
+# it therefore takes no lock and only appends here (deque.append is atomic); _out / flush_result_pool /
+# result_pool_bytes drain the queue under the lock.
+_returned = collections.deque()
 
 
 def _pool_cap():
@@ -242,10 +248,21 @@ def _pool_cap():
 
 
 def _give_back(blk, lease_id):
+    _returned.append((blk, lease_id))
+
+
+def _drain_returned(cap):
+    "caller holds _pool_lock"
     global _pool_bytes
-    with _pool_lock:
-        _leases.pop(lease_id, None)
-        if _pool_bytes + blk.nbytes <= _pool_cap():
+    while True:
+        try:
+            blk, lease_id = _returned.popleft()
+        except IndexError:
+            return
+        r = _leases.get(lease_id)
+        if r is not None and r() is None:      # (a NEW lease may sit at the dead one's address: its entry stays)
+            del _leases[lease_id]
+        if _pool_bytes + blk.nbytes <= cap:
             _pool.append(blk)
             _pool_bytes += blk.nbytes
 
@@ -259,8 +276,17 @@ def flush_result_pool():
     "free the idle result blocks"
     global _pool_bytes
     with _pool_lock:
+        _drain_returned(0)
         _pool.clear()
         _pool_bytes = 0
+
+
+def result_pool_bytes():
+    "bytes of idle result blocks (blocks whose arrays have been dropped included)"
+    cap = _pool_cap()
+    with _pool_lock:
+        _drain_returned(cap)
+        return _pool_bytes
 
 
 def _out(shape, dtype):
@@ -269,10 +295,12 @@ def _out(shape, dtype):
     dtype = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64))
     nbytes = n * dtype.itemsize
-    if nbytes < _POOL_MIN or _pool_cap() <= 0:
+    cap = _pool_cap()
+    if nbytes < _POOL_MIN or cap <= 0:
         return np.empty(shape, dtype=dtype)
     blk = None
     with _pool_lock:
+        _drain_returned(cap)
         best = -1
         for i, b in enumerate(_pool):      # smallest idle block that fits without wasting more than a quarter
             if nbytes <= b.nbytes <= nbytes + nbytes // 4 and (best < 0 or b.nbytes < _pool[best].nbytes):
@@ -284,8 +312,7 @@ def _out(shape, dtype):
         blk = np.empty(nbytes, dtype=np.uint8)
     lease = (C.c_char * blk.nbytes).from_buffer(blk)
     weakref.finalize(lease, _give_back, blk, id(lease)).atexit = False
-    with _pool_lock:
-        _leases[id(lease)] = weakref.ref(lease)
+    _leases[id(lease)] = weakref.ref(lease)      # (a dict store: atomic; a finalizer running inside it only appends to _returned)
     arr = np.frombuffer(lease, dtype=dtype, count=n)      # (its base is the lease itself: what the handle cache checks)
     return arr if np.ndim(shape) == 0 or len(shape) == 1 else arr.reshape(shape)
 

@@ -328,9 +328,9 @@ def test_result_arrays_are_recycled_only_when_nobody_holds_them(K, monkeypatch):
     assert b.ctypes.data != addr and view[0] == 1.0
     del view
     gc.collect()
-    assert K._pool_bytes == n * 8                     # now it is idle ...
+    assert K.result_pool_bytes() == n * 8             # now it is idle ...
     c = K._out((n // 2, 2), np.float64)               # ... and serves the next result of that size (any shape / dtype)
-    assert c.ctypes.data == addr and c.shape == (n // 2, 2) and K._pool_bytes == 0
+    assert c.ctypes.data == addr and c.shape == (n // 2, 2) and K.result_pool_bytes() == 0
     d = K._out(n // 4, np.float32)                    # a quarter of the size: the idle block would be mostly waste
     del b, c
     gc.collect()
@@ -341,7 +341,40 @@ def test_result_arrays_are_recycled_only_when_nobody_holds_them(K, monkeypatch):
     del d, e
     gc.collect()
     K.flush_result_pool()
-    assert K._pool_bytes == 0 and not K._pool
+    assert K.result_pool_bytes() == 0 and not K._pool
+
+
+def test_result_pool_survives_a_collection_inside_its_own_lock(K):
+    """
+    A result array held in a reference cycle is freed by the cyclic collector, which may run inside ANY allocation --
+    including those _out makes while it holds the pool's lock.  The lease's finalizer must not need that lock
+    (with a plain Lock the process hung in _give_back -> _give_back).
+    """
+    import faulthandler
+    K.flush_result_pool()
+
+    class Box:
+        pass
+
+    old = gc.get_threshold()
+    faulthandler.dump_traceback_later(60, exit=True)      # a deadlock would otherwise hang the suite
+    try:
+        for thr in (1, 2, 3, 5, 8):
+            gc.set_threshold(thr, 1, 1)                   # a collection every few allocations
+            for _ in range(40):
+                b = Box()
+                b.me = b                                  # the cycle
+                b.y = K._out(1 << 18, np.float64)         # 2 MiB: pooled
+                del b
+                r = K._out(1 << 18, np.float64)           # dropped at once: its finalizer runs right here
+                del r
+    finally:
+        gc.set_threshold(*old)
+        faulthandler.cancel_dump_traceback_later()
+    gc.collect()
+    assert K.result_pool_bytes() <= K._pool_cap()
+    K.flush_result_pool()
+    assert K.result_pool_bytes() == 0 and not K._pool and not K._returned
 
 
 def test_a_matrix_made_of_result_arrays_is_cacheable(K):
