@@ -60,7 +60,7 @@ void spmv_plan_bytes_by_part(const SpmvPlan *p, int64_t out[5])
     auto add = [&](int part, std::initializer_list<const DevBuf *> bufs) {
         for (const DevBuf *b : bufs) out[part] += (int64_t)b->bytes;
     };
-    for (const AccPanel *ap : p->acc) add(0, {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial});
+    for (const AccPanel *ap : p->acc) add(0, {&ap->row_list, &ap->vals, &ap->idx, &ap->tile_row0, &ap->segs, &ap->wg_seg, &ap->partial, &ap->z});
     const Panel &t = p->tier1;
     add(1, {&t.row_list, &t.rp, &t.ci, &t.vs, &t.tile, &t.group, &t.carry_row, &t.carry_val, &t.y, &t.crp, &t.cidx});
     const LightStream *l = &p->ls;
@@ -332,12 +332,23 @@ __global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__r
     if (i < n_hot) xh[i] = x[hot_cols[i]];
 }
 
+// Tier 0's reduce as extra workgroups of the pair kernel's launch.  The accumulator kernel has finished when the pair kernel
+// starts (stream order) and the pair kernel waits on L1 line fills, not on HBM: the 33 MB of partials are read beside
+// it, the epilogue only scatters the 15 936 sums (z -> y[row_list]) instead of reading them.  Workgroups
+// [first, first + ceil(H / 64)) of the launch; first = the launch's size when nothing rides along.
+struct PanelRider {
+    int64_t first;
+    const double *partial;      // [n_wg][H]: the accumulator kernel's per-workgroup sums
+    double *z;                  // [H]
+    int32_t H, n_wg;
+};
+
 template <class PP, int PT, bool R32 = false>
 __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
     const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
-    double *__restrict__ carry_val, int64_t pnnz, int32_t cb)
+    double *__restrict__ carry_val, int64_t pnnz, int32_t cb, PanelRider rider)
 {
     // (a tile's entries are stored in column order; an index word = {column - block start | row-major position}: spmv_plan.h)
     constexpr uint32_t POS_MASK = (1u << PANEL_POS_BITS) - 1;
@@ -349,6 +360,27 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     constexpr int PPAIRS = MERGE_ITEMS / PT / 2;      // consecutive pairs per lane
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1), wv = tid / WAVE;
+    if ((int64_t)blockIdx.x >= rider.first) {
+        // Tier 0's ordered reduce rides along (PanelRider): this workgroup sums the accumulator kernel's partials of 64
+        // heavy rows -- wavefront g the workgroups [g * per, (g + 1) * per), joined in order through LDS -- into z[h].
+        constexpr int G = PT / WAVE;
+        const int h = (int)((int64_t)blockIdx.x - rider.first) * WAVE + lane;
+        const int per = (rider.n_wg + G - 1) / G;
+        const int w0 = wv * per, w1 = w0 + per < rider.n_wg ? w0 + per : rider.n_wg;
+        double acc = 0.0;
+        if (h < rider.H) {
+#pragma unroll 8
+            for (int w = w0; w < w1; w++) acc += rider.partial[(int64_t)w * rider.H + h];
+        }
+        s_buf[wv * WAVE + lane] = acc;
+        __syncthreads();
+        if (wv == 0 && h < rider.H) {
+            double tot = s_buf[lane];
+            for (int u = 1; u < G; u++) tot += s_buf[u * WAVE + lane];
+            rider.z[h] = tot;
+        }
+        return;
+    }
     const PanelGroup grp = groups[blockIdx.x];
     if (grp.nt == 0) return;                      // padding group of an XCD stream
     // Software pipeline over the group's tiles: the entries (and row ends) of tile it+1 are loaded
@@ -383,11 +415,7 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         const int nn = pt.nn;
         const int nr = i1 - i0;
         PanelTile nx = pt;
-#ifdef PANEL_NOPIPE
-        const bool more = false;
-#else
         const bool more = it + 1 < grp.nt;
-#endif
         if (more) nx = tiles[t + 1];
 
         __syncthreads();      // previous tile's LDS reads finished
@@ -395,13 +423,8 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-#if defined(PANEL_DIAG) && PANEL_DIAG == 1
-            const double t0 = spmv_prod<R32>(p0[u], xw[((uint32_t)c0[u] >> PANEL_POS_BITS) & 1023]);
-            const double t1 = spmv_prod<R32>(p1[u], xw[((uint32_t)c1[u] >> PANEL_POS_BITS) & 1023]);
-#else
             const double t0 = spmv_prod<R32>(p0[u], xw[(uint32_t)c0[u] >> PANEL_POS_BITS]);
             const double t1 = spmv_prod<R32>(p1[u], xw[(uint32_t)c1[u] >> PANEL_POS_BITS]);
-#endif
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
             p1[u] = k + 1 < nn ? t1 : 0.0;
         }
@@ -418,8 +441,7 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
                 double tot = s_wpart[0];
 #pragma unroll
                 for (int w = 1; w < PT / WAVE; w++) tot += s_wpart[w];
-                carry_row[t] = i1 < n_prows ? i1 : -1;
-                carry_val[t] = tot;
+                *(pt.cslot >= 0 ? yp + pt.cslot : carry_val + t) = tot;
             }
             pt = nx;
             continue;         // the barrier at the top of the next pass orders the s_wpart reuse
@@ -455,8 +477,7 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
             if (r < nr) {
                 yp[i0 + r] = acc;
             } else {
-                carry_row[t] = i1 < n_prows ? i1 : -1;
-                carry_val[t] = acc;
+                *(pt.cslot >= 0 ? yp + pt.cslot : carry_val + t) = acc;
             }
         }
         __syncthreads();
@@ -472,8 +493,7 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
                 if (r < nr) {
                     yp[i0 + r] = acc;
                 } else {
-                    carry_row[t] = i1 < n_prows ? i1 : -1;
-                    carry_val[t] = acc;
+                    *(pt.cslot >= 0 ? yp + pt.cslot : carry_val + t) = acc;
                 }
             }
         }
@@ -682,18 +702,22 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const SV *__restrict__ pva
     for (int h = tid; h < H; h += PT) partial[(int64_t)blockIdx.x * H + h] = s_acc[h];
 }
 
-// The per-SpMV epilogue -- the carry fix-up of the light stream, the ordered reduces of tier 0 (over the accumulator
-// kernel's workgroups) and of tier 1 (over the column blocks, plus the pair kernel's carries) -- is ONE launch covering up
-// to six jobs (a job = a contiguous range of 1024-thread workgroups).  As separate launches the two small kernels took
-// 5.4 + 14.7 us of a 0.553 ms SpMV, mostly launch latency and exposed round trips.
-//   fix:    y[row] += the carries of the tiles that end inside `row`, in tile order (one thread per tile; the first tile of a
-//           run of equal carry_row adds the whole run).
-//   reduce: y[row_list[h]] = sum over w < n_wg of partial[w][h], in order, then the row's listed carries (crp/cidx: the
-//           tiles of the pair kernel whose last row end falls in a pair of long row h), in tile order.  A workgroup takes
-//           1024 / (64 G) sets of 64 rows; the G wavefronts of a set each sum a contiguous range of w, joined in order
-//           through LDS.  G = 4 for tier 0 (256 partials per row: 64 per wavefront), 2 for tier 1 (38 blocks).  Measured
-//           on the headline matrix (tier 0 / tier 1): 16 / 2 -> 21.1 us, 8 / 2 -> 19.1, 4 / 2 -> 17.4, 2 / 2 -> 23.7,
-//           1 / 2 -> 38.2, 4 / 4 -> 18.5, 16 / 4 (588 workgroups: two rounds) -> 21.9.
+// The per-SpMV epilogue -- the carry fix-up of the light stream, the ordered reduce of tier 1 (over the column blocks, plus
+// the pair kernel's carries) and what is left of tier 0's -- is ONE launch covering up to six jobs (a job = a contiguous
+// range of 1024-thread workgroups).
+//   fix:     y[row] += the carries of the tiles that end inside `row`, in tile order (one thread per tile; the first tile of
+//            a run of equal carry_row adds the whole run).
+//   reduce:  y[row_list[h]] = sum over w < n_wg of partial[w][h], in order, then the `extra` carry rows partial[n_wg + j][h]
+//            (Panel::ncs), then the row's listed carries (crp / cidx), in tile order.  A workgroup takes 1024 / (64 G) sets of
+//            64 rows; the G wavefronts of a set each sum a contiguous range of w, joined in order through LDS.
+//   scatter: y[row_list[h]] = partial[h] -- tier 0's sums when its reduce rode in the pair kernel's launch (PanelRider).
+// What the kernel costs is its longest chain of dependent round trips, not its 55 MB (rocprofv3, headline matrix, round 6):
+// 17.5 us with tier 0's reduce (63 workgroups of 256 partials per row: 17 us on its own) beside tier 1's whose listed carries
+// were chased lane by lane (crp -> cidx -> carry_val per carry of the longest list: a few rows hold a carry per column
+// block); 11.5 us with tier 0's reduce riding in the pair kernel's launch (+3.4 us there), the first carries of a row in
+// carry rows behind the partials and the listed rest loaded a row at a time by the whole wavefront; 5 us is the floor of a
+// launch that only scatters.  Measured and left out (profiles/r06_experiments.json): sixteen partials in flight per lane,
+// row ids and carry ends requested at the top, G = 16 for tier 0 (25 us), 256-thread workgroups (12.5).
 struct EpiJob {
     int32_t kind, blocks;      // 0 = fix, 1 = reduce
     // fix
@@ -705,7 +729,8 @@ struct EpiJob {
     const double *partial;
     const int32_t *row_list;
     int32_t H, n_wg, G;
-    const int32_t *crp, *cidx;      // optional (nullptr: no carries to add)
+    int32_t extra;                  // rows of partial[] behind the n_wg: added last, in order (tier 1's carry rows, Panel::ncs)
+    const int32_t *crp, *cidx;      // optional (nullptr: no listed carries to add)
     const double *cval;
 };
 struct EpiJobs {
@@ -731,25 +756,60 @@ __global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs
         J.fy[row] = acc + J.fy[row];
         return;
     }
+    if (J.kind == 2) {      // scatter: the sums a rider of the pair kernel's launch left in `partial`
+        const int h = b * EPI_THREADS + (int)threadIdx.x;
+        if (h < J.H) y[J.row_list[h]] = J.partial[h];
+        return;
+    }
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const int G = J.G, set = wv / G, g = wv % G;                      // G divides 16
+    const int G = J.G, set = wv / G, g = wv % G;                      // G divides EPI_THREADS / 64
     const int h = (b * (EPI_THREADS / WAVE / G) + set) * WAVE + lane;
+    const bool live = h < J.H;
+    const int hc = live ? h : J.H - 1;
     const int per = (J.n_wg + G - 1) / G;
     const int w0 = g * per, w1 = w0 + per < J.n_wg ? w0 + per : J.n_wg;
+    // the carry rows and the ends of the listed carries: requested with the partials (no branch around them: behind one
+    // the compiler drains the queue before the loop below starts)
+    double ex[PANEL_CARRY_ROWS];
+#pragma unroll
+    for (int j = 0; j < PANEL_CARRY_ROWS; j++) ex[j] = J.partial[(int64_t)(j < J.extra ? J.n_wg + j : 0) * J.H + hc];
+    int32_t k0 = 0, k1 = 0;
+    if (J.crp) {
+        k0 = J.crp[hc];
+        k1 = J.crp[hc + 1];
+    }
     double acc = 0.0;
-    if (h < J.H) {
+    if (live) {
 #pragma unroll 8
         for (int w = w0; w < w1; w++) acc += J.partial[(int64_t)w * J.H + h];
     }
     s_p[wv][lane] = acc;
     __syncthreads();
-    if (g == 0 && h < J.H) {
-        double tot = s_p[wv][lane];
-        for (int u = 1; u < G; u++) tot += s_p[wv + u][lane];
-        if (J.crp)
-            for (int32_t k = J.crp[h]; k < J.crp[h + 1]; k++) tot += J.cval[J.cidx[k]];
-        y[J.row_list[h]] = tot;
+    if (g != 0) return;
+    double tot = s_p[wv][lane];
+    for (int u = 1; u < G; u++) tot += s_p[wv + u][lane];
+#pragma unroll
+    for (int j = 0; j < PANEL_CARRY_ROWS; j++) tot += j < J.extra ? ex[j] : -0.0;
+    // Listed carries.  Tile boundaries fall at about the same rows in every column block, so a few rows hold a carry per
+    // block (dozens) and most hold none: lane by lane that was a chain of two dependent loads per carry of the longest
+    // list.  The wavefront takes its rows that have some one after the other: a row's carries are loaded together, one per
+    // lane, and added in list order.
+    unsigned long long todo = __ballot(live && k1 > k0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int32_t s0 = __shfl(k0, src, WAVE), s1 = __shfl(k1, src, WAVE);
+        double T = __shfl(tot, src, WAVE);
+        for (int32_t kb = s0; kb < s1; kb += WAVE) {
+            const int32_t k = kb + lane;
+            double c = -0.0;
+            if (k < s1) c = J.cval[J.cidx[k]];
+            const int cnt = s1 - kb < WAVE ? s1 - kb : WAVE;
+            for (int u = 0; u < cnt; u++) T += __shfl(c, u, WAVE);
+        }
+        if (lane == src) tot = T;
     }
+    if (live) y[J.row_list[h]] = tot;
 }
 
 // ---- short rows: the light stream ---------------------------------------------------------------------
@@ -1290,7 +1350,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             return CSRK_OK;
         };
         auto add_red = [&](const double *part, const int32_t *rows, int32_t H, int32_t n_wg, int G, const int32_t *crp,
-                           const int32_t *cidx, const double *cval) -> int {
+                           const int32_t *cidx, const double *cval, int32_t extra = 0) -> int {
             if (H <= 0) return CSRK_OK;
             if (epi.n == 6) CSRK_TRY(flush_epi());
             EpiJob J = {};
@@ -1301,6 +1361,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             J.H = H;
             J.n_wg = n_wg;
             J.G = G;
+            J.extra = extra;
             J.crp = crp;
             J.cidx = cidx;
             J.cval = cval;
@@ -1323,6 +1384,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                                                                             p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
         }
+        bool t0_rides = false;      // tier 0's reduce ran inside the pair kernel's launch: the epilogue only scatters its sums
         if (do_heavy && p->n_heavy && !p->acc.empty()) {        // tier 0, accumulator form
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
@@ -1344,8 +1406,17 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
 #define PANEL_ARGS(PP)                                                                                              \
     pn->rp.as<PP>(), pn->ci.as<int32_t>(), pn->vs.as<double>(), d_x, m->ncols, pn->y.as<double>(),                    \
         pn->tile.as<PanelTile>(), pn->group.as<PanelGroup>(), pn->rows, pn->carry_row.as<int32_t>(),                  \
-        pn->carry_val.as<double>(), pn->nnz, pn->cb
-            const unsigned grid = (unsigned)pn->groups;
+        pn->carry_val.as<double>(), pn->nnz, pn->cb, rider
+            PanelRider rider = {pn->groups, nullptr, nullptr, 0, 0};
+            if (PANEL_T1 / WAVE == 4 && do_heavy && p->acc.size() == 1 && p->acc[0]->z.p) {
+                AccPanel *ap = p->acc[0];
+                rider.partial = ap->partial.as<double>();
+                rider.z = ap->z.as<double>();
+                rider.H = ap->nrow;
+                rider.n_wg = ap->n_wg;
+                t0_rides = true;
+            }
+            const unsigned grid = (unsigned)(pn->groups + (t0_rides ? ceil_div(rider.H, WAVE) : 0));
             if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
             else spmv_panel_kernel<int32_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
 #undef PANEL_ARGS
@@ -1422,14 +1493,24 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             CSRK_LAUNCH_CHECK();
             }
         }
-        if (do_heavy && p->n_heavy && !p->acc.empty())
+        if (do_heavy && p->n_heavy && !p->acc.empty() && t0_rides) {
+            AccPanel *ap = p->acc[0];
+            if (epi.n == 6) CSRK_TRY(flush_epi());
+            EpiJob J = {};
+            J.kind = 2;
+            J.blocks = (int32_t)ceil_div(ap->nrow, EPI_THREADS);
+            J.partial = ap->z.as<double>();
+            J.row_list = ap->row_list.as<int32_t>();
+            J.H = ap->nrow;
+            epi.j[epi.n++] = J;
+        } else if (do_heavy && p->n_heavy && !p->acc.empty())
             for (AccPanel *ap : p->acc)
                 CSRK_TRY(add_red(ap->partial.as<double>(), ap->row_list.as<int32_t>(), ap->nrow, ap->n_wg, 4, nullptr, nullptr, nullptr));
         if (do_heavy && p->n_heavy && p->tier1.on) {
             // y[row] = sum over column blocks of the (block, row) partials, in block order, then the row's listed carries
             Panel *pn = &p->tier1;
-            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb, pn->nb > 64 ? 16 : 2,
-                             pn->crp.as<int32_t>(), pn->cidx.as<int32_t>(), pn->carry_val.as<double>()));
+            CSRK_TRY(add_red(pn->y.as<double>(), pn->row_list.as<int32_t>(), pn->nrow, pn->nb, pn->nb > 64 ? 4 : 2,
+                             pn->crp.as<int32_t>(), pn->cidx.as<int32_t>(), pn->carry_val.as<double>(), pn->ncs));
         }
         CSRK_TRY(flush_epi());      // the light stream's carries and the ordered reduces of the tiers, one launch
         break;

@@ -54,8 +54,13 @@ struct Panel {
     int64_t rows = 0, tiles = 0, nnz = 0, groups = 0;
     DevBuf row_list;                             // int32[nrow]: original row ids, ascending
     DevBuf rp, ci, vs, tile, group, carry_row, carry_val, y;
-    // the tiles' carries, listed per long row (static: a tile's carry belongs to the pair its last row end falls in):
-    // carries of long row h = carry_val[cidx[crp[h] .. crp[h + 1])], in tile order -- added by the tier's ordered reduce
+    // The tiles' carries (static: a tile's carry belongs to the pair its last row end falls in) are added by the tier's
+    // ordered reduce after the row's block partials, in tile order.  The j-th carry of long row h, j < ncs, is WRITTEN by its
+    // tile into y[(nb + j) * nrow + h] -- `ncs` carry rows behind the nb block rows of the partials, -0.0 where a row has no
+    // such carry (set once; x + -0.0 = x) -- so the reduce reads them like partials instead of chasing crp -> cidx -> carry_val
+    // (three dependent round trips: 5.5 of the epilogue's 16 us).  Carries beyond ncs per row: carry_val[cidx[crp[h] ..
+    // crp[h + 1])] as before (crp empty when there are none).
+    int32_t ncs = 0;
     DevBuf crp, cidx;
 };
 
@@ -73,6 +78,7 @@ struct AccPanel {
     int64_t tiles = 0, nnz = 0, n_segs = 0;
     size_t lds = 0;
     DevBuf row_list, vals, idx, tile_row0, segs, wg_seg, partial;      // idx: 16-bit words (column, row step)
+    DevBuf z;              // double[nrow]: the rows' sums when the reduce rides in the pair kernel's launch (PanelRider)
     bool f32 = false;      // vals holds float32 (a float32 matrix: 6 B per entry instead of 10; widening them in the kernel is exact)
 };
 
@@ -219,10 +225,12 @@ __host__ __device__ __forceinline__ int panel_slot_of_rank(int rank, int nn)
 
 struct PanelTile {
     int64_t j0;      // first entry of the tile in M'
+    int64_t cslot;   // where the tile's carry goes: an index into the partials' carry rows (Panel::ncs), or -1: carry_val[t]
     int32_t i0, i1;  // rows of M' completed before the tile start / end
     int32_t nn;      // entries in the tile
     int32_t blk;     // column block
 };
+constexpr int PANEL_CARRY_ROWS = 4;      // carry rows behind the block partials at most (a long row's first carries)
 
 struct PanelGroup {
     int64_t t0;      // first tile

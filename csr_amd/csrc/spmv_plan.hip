@@ -364,6 +364,7 @@ __global__ void panel_plan_kernel(const PP *__restrict__ prp, int32_t n_heavy, i
     pt.j0 = e0 + (d0 - coord[0]);
     pt.nn = (int32_t)((d1 - coord[1]) - (d0 - coord[0]));
     pt.blk = b;
+    pt.cslot = -1;
     tiles[t] = pt;
 }
 
@@ -779,29 +780,54 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
         for (size_t i = 0; i < longest; i++)
             for (int q = 0; q < HEAVY_STREAMS; q++) groups.push_back(i < st[q].size() ? st[q][i] : pad);
     }
-    // the tiles' carries per long row (a tile's carry belongs to the pair holding its last, unfinished row end: static)
+    // the tiles' carries per long row (a tile's carry belongs to the pair holding its last, unfinished row end: static): the
+    // first `ncs` of a row go to carry rows behind the block partials (Panel::ncs), the others are listed
+    int32_t ncs = 0;
     {
         std::vector<PanelTile> ht((size_t)n_tiles);
         CSRK_TRY(stage_d2h(ht.data(), pn->tile.p, (size_t)n_tiles * sizeof(PanelTile), nullptr));
-        std::vector<int32_t> crp((size_t)n + 1, 0), cidx;
+        std::vector<int32_t> cnt((size_t)n, 0);
         for (int64_t t = 0; t < n_tiles; t++)
-            if ((int64_t)ht[(size_t)t].i1 < pairs) crp[(size_t)(ht[(size_t)t].i1 % n) + 1]++;
-        for (int32_t h = 0; h < n; h++) crp[(size_t)h + 1] += crp[(size_t)h];
+            if ((int64_t)ht[(size_t)t].i1 < pairs) {
+                const int32_t c = ++cnt[(size_t)(ht[(size_t)t].i1 % n)];
+                ncs = c > ncs ? c : ncs;
+            }
+        ncs = ncs < PANEL_CARRY_ROWS ? ncs : PANEL_CARRY_ROWS;
+        std::vector<int32_t> crp((size_t)n + 1, 0), cidx;
+        bool listed = false;
+        for (int32_t h = 0; h < n; h++) {
+            crp[(size_t)h + 1] = crp[(size_t)h] + (cnt[(size_t)h] > ncs ? cnt[(size_t)h] - ncs : 0);
+            listed = listed || cnt[(size_t)h] > ncs;
+        }
         cidx.resize((size_t)crp[(size_t)n] + 1);
-        std::vector<int32_t> cur(crp.begin(), crp.end() - 1);
-        for (int64_t t = 0; t < n_tiles; t++)      // ascending tiles: each row's list comes out in tile order
-            if ((int64_t)ht[(size_t)t].i1 < pairs) cidx[(size_t)cur[(size_t)(ht[(size_t)t].i1 % n)]++] = (int32_t)t;
-        CSRK_TRY(pn->crp.alloc(crp.size() * 4));
-        CSRK_TRY(pn->cidx.alloc(cidx.size() * 4));
-        CSRK_TRY(stage_h2d(pn->crp.p, crp.data(), crp.size() * 4, nullptr));
-        CSRK_TRY(stage_h2d(pn->cidx.p, cidx.data(), cidx.size() * 4, nullptr));
+        std::vector<int32_t> seen((size_t)n, 0);
+        for (int64_t t = 0; t < n_tiles; t++) {      // ascending tiles: each row's carries come out in tile order
+            PanelTile &T = ht[(size_t)t];
+            T.cslot = -1;
+            if ((int64_t)T.i1 >= pairs) continue;
+            const int32_t h = (int32_t)(T.i1 % n), j = seen[(size_t)h]++;
+            if (j < ncs) T.cslot = pairs + (int64_t)j * n + h;
+            else cidx[(size_t)(crp[(size_t)h] + j - ncs)] = (int32_t)t;
+        }
+        CSRK_TRY(stage_h2d(pn->tile.p, ht.data(), (size_t)n_tiles * sizeof(PanelTile), nullptr));
+        if (listed) {
+            CSRK_TRY(pn->crp.alloc(crp.size() * 4));
+            CSRK_TRY(pn->cidx.alloc(cidx.size() * 4));
+            CSRK_TRY(stage_h2d(pn->crp.p, crp.data(), crp.size() * 4, nullptr));
+            CSRK_TRY(stage_h2d(pn->cidx.p, cidx.data(), cidx.size() * 4, nullptr));
+        }
     }
     pn->groups = (int64_t)groups.size();
     CSRK_TRY(pn->group.alloc(groups.size() * sizeof(PanelGroup)));
     CSRK_TRY(stage_h2d(pn->group.p, groups.data(), groups.size() * sizeof(PanelGroup), s));
     CSRK_TRY(pn->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(pn->carry_val.alloc((size_t)n_tiles * 8));
-    CSRK_TRY(pn->y.alloc((size_t)pairs * 8));
+    CSRK_TRY(pn->y.alloc((size_t)(pairs + (int64_t)ncs * n) * 8));
+    if (ncs) {      // -0.0 where no tile writes (x + -0.0 = x for every x)
+        std::vector<double> neg0((size_t)ncs * n, -0.0);
+        CSRK_TRY(stage_h2d(pn->y.as<double>() + pairs, neg0.data(), neg0.size() * 8, s));
+    }
+    pn->ncs = ncs;
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
     pn->on = true;
     pn->cb = cb;
@@ -921,6 +947,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     CSRK_TRY(stage_h2d(ap->segs.p, segs.data(), segs.size() * sizeof(AccSeg), s));
     CSRK_TRY(stage_h2d(ap->wg_seg.p, wg_seg.data(), wg_seg.size() * 4, s));
     CSRK_TRY(ap->partial.alloc((size_t)n_wg * n * 8));
+    CSRK_TRY(ap->z.alloc((size_t)n * 8));
     ap->lds = (size_t)(ACC_CB + 2) * 8 + (size_t)((n + 1) & ~1) * 8 + (size_t)ACC_SEG_TILES * 12;
     CSRK_TRY(spmv_kernel_attributes());
     CSRK_HIP(hipStreamSynchronize(s));     // `segs`, `wg_seg`, `t0` are host temporaries of async copies
