@@ -80,6 +80,7 @@ SIGNATURES = {
     'csrk_spgemm_abt': (_int, [handle_t, handle_t, C.POINTER(handle_t)]),
     'csrk_spgemm_set_order': (_int, [_int]),
     'csrk_spgemm_get_order': (_int, [C.POINTER(_int)]),
+    'csrk_spgemm_last_route': (_int, [C.POINTER(_int)]),
     'csrk_spmm_dense': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64]),
     'csrk_spmm_dense_device': (_int, [handle_t, _vp, _i32, _i64, _vp, _i64, _vp]),
     'csrk_spmm_plan_stats': (_int, [handle_t, _vp, _int]),

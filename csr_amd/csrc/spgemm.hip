@@ -2008,8 +2008,18 @@ static int spgemm_run(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend, De
 
 // b_rows_ascend: the caller knows that B's rows hold strictly ascending columns (the transpose of a matrix without
 // repeated entries); otherwise a kernel checks before the strips rely on it
+int spgemm_dense_b(Matrix *a, Matrix *b, Matrix **out, bool *taken);      // spmm_dense.hip
+static thread_local int t_last_route = 0;      // csrk_spgemm_last_route
+
 static int spgemm_impl(Matrix *a, Matrix *b, Matrix **out, bool b_rows_ascend)
 {
+    {   // a fully populated B in row-major panel form: the dense-panel kernels, C as the reference returns it
+        bool taken = false;
+        t_last_route = 0;
+        CSRK_TRY(spgemm_dense_b(a, b, out, &taken));
+        t_last_route = taken ? 1 : 0;
+        if (taken) return CSRK_OK;
+    }
     const bool fast = !a->ptr64 && !b->ptr64 && a->val_type == CSRK_VAL_F64 && b->val_type == CSRK_VAL_F64;
     const bool ordered = spgemm_reference_order_wanted();
     DevBuf products;                            // products of every row of A B (int64), when the product kernels counted them
@@ -2040,6 +2050,13 @@ CSRK_API int csrk_debug_sg_stamps(unsigned long long *out, int n)
     return CSRK_OK;
 }
 #endif
+
+int csrk_spgemm_last_route(int *route)
+{
+    CSRK_REQUIRE(route, "route is NULL");
+    *route = t_last_route;
+    return CSRK_OK;
+}
 
 int csrk_spgemm_ab(csrk_handle_t ah, csrk_handle_t bh, csrk_handle_t *out)
 {

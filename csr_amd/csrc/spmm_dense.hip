@@ -174,6 +174,37 @@ __device__ __forceinline__ void mm_unit(const int32_t *__restrict__ ci, const vo
     }
 }
 
+// Where a row of the product goes.  Plain (csrk_spmm_dense): row i at C + i * ldc, columns ascending.  As the reference's
+// mult_ab returns a product with a fully populated B (csrk_spgemm_ab's dense route, below): the rows of A without
+// entries have no entries in C (row_base < 0: nothing stored), the others k each at C + row_base[i], columns k - 1 .. 0
+// (rev_k = k: panel column c is stored at k - 1 - c).
+struct SpmmOut {
+    const int64_t *row_base;      // nullptr: i * ldc
+    int32_t rev_k;                // 0: ascending columns
+};
+__device__ __forceinline__ double *mm_row_dst(double *C, int64_t ldc, int64_t row, const SpmmOut &o)
+{
+    if (!o.row_base) return C + row * ldc;
+    const int64_t b = o.row_base[row];
+    return b < 0 ? nullptr : C + b;
+}
+
+// the same four sums stored for a reversed row: column c + i at k - 1 - (c + i)
+template <bool FULL4>
+__device__ __forceinline__ void mm_store4_rev(double *__restrict__ dst, int32_t c, int32_t k, const double acc[4])
+{
+    if (c >= k) return;
+    if (FULL4) {
+        mm_f64x2 t0 = {acc[3], acc[2]}, t1 = {acc[1], acc[0]};
+        __builtin_nontemporal_store(t0, (MMF64x2 *)(dst + k - 4 - c));
+        __builtin_nontemporal_store(t1, (MMF64x2 *)(dst + k - 2 - c));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (c + i < k) dst[k - 1 - c - i] = acc[i];
+    }
+}
+
 template <bool FULL4>
 __device__ __forceinline__ void mm_store4(double *__restrict__ dst, int32_t c, int32_t k, const double acc[4])
 {
@@ -405,10 +436,11 @@ __global__ __launch_bounds__(HR_THREADS) void spmm_hrows_kernel(const int64_t *_
     }
 }
 
-// C[row of heavy row i, c] = sum over the column ranges, in order, of the workgroups' partials: one wavefront per row
+// C[row of heavy row i, c0 + c] = sum over the column ranges, in order, of the workgroups' partials: one wavefront per row
 __global__ __launch_bounds__(256) void spmm_hrows_reduce_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ code,
                                                                int32_t n, int32_t G, int32_t R, int32_t kc,
-                                                               const double *__restrict__ part, double *__restrict__ C, int64_t ldc)
+                                                               const double *__restrict__ part, double *__restrict__ C, int64_t ldc,
+                                                               int32_t c0, SpmmOut om)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -427,7 +459,8 @@ __global__ __launch_bounds__(256) void spmm_hrows_reduce_kernel(const int32_t *_
         for (int t = 0; t < 8; t++) acc += v[t];
     }
     for (; q < R; q++) acc += p[q * step];
-    C[(int64_t)rows[i] * ldc + lane] = acc;
+    const int32_t c = c0 + lane;
+    mm_row_dst(C, ldc, rows[i], om)[om.rev_k ? om.rev_k - 1 - c : c] = acc;      // (a heavy row has entries: it has a place)
 }
 
 // plan time: the entries of heavy row i as sortable records, in the order (i, storage order)
@@ -486,7 +519,7 @@ template <int VT, bool FULL4>
 __global__ __launch_bounds__(256) void spmm_seg_kernel(const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                                       const double *__restrict__ B, int32_t k, int64_t ldb,
                                                       double *__restrict__ C, int64_t ldc, const SegDesc *__restrict__ seg,
-                                                      int64_t n_segs, double *__restrict__ part)
+                                                      int64_t n_segs, double *__restrict__ part, SpmmOut om)
 {
     const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MM_G;
     const int sub = threadIdx.x & (MM_G - 1);
@@ -494,12 +527,17 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const int32_t *__restrict
     d.start = 0, d.n = 0, d.row = 0, d.part = -1;
     if (q < n_segs) d = seg[q];
     const int nmax = mm_wave_max4(d.n);
-    double *dst = d.part < 0 ? C + (int64_t)d.row * ldc : part + d.part * (int64_t)k;
+    const bool to_c = d.part < 0;
+    double *dst = to_c ? mm_row_dst(C, ldc, d.row, om) : part + d.part * (int64_t)k;
+    const bool rev = to_c && om.rev_k != 0;
     for (int32_t c0 = 0; c0 < k; c0 += MM_CHUNK) {
         const int32_t c = c0 + 4 * sub;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         mm_unit<VT, FULL4>(ci, vs, d.start, d.n, nmax, B, ldb, c, k, sub, acc);
-        if (q < n_segs) mm_store4<FULL4>(dst, c, k, acc);      // (an empty row's single segment stores its zeros)
+        if (q < n_segs && dst) {      // (an empty row's single segment stores its zeros -- or nothing, where the row has no place)
+            if (rev) mm_store4_rev<FULL4>(dst, c, k, acc);
+            else mm_store4<FULL4>(dst, c, k, acc);
+        }
     }
 }
 
@@ -516,7 +554,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int64_t *__restri
                                                         const int64_t *__restrict__ part_off,
                                                         const int32_t *__restrict__ split_rows, int32_t n_split, int32_t k,
                                                         const double *__restrict__ part, double *__restrict__ C,
-                                                        int64_t ldc)
+                                                        int64_t ldc, SpmmOut om)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -524,10 +562,11 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int64_t *__restri
     const int64_t r = split_rows[i];
     const int64_t n = seg_off[r + 1] - seg_off[r];
     const int64_t a = part_off[r];
+    double *dst = mm_row_dst(C, ldc, r, om);      // (a split row has entries: it has a place)
     for (int32_t c = lane; c < k; c += WAVE) {
         double acc = 0.0;
         for (int64_t q = a; q < a + n; q++) acc += part[q * (int64_t)k + c];
-        C[r * ldc + c] = acc;
+        dst[om.rev_k ? k - 1 - c : c] = acc;
     }
 }
 
@@ -729,7 +768,8 @@ static int build_hrows(Matrix *m, SpmmPlan *p, int32_t k, bool force, hipStream_
     return CSRK_OK;
 }
 
-static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, double *dC, int64_t ldc, hipStream_t s)
+static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, double *dC, int64_t ldc, hipStream_t s,
+                       SpmmOut om = {nullptr, 0})
 {
     CSRK_REQUIRE(k >= 0 && ldb >= k && ldc >= k, "bad panel geometry k=%d ldb=%lld ldc=%lld", k, (long long)ldb, (long long)ldc);
     if (m->nrows == 0 || k == 0) return CSRK_OK;
@@ -781,7 +821,7 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
 #undef HROWS
             CSRK_LAUNCH_CHECK();
             spmm_hrows_reduce_kernel<<<rgrid, 256, 0, s>>>(p->hr_rows.as<int32_t>(), p->hr_code.as<int32_t>(), p->hr_n, p->hr_G, p->hr_R,
-                                                          kc, p->hr_part.as<double>(), dC + c0, ldc);
+                                                          kc, p->hr_part.as<double>(), dC, ldc, c0, om);
             CSRK_LAUNCH_CHECK();
         }
     }
@@ -789,7 +829,7 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     const unsigned grid = (unsigned)ceil_div(p->n_segs * MM_G, 256);
 #define GO(VT, F4)                                                                                                     \
     spmm_seg_kernel<VT, F4><<<grid, 256, 0, s>>>(m->d_colinds, m->d_values, dB, k, ldb, dC, ldc, p->seg.as<SegDesc>(),   \
-                                                 p->n_segs, p->part.as<double>())
+                                                 p->n_segs, p->part.as<double>(), om)
     if (m->val_type == CSRK_VAL_F64) {
         if (full4) GO(CSRK_VAL_F64, true);
         else GO(CSRK_VAL_F64, false);
@@ -805,9 +845,129 @@ static int spmm_device(Matrix *m, const double *dB, int32_t k, int64_t ldb, doub
     if (p->n_multi > 0) {
         spmm_fixup_kernel<<<(unsigned)ceil_div((int64_t)p->n_split * WAVE, 256), 256, 0, s>>>(
             p->seg_off.as<int64_t>(), p->part_off.as<int64_t>(), p->split_rows.as<int32_t>(), p->n_split, k,
-            p->part.as<double>(), dC, ldc);
+            p->part.as<double>(), dC, ldc, om);
         CSRK_LAUNCH_CHECK();
     }
+    return CSRK_OK;
+}
+
+// ---- mult_ab(A, B) with B a fully populated CSR: the reference's own route to BASELINE configs[2] ---------------------
+// The reference has no dense-panel entry: a caller computes A x dense B as A.multiply(CSR(B)) -> K.mult_ab
+// (csr/csr.py:524-567, csr/kernels/numba/multiply.py:13-38).  When every row of B holds all k columns in ascending order
+// its `values` array IS the row-major panel, and the product the reference returns is fixed by its loops alone: the first
+// entry of a row of A discovers the k columns 0 .. k - 1 of its row of B, pushed one by one onto the FRONT of the row's
+// list (multiply.py:79-82), copied out front to back (:94-97) -- every row of C whose row of A holds an entry is
+// k - 1 .. 0, the others are empty -- and the values are the panel's (work[c] += a * b over the row's entries in storage
+// order, :110-122; explicit zeros kept).  One kernel checks B, the dense-panel kernels above write C's values in place
+// (SpmmOut), C's index arrays are filled beside them.  Anything else -- a row of B short of a column, or in another
+// order; float32 values on BOTH operands, whose products the reference rounds to float32 -- takes the general product.
+template <class P>
+__global__ __launch_bounds__(256) void dense_b_check_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                           int32_t nrows, int32_t k, int32_t *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)nrows * k;
+    bool ok = true;
+    if (i <= nrows) ok = (int64_t)rp[i] == i * k;
+    if (i < n) ok = ok && ci[i] == (int32_t)(i % k);
+    if (!ok) *bad = 1;      // (any one writer: the flag is all that is read)
+}
+
+template <class P>
+__global__ void dense_c_live_kernel(const P *__restrict__ rp, int32_t nrows, int64_t *__restrict__ live)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) live[i] = rp[i + 1] > rp[i] ? 1 : 0;
+}
+
+// rank[i] = rows of A with entries before row i (rank[nrows] = all of them): C's row pointers and where its rows start
+__global__ void dense_c_rows_kernel(const int64_t *__restrict__ rank, int32_t nrows, int32_t k, int32_t *__restrict__ crp,
+                                    int64_t *__restrict__ row_base)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nrows) return;
+    crp[i] = (int32_t)(rank[i] * k);
+    if (i < nrows) row_base[i] = rank[i + 1] > rank[i] ? rank[i] * k : -1;
+}
+
+__global__ __launch_bounds__(256) void dense_c_cols_kernel(int32_t *__restrict__ ci, int64_t n, int32_t k)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(k - 1 - (int32_t)(i % k), ci + i);
+}
+
+__global__ void dense_widen_kernel(const float *__restrict__ in, double *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+// *taken = false: B is not a row-major panel (or the route is switched off): the caller runs the general product
+int spgemm_dense_b(Matrix *a, Matrix *b, Matrix **out, bool *taken)
+{
+    *taken = false;
+    const char *env = getenv("CSRK_SPGEMM_DENSE");
+    if (env && env[0] == '0') return CSRK_OK;
+    const int32_t k = b->ncols;
+    if (a->ncols != b->nrows || k < 1 || b->nrows < 1 || a->nnz == 0 || b->nnz != (int64_t)b->nrows * k) return CSRK_OK;
+    if (a->val_type == CSRK_VAL_NONE || b->val_type == CSRK_VAL_NONE) return CSRK_OK;      // (the general product reports it)
+    if (a->val_type == CSRK_VAL_F32 && b->val_type == CSRK_VAL_F32) return CSRK_OK;         // float32 products: multiply.py:120
+    DevBuf bad;
+    CSRK_TRY(bad.alloc(4));
+    CSRK_HIP(hipMemsetAsync(bad.p, 0, 4, nullptr));
+    const unsigned gb = (unsigned)ceil_div(b->nnz + 1, 256);
+    if (b->ptr64) dense_b_check_kernel<int64_t><<<gb, 256>>>((const int64_t *)b->d_rowptrs, b->d_colinds, b->nrows, k, bad.as<int32_t>());
+    else dense_b_check_kernel<int32_t><<<gb, 256>>>((const int32_t *)b->d_rowptrs, b->d_colinds, b->nrows, k, bad.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
+    // C's rows meanwhile: which rows of A hold an entry
+    const int32_t nr = a->nrows;
+    DevBuf rank, row_base;
+    CSRK_TRY(rank.alloc((size_t)(nr + 1) * 8));
+    CSRK_TRY(row_base.alloc((size_t)(nr + 1) * 8));
+    const unsigned ga = (unsigned)ceil_div(nr + 1, 256);
+    if (a->ptr64) dense_c_live_kernel<int64_t><<<ga, 256>>>((const int64_t *)a->d_rowptrs, nr, rank.as<int64_t>());
+    else dense_c_live_kernel<int32_t><<<ga, 256>>>((const int32_t *)a->d_rowptrs, nr, rank.as<int64_t>());
+    CSRK_LAUNCH_CHECK();
+    CSRK_TRY(exclusive_scan_i64(rank.as<int64_t>(), rank.as<int64_t>(), nr, nullptr));
+    int32_t is_bad = 0;
+    int64_t live = 0;
+    CSRK_TRY(stage_d2h(&is_bad, bad.p, 4, nullptr));
+    CSRK_TRY(stage_d2h(&live, rank.as<int64_t>() + nr, 8, nullptr));
+    if (is_bad) return CSRK_OK;
+    const int64_t c_nnz = live * k;
+    if (c_nnz > INT32_MAX) {
+        set_error("product has %lld entries; the reference's int32 row pointers (multiply.py:28) cannot hold it: "
+                  "multiply row blocks of A instead", (long long)c_nnz);
+        return CSRK_ERR_OVERFLOW;
+    }
+    Matrix *c = nullptr;
+    CSRK_TRY(new_matrix(nr, k, c_nnz, 0, CSRK_VAL_F64, &c));
+    dense_c_rows_kernel<<<ga, 256>>>(rank.as<int64_t>(), nr, k, (int32_t *)c->d_rowptrs, row_base.as<int64_t>());
+    int rc = hipGetLastError() == hipSuccess ? CSRK_OK : CSRK_ERR_HIP;
+    if (rc == CSRK_OK && c_nnz > 0) {
+        dense_c_cols_kernel<<<(unsigned)ceil_div(c_nnz, 256), 256>>>(c->d_colinds, c_nnz, k);
+        rc = hipGetLastError() == hipSuccess ? CSRK_OK : CSRK_ERR_HIP;
+    }
+    DevBuf wide;      // a float32 panel under float64 values of A: widened (exactly) once
+    const double *panel = (const double *)b->d_values;
+    if (rc == CSRK_OK && b->val_type == CSRK_VAL_F32) {
+        rc = wide.alloc((size_t)b->nnz * 8);
+        if (rc == CSRK_OK) {
+            dense_widen_kernel<<<(unsigned)ceil_div(b->nnz, 256), 256>>>((const float *)b->d_values, wide.as<double>(), b->nnz);
+            rc = hipGetLastError() == hipSuccess ? CSRK_OK : CSRK_ERR_HIP;
+            panel = wide.as<double>();
+        }
+    }
+    if (rc == CSRK_OK && c_nnz > 0) rc = spmm_device(a, panel, k, k, (double *)c->d_values, k, nullptr, SpmmOut{row_base.as<int64_t>(), k});
+    // (row_base, the widened panel and C's arrays are recycled in default-stream order: the launches above are on it)
+    if (rc == CSRK_OK && hipDeviceSynchronize() != hipSuccess) rc = CSRK_ERR_HIP;
+    if (rc != CSRK_OK) {
+        if (rc == CSRK_ERR_HIP) set_error("mult_ab (dense B): %s", hipGetErrorString(hipGetLastError()));
+        delete c;
+        return rc;
+    }
+    *out = c;
+    *taken = true;
     return CSRK_OK;
 }
 

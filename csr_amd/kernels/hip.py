@@ -634,6 +634,16 @@ def spgemm_order():
     return 'reference' if o.value else 'ascending'
 
 
+def spgemm_last_route():
+    """
+    what this thread's last mult_ab / mult_abt took: 'dense-panel' -- B was a fully populated CSR in row-major panel form
+    (BASELINE configs[2] through the reference's own entry: csr/csr.py:524-567 -> multiply.py:13-38) -- or 'general'
+    """
+    r = C.c_int(0)
+    check(lib.csrk_spgemm_last_route(C.byref(r)))
+    return 'dense-panel' if r.value else 'general'
+
+
 def set_spmv_algo(h, name):
     "select the SpMV kernel for this handle: 'auto' | 'merge' | 'vector' | 'scalar'"
     code = {'auto': _lib.SPMV_AUTO, 'merge': _lib.SPMV_MERGE, 'vector': _lib.SPMV_VECTOR,

@@ -189,6 +189,18 @@ CSRK_API int csrk_spgemm_abt(csrk_handle_t a, csrk_handle_t b, csrk_handle_t *c)
  * value has the same bits either way.  csrk_spgemm_get_order: the order in force (0 or 1). */
 CSRK_API int csrk_spgemm_set_order(int order);
 CSRK_API int csrk_spgemm_get_order(int *order);
+/* A x dense B through the reference's own entry (BASELINE configs[2]: the reference has no dense-panel call; a caller hands
+ * B over as a fully populated CSR, csr/csr.py:524-567 -> multiply.py:13-38).  csrk_spgemm_ab / _abt recognise such a B on the
+ * device -- every row holds all k columns 0 .. k - 1 in ascending order, so that its values ARE the row-major panel -- and
+ * run the dense-panel kernels (csrk_spmm_dense's), writing C as the reference returns it: int32 row pointers with k entries
+ * per row of C whose row of A holds an entry and none otherwise, columns k - 1 .. 0 (reverse order of first discovery,
+ * multiply.py:79-82, 94-97), explicit zeros kept, values = the panel's sums (work[c] += a * b over the row's entries in
+ * storage order, :110-122: bit for bit for rows of A of at most 64 entries, the dense-panel kernels' fixed order of
+ * partial sums beyond -- within 1e-12 of sum |a b|).  A B whose rows are short of a column or in another order, and
+ * float32 values on BOTH operands (float32 products, multiply.py:120), take the general product.  CSRK_SPGEMM_DENSE=0
+ * switches the route off.  csrk_spgemm_last_route: what the calling thread's last product took -- 0 the general product,
+ * 1 the dense-panel route. */
+CSRK_API int csrk_spgemm_last_route(int *route);
 
 /* ---- dense-panel SpMM: C = A B, B dense row-major [ncols x k] --------------------------
  * Not a reference entry point (the reference's mult_ab is sparse x sparse only); serves

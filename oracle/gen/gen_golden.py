@@ -288,18 +288,33 @@ def gen_spmm_dense(n=12):
     """
     The dense-panel product of BASELINE.json configs[2] through the reference's own entry point: B [ncols x k] handed to
     K.mult_ab as a fully populated CSR (csr/kernels/numba/multiply.py:13-38; numeric recurrence :110-122), the raw
-    product (explicit zeros kept) densified.  k in {1, 7, 64}.
+    product (explicit zeros kept) densified AND as the reference returns it (raw rowptrs / colinds / values: k entries per
+    row of C whose row of A holds an entry, columns in reverse order of first discovery, multiply.py:79-82, 94-97).
+    k in {1, 7, 64}.  Cases n and n + 1 (appended: the first n keep their inputs): the rows of B in a shuffled column
+    order -- a dense B that is not the row-major panel -- and an A with whole blocks of empty rows.
     """
     rng = np.random.default_rng(64064)
-    d = {'n': np.array(n)}
-    for c in range(n):
-        k = (1, 7, 64)[c % 3]
+    d = {'n': np.array(n + 2)}
+    for c in range(n + 2):
+        k = (1, 7, 64)[c % 3] if c < n else (7, 64)[c - n]
         A = draw_csr(rng, values=True, dtype='f4' if c % 4 == 3 else 'f8')
+        if c == n + 1:                                        # rows 3 .. 3 + a third of them emptied
+            keep = np.ones(A.nrows, dtype=bool)
+            keep[3:3 + A.nrows // 3] = False
+            rows = np.repeat(np.arange(A.nrows), np.diff(A.rowptrs))
+            m = keep[rows]
+            A = CSR.from_coo(rows[m].astype(np.int32), A.colinds[m].copy(), A.values[m].copy(), (A.nrows, A.ncols))
         B = rng.uniform(-1.0, 1.0, size=(A.ncols, k))
         if c == 5:
             B[rng.integers(0, A.ncols), :] = 0.0              # a zero row of B: explicit zeros in the product
-        Bc = CSR(A.ncols, k, A.ncols * k, np.arange(A.ncols + 1, dtype=np.int32) * k,
-                 np.tile(np.arange(k, dtype=np.int32), A.ncols), B.reshape(-1).copy())
+        cols = np.tile(np.arange(k, dtype=np.int32), A.ncols)
+        vals = B.reshape(-1).copy()
+        if c == n:                                            # every row of B in its own column order
+            for j in range(A.ncols):
+                o = rng.permutation(k)
+                cols[j * k:(j + 1) * k] = o
+                vals[j * k:(j + 1) * k] = B[j, o]
+        Bc = CSR(A.ncols, k, A.ncols * k, np.arange(A.ncols + 1, dtype=np.int32) * k, cols, vals)
         raw = K.mult_ab(K.to_handle(A), K.to_handle(Bc))
         Cd = np.zeros((A.nrows, k))
         rp, ci, vs = np.asarray(raw.rowptrs), np.asarray(raw.colinds), np.asarray(raw.values)
@@ -307,8 +322,11 @@ def gen_spmm_dense(n=12):
             Cd[i, ci[rp[i]:rp[i + 1]]] = vs[rp[i]:rp[i + 1]]
         put(d, f'c{c}_a_', A)
         d[f'c{c}_B'] = B
+        d[f'c{c}_b_colinds'] = cols
+        d[f'c{c}_b_values'] = vals
         d[f'c{c}_C'] = Cd
         d[f'c{c}_raw_nnz'] = np.array(raw.nnz)
+        d[f'c{c}_raw_rowptrs'], d[f'c{c}_raw_colinds'], d[f'c{c}_raw_values'] = rp.copy(), ci.copy(), vs.copy()
     np.savez_compressed(os.path.join(OUT, 'spmm_dense.npz'), **d)
 
 

@@ -691,6 +691,134 @@ def test_spmm_dense_golden(golden):
         assert np.all(np.abs(Cm - Cref) <= 1e-12 * bound + 1e-300), c
 
 
+def _panel_csr(B, cols=None, vals=None, ptr64=False):
+    "B [n x k] as the fully populated CSR a reference caller hands to mult_ab (row-major unless cols / vals are given)"
+    from csr_amd import CSR
+    n, k = B.shape
+    rp = np.arange(n + 1, dtype=np.int64 if ptr64 else np.int32) * k
+    cols = np.tile(np.arange(k, dtype=np.int32), n) if cols is None else cols
+    vals = B.reshape(-1).copy() if vals is None else vals
+    return CSR(n, k, n * k, rp, cols, vals, _cast=False)
+
+
+def test_mult_ab_with_a_dense_b_golden(golden):
+    """
+    BASELINE configs[2] through the reference's OWN entry point: K.mult_ab(A, CSR(B)) with B fully populated
+    (csr/csr.py:524-567 -> csr/kernels/numba/multiply.py:13-38).  The library recognises the row-major panel on the
+    device and runs the dense-panel kernels; what comes back are the reference's raw arrays bit for bit (fixtures:
+    oracle/gen/gen_golden.py gen_spmm_dense, captured from the imported reference): int32 rowptrs with k entries per row
+    of C whose row of A holds an entry, colinds k - 1 .. 0, explicit zeros kept (case 5: a zero row of B), values equal
+    bit for bit (every fixture row has at most 64 entries: one segment, the reference's order of additions).
+    f8 and f4 values on A, k in {1, 7, 64}; case 12 (rows of B in shuffled column order) must take the general product
+    and still return the reference's arrays; case 13 has blocks of empty rows in A.
+    """
+    from csr_amd.kernels import hip as K
+    g = golden('spmm_dense')
+    routes = []
+    for c in range(int(g['n'])):
+        a = Mat(g, f'c{c}_a_')
+        B = g[f'c{c}_B']
+        bh = K.to_handle(_panel_csr(B, g[f'c{c}_b_colinds'], g[f'c{c}_b_values']))
+        ah = K.to_handle(_csr(a))
+        try:
+            ch = K.mult_ab(ah, bh)
+            routes.append(K.spgemm_last_route())
+            C = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(ah)
+            K.release_handle(bh)
+        assert (C.nrows, C.ncols, C.nnz) == (a.nrows, B.shape[1], int(g[f'c{c}_raw_nnz'])), c
+        assert C.rowptrs.dtype == np.int32 and np.array_equal(C.rowptrs, g[f'c{c}_raw_rowptrs']), c
+        assert np.array_equal(C.colinds, g[f'c{c}_raw_colinds']), c
+        assert C.values.dtype == np.float64 and np.array_equal(C.values, g[f'c{c}_raw_values']), c
+    assert routes[12] == 'general' and all(r == 'dense-panel' for i, r in enumerate(routes) if i != 12 and int(g[f'c{i}_a_shape'][2]) > 0)
+
+
+@pytest.mark.parametrize('k,dtype,ptr64', [(64, np.float64, False), (7, np.float32, False), (130, np.float64, True), (1, np.float64, False)])
+def test_mult_ab_with_a_dense_b_vs_oracle(k, dtype, ptr64, monkeypatch):
+    """
+    The same route on a power-law A with rows far beyond one segment (and, forced, the heavy-row kernels), against the
+    pinned oracle's orc_mult_ab on the same two CSR operands: rowptrs and colinds bit for bit, values bit for bit on the
+    rows of at most 64 entries and within 1e-12 of sum |a b| on the longer ones (the dense-panel kernels add a long row's
+    partial sums in their own fixed order).  CSR.multiply on top of it drops the exact zeros like the reference does
+    (csr/csr.py:555).  int64 row pointers on both operands in one case; a float32 B under float64 A is widened.
+    """
+    from oracle import oracle as O
+    from csr_amd.kernels import hip as K
+    monkeypatch.setenv('CSRK_SPMM_HEAVY', '1')
+    rng = np.random.default_rng(1000 + k)
+    lens = np.minimum((rng.pareto(0.9, 6000) * 3).astype(np.int64), 7000)
+    lens[rng.integers(0, 6000, 900)] = 0
+    A = _rand(rng, 6000, 5000, lens, dtype=dtype, ptr64=ptr64)
+    B = rng.uniform(-1, 1, (A.ncols, k)).astype(np.float32 if k == 130 else np.float64)
+    B[17, :] = 0.0
+    Bc = _panel_csr(B, ptr64=ptr64)
+    ah, bh = K.to_handle(A), K.to_handle(Bc)
+    try:
+        ch = K.mult_ab(ah, bh)
+        route = K.spgemm_last_route()
+        C = K.from_handle(ch)
+        K.release_handle(ch)
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+    assert route == 'dense-panel'
+    _, _, rp, ci, vs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), (Bc.nrows, Bc.ncols, Bc.rowptrs, Bc.colinds, Bc.values))
+    assert C.rowptrs.dtype == np.int32 and np.array_equal(C.rowptrs, rp) and np.array_equal(C.colinds, ci)
+    _, _, _, _, bound = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, np.abs(A.values)),
+                                  (Bc.nrows, Bc.ncols, Bc.rowptrs, Bc.colinds, np.abs(Bc.values)))
+    assert np.all(np.abs(C.values - vs) <= 1e-12 * bound + 1e-300)
+    short = np.repeat(np.diff(A.rowptrs) <= 64, np.diff(rp))
+    assert short.any() and (~short).any() and np.array_equal(C.values[short], vs[short])
+    # the caller's product: exact zeros dropped, as csr/csr.py:555 does
+    P = A.multiply(Bc)
+    keep = vs != 0.0
+    assert P.nnz == int(keep.sum()) and np.array_equal(P.colinds, ci[keep]) and np.array_equal(P.values, C.values[keep])
+
+
+def test_mult_ab_dense_route_declines(monkeypatch):
+    "what is NOT a row-major panel takes the general product: a row short of one column, float32 on both operands, the switch"
+    from oracle import oracle as O
+    from csr_amd import CSR
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(77)
+    A = _rand(rng, 300, 200, rng.integers(0, 30, 300))
+    B = rng.uniform(-1, 1, (200, 8))
+
+    def run(a, b):
+        ah, bh = K.to_handle(a), K.to_handle(b)
+        try:
+            ch = K.mult_ab(ah, bh)
+            r = K.spgemm_last_route()
+            c = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(ah)
+            K.release_handle(bh)
+        _, _, rp, ci, vs = O.mult_ab((a.nrows, a.ncols, a.rowptrs, a.colinds, a.values), (b.nrows, b.ncols, b.rowptrs, b.colinds, b.values))
+        assert np.array_equal(c.rowptrs, rp) and np.array_equal(c.colinds, ci) and np.array_equal(c.values, vs)
+        return r
+
+    full = _panel_csr(B)
+    assert run(A, full) == 'dense-panel'
+    # the same entries minus one: nnz no longer nrows * ncols
+    keep = np.ones(full.nnz, dtype=bool)
+    keep[8 * 50 + 3] = False
+    rp = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(200), 8)[keep], minlength=200))]).astype(np.int32)
+    assert run(A, CSR(200, 8, full.nnz - 1, rp, full.colinds[keep], full.values[keep], _cast=False)) == 'general'
+    # right count, wrong place: one row holds a column twice and lacks another
+    cols = full.colinds.copy()
+    cols[8 * 20 + 5] = 4
+    assert run(A, CSR(200, 8, full.nnz, full.rowptrs, cols, full.values, _cast=False)) == 'general'
+    # float32 x float32: the reference rounds every product to float32 (multiply.py:120)
+    A32 = CSR(A.nrows, A.ncols, A.nnz, A.rowptrs, A.colinds, A.values.astype(np.float32), _cast=False)
+    B32 = CSR(200, 8, full.nnz, full.rowptrs, full.colinds, full.values.astype(np.float32), _cast=False)
+    assert run(A32, B32) == 'general'
+    monkeypatch.setenv('CSRK_SPGEMM_DENSE', '0')
+    assert run(A, full) == 'general'
+
+
 @pytest.mark.parametrize('k', [64, 7, 130])
 def test_spmm_dense(k):
     from oracle import oracle as O

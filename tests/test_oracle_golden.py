@@ -204,6 +204,33 @@ def test_spmm_dense_golden(golden):
     assert ks == {1, 7, 64} and f4 >= 2
 
 
+def test_mult_ab_with_a_dense_b_golden(golden):
+    """
+    The same products as the reference returns them -- raw rowptrs / colinds / values of K.mult_ab(A, CSR(B)) -- pin
+    orc_mult_ab on fully populated B's: k entries per row of C whose row of A holds an entry, none otherwise, columns in
+    reverse order of first discovery (for row-major B rows: k - 1 .. 0), explicit zeros kept (multiply.py:79-82, 94-97).
+    Case 12 has every row of B in a shuffled column order, case 13 blocks of empty rows in A.
+    """
+    g = golden('spmm_dense')
+    shuffled = gaps = 0
+    for c in range(int(g['n'])):
+        a = Mat(g, f'c{c}_a_')
+        k = g[f'c{c}_B'].shape[1]
+        brp = np.arange(a.ncols + 1, dtype=np.int32) * k
+        _, _, rp, ci, vs = O.mult_ab((a.nrows, a.ncols, a.rowptrs, a.colinds, a.values),
+                                     (a.ncols, k, brp, g[f'c{c}_b_colinds'], g[f'c{c}_b_values']))
+        assert np.array_equal(rp, g[f'c{c}_raw_rowptrs']) and np.array_equal(ci, g[f'c{c}_raw_colinds']), c
+        assert np.array_equal(vs, g[f'c{c}_raw_values']), c
+        rowmajor = np.array_equal(g[f'c{c}_b_colinds'], np.tile(np.arange(k, dtype=np.int32), a.ncols))
+        shuffled += not rowmajor
+        live = np.diff(a.rowptrs) > 0
+        gaps += int((~live).sum() > a.nrows // 4)
+        assert np.array_equal(np.diff(rp), live * k)
+        if rowmajor:
+            assert np.array_equal(ci, np.tile(np.arange(k - 1, -1, -1, dtype=np.int32), int(live.sum())))
+    assert shuffled == 1 and gaps >= 1
+
+
 def test_spmm_dense_matches_dense_product():
     rng = np.random.default_rng(3)
     nr, nc, k = 37, 23, 5
