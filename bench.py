@@ -69,6 +69,7 @@ def parse():
                     help='N = 1: skip the `secondary` block (SpMM configs[2], transpose + A B^T configs[4], unit_rows on the '
                          'headline matrix: bench_secondary.py), which adds ~30 s after the SpMV has been timed')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
+    ap.add_argument('--secondary-seconds', type=float, default=240.0, help='N = 1: time limit of the secondary block (a child process)')
     ap.add_argument('--traffic-json', default=None, help='rocprofv3 PMC summary with per-launch HBM bytes')
     return ap.parse_args()
 
@@ -628,12 +629,30 @@ def main():
         # the other BASELINE configs, AFTER the SpMV has been timed and checked (nothing above depends on this):
         # each entry carries ms, algorithmic bytes, frac of 8 TB/s, a parity flag and the oracle's time on a stated sample
         # (a Python error anywhere in here must not cost the line that has been timed and verified above)
+        # It runs as a CHILD process under a time limit: a hang or a GPU fault among its five kernel families cannot cost
+        # the line above, which this process still holds (never a re-exec: a child, started after this process's own GPU
+        # work is done and its matrix freed).
+        import subprocess
+        del y, rp, ci, vs, x
         try:
-            import bench_secondary
-            del y
             check(lib.csrk_trim_cache())
-            out['secondary'] = bench_secondary.run_all(dev, headline=(rp, ci, vs, nrows, ncols), product_ms=ms_per_step,
-                                                       log=lambda m: print(m, file=sys.stderr, flush=True))
+            torch.cuda.empty_cache()
+        except Exception:                     # noqa: BLE001
+            pass
+        cmd = [sys.executable, os.path.join(ROOT, 'bench_secondary.py'), '--product-ms', repr(float(ms_per_step))]
+        try:
+            child = subprocess.Popen(cmd, stdout=subprocess.PIPE, cwd=ROOT)
+            try:
+                so, _ = child.communicate(timeout=args.secondary_seconds)
+                lines = [ln for ln in so.decode(errors='replace').splitlines() if ln.startswith('{')]
+                if child.returncode == 0 and lines:
+                    out['secondary'] = json.loads(lines[-1])
+                else:
+                    out['secondary'] = {'error': f'the secondary process ended with code {child.returncode} and {len(lines)} result line(s)'}
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.communicate()
+                out['secondary'] = {'error': f'the secondary process was stopped after {args.secondary_seconds:.0f} s'}
         except Exception as e:                # noqa: BLE001
             out['secondary'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     if rank == 0:

@@ -77,7 +77,7 @@ def ml_matrix(dev):
     return m
 
 
-def spmm(dev, reps=10, cpu_entries=2_000_000):
+def spmm(dev, reps=10, cpu_entries=None):
     from oracle import oracle as O
     n, nnz, k = 2_000_000, 50_000_000, 64
     m = synth.powerlaw_csr(n, n, nnz, device=dev, max_degree=250_000)
@@ -97,9 +97,10 @@ def spmm(dev, reps=10, cpu_entries=2_000_000):
     check(lib.csrk_spmv_device(habs, xa.data_ptr(), bound.data_ptr(), None))
     torch.cuda.synchronize()
     col0 = float(((Cm[:, 0] - y).abs() / (bound + 1e-300)).max())
-    # oracle on the first rows holding ~cpu_entries entries: baseline + parity sample
+    # the oracle on the WHOLE of configs[2] (cpu_entries=None; ~4 s on one core) or on the first rows holding ~cpu_entries
+    # entries: baseline + parity
     rp_h = m['rowptrs'].cpu().numpy()
-    r_s = int(np.searchsorted(rp_h, cpu_entries))
+    r_s = n if cpu_entries is None else int(np.searchsorted(rp_h, cpu_entries))
     e_s = int(rp_h[r_s])
     ci_h, vs_h = m['colinds'][:e_s].cpu().numpy(), m['values'][:e_s].cpu().numpy()
     B_h = B.cpu().numpy()
@@ -150,7 +151,8 @@ def spmm(dev, reps=10, cpu_entries=2_000_000):
            'gather_bound': gather,
            'via_mult_ab': via,
            'cpu_baseline': {'value': round(2.0 * e_s * k / t_cpu / 1e9, 3), 'unit': 'GFLOP/s', 'cores': 1, 'kind': 'port',
-                            'sample': f'the first {r_s} rows of A ({e_s} entries) x the same B, one pass of orc_spmm_dense ({t_cpu:.2f} s)'}}
+                            'sample': (f'the whole of configs[2] ({e_s} entries)' if r_s == n else f'the first {r_s} rows of A ({e_s} entries)') +
+                                      f' x the same B, one pass of orc_spmm_dense ({t_cpu:.2f} s)'}}
     return out
 
 
@@ -537,3 +539,43 @@ def run_all(dev, headline=None, log=None, product_ms=None):
         pass
     out['seconds'] = round(time.perf_counter() - t_all, 2)
     return out
+
+
+def main():
+    """
+    `python bench_secondary.py [--product-ms MS] [--only NAME ...]`: the secondary block as a process of its own -- how
+    bench.py runs it (a child process: a hang or a GPU fault in here cannot cost the headline line, which the parent has
+    timed and verified and still holds).  Prints ONE JSON object (the `secondary` value) as the last line of stdout.
+    """
+    import argparse
+    import json
+    import sys
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--product-ms', type=float, default=None, help="the headline product's step time (for `protocol`'s split)")
+    ap.add_argument('--only', nargs='*', default=None, help='run only these parts (spmm transpose abt unit_rows protocol spmv_f32)')
+    a = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    n, nnz = 10_000_000, 200_000_000
+    m = synth.powerlaw_csr(n, n, nnz, alpha=1.1, device=dev)
+    head = (m['rowptrs'], m['colinds'], m['values'], n, n)
+    log = lambda t: print(t, file=sys.stderr, flush=True)      # noqa: E731
+    if a.only:
+        out = {}
+        fns = {'spmm': lambda: spmm(dev), 'transpose': lambda: transpose(dev), 'abt': lambda: abt(dev),
+               'unit_rows': lambda: unit_rows(dev, *head), 'protocol': lambda: protocol(dev, *head, product_ms=a.product_ms),
+               'spmv_f32': lambda: spmv_f32(dev, *head)}
+        for name in a.only:
+            t0 = time.perf_counter()
+            try:
+                out[name] = fns[name]()
+            except Exception as e:            # noqa: BLE001
+                out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            out[name]['seconds'] = round(time.perf_counter() - t0, 2)
+    else:
+        out = run_all(dev, headline=head, log=log, product_ms=a.product_ms)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()
