@@ -111,21 +111,35 @@ void pool_free(void *p)
 }
 
 namespace {
-std::mutex g_stage_mu;
-void *g_stage = nullptr;
-size_t g_stage_bytes = 0;
+// One pinned staging buffer per DEVICE (plan builds on different GPUs -- dist.py's ranks in one process, nogil callers --
+// do not wait for each other), grown on demand up to STAGE_CAP; larger tables go through the runtime's own copy.
+constexpr int STAGE_MAX_DEV = 16;
 constexpr size_t STAGE_DIRECT = 1024;          // copies of at most this many bytes: the runtime's own path
+constexpr size_t STAGE_CAP = 64u << 20;        // ... and of more than this many
+struct Stage {
+    std::mutex mu;
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+Stage g_stages[STAGE_MAX_DEV];
 
-int stage_room_locked(size_t n)
+Stage *stage_of_current_device()
 {
-    if (g_stage_bytes >= n) return CSRK_OK;
-    if (g_stage) (void)hipHostFree(g_stage);
-    g_stage = nullptr;
-    g_stage_bytes = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return &g_stages[(dev < 0 ? 0 : dev) % STAGE_MAX_DEV];
+}
+
+int stage_room_locked(Stage *st, size_t n)
+{
+    if (st->bytes >= n) return CSRK_OK;
+    if (st->p) (void)hipHostFree(st->p);
+    st->p = nullptr;
+    st->bytes = 0;
     size_t want = 1u << 20;
     while (want < n) want <<= 1;
-    CSRK_HIP(hipHostMalloc(&g_stage, want, hipHostMallocPortable | hipHostMallocMapped));
-    g_stage_bytes = want;
+    CSRK_HIP(hipHostMalloc(&st->p, want, hipHostMallocPortable | hipHostMallocMapped));
+    st->bytes = want;
     return CSRK_OK;
 }
 
@@ -153,33 +167,46 @@ int stage_copy(const void *src, void *dst, size_t n, hipStream_t s)
 }
 }  // namespace
 
+// the pinned staging buffers go back to the runtime (csrk_trim_cache)
+void stage_release_all()
+{
+    for (Stage &st : g_stages) {
+        std::lock_guard<std::mutex> lk(st.mu);
+        if (st.p) (void)hipHostFree(st.p);
+        st.p = nullptr;
+        st.bytes = 0;
+    }
+}
+
 int stage_d2h(void *host_dst, const void *dev_src, size_t n, hipStream_t s)
 {
     if (n == 0) return CSRK_OK;
-    if (n <= STAGE_DIRECT) {
+    if (n <= STAGE_DIRECT || n > STAGE_CAP) {
         CSRK_HIP(hipMemcpyAsync(host_dst, dev_src, n, hipMemcpyDeviceToHost, s));
         CSRK_HIP(hipStreamSynchronize(s));
         return CSRK_OK;
     }
-    std::lock_guard<std::mutex> lk(g_stage_mu);
-    CSRK_TRY(stage_room_locked(n));
-    CSRK_TRY(stage_copy(dev_src, g_stage, n, s));
-    memcpy(host_dst, g_stage, n);
+    Stage *st = stage_of_current_device();
+    std::lock_guard<std::mutex> lk(st->mu);
+    CSRK_TRY(stage_room_locked(st, n));
+    CSRK_TRY(stage_copy(dev_src, st->p, n, s));
+    memcpy(host_dst, st->p, n);
     return CSRK_OK;
 }
 
 int stage_h2d(void *dev_dst, const void *host_src, size_t n, hipStream_t s)
 {
     if (n == 0) return CSRK_OK;
-    if (n <= STAGE_DIRECT) {
+    if (n <= STAGE_DIRECT || n > STAGE_CAP) {
         CSRK_HIP(hipMemcpyAsync(dev_dst, host_src, n, hipMemcpyHostToDevice, s));
         CSRK_HIP(hipStreamSynchronize(s));       // (the caller's buffer may go out of scope)
         return CSRK_OK;
     }
-    std::lock_guard<std::mutex> lk(g_stage_mu);
-    CSRK_TRY(stage_room_locked(n));
-    memcpy(g_stage, host_src, n);
-    CSRK_TRY(stage_copy(g_stage, dev_dst, n, s));      // (waits: the staging buffer is the next copy's)
+    Stage *st = stage_of_current_device();
+    std::lock_guard<std::mutex> lk(st->mu);
+    CSRK_TRY(stage_room_locked(st, n));
+    memcpy(st->p, host_src, n);
+    CSRK_TRY(stage_copy(st->p, dev_dst, n, s));      // (waits: the staging buffer is the next copy's)
     return CSRK_OK;
 }
 
@@ -315,8 +342,11 @@ int csrk_set_device(int device)
 int csrk_trim_cache(void)
 {
     CSRK_HIP(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    pool_trim_locked(0);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+    }
+    stage_release_all();
     return CSRK_OK;
 }
 

@@ -239,9 +239,12 @@ typedef double hr_d8 __attribute__((ext_vector_type(8)));
 // acc[I / 2] += V * Bv for eight entries, the accumulators being v[64:127] (A0 .. A3): VGPR index mode with relative
 // destination and addend, switched on ONCE for the eight (s_set_gpr_idx_idx moves the index; entering and leaving the
 // mode per entry cost more than everything else the entry needs).  Nothing but the FMAs may execute in between -- the
-// mode applies to every vector instruction -- hence one asm statement.
+// mode applies to every vector instruction -- hence one asm statement.  s_set_gpr_idx_* write M0[7:0] and M0[15:12]; the
+// compiler does not accept M0 in a clobber list (reserved), so the statement saves and restores it itself (`m0_keep`: a
+// scratch SGPR the caller declares).
 #define HR_FMA8(I, V, Bv) \
-    asm volatile("s_set_gpr_idx_on %[i0], 0xc\n\t" \
+    asm volatile("s_mov_b32 %[m0s], m0\n\t" \
+                 "s_set_gpr_idx_on %[i0], 0xc\n\t" \
                  "v_fma_f64 v[64:65], %[v0], %[b0], v[64:65]\n\t" \
                  "s_set_gpr_idx_idx %[i1]\n\t" \
                  "v_fma_f64 v[64:65], %[v1], %[b1], v[64:65]\n\t" \
@@ -257,8 +260,9 @@ typedef double hr_d8 __attribute__((ext_vector_type(8)));
                  "v_fma_f64 v[64:65], %[v6], %[b6], v[64:65]\n\t" \
                  "s_set_gpr_idx_idx %[i7]\n\t" \
                  "v_fma_f64 v[64:65], %[v7], %[b7], v[64:65]\n\t" \
-                 "s_set_gpr_idx_off" \
-                 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3) \
+                 "s_set_gpr_idx_off\n\t" \
+                 "s_mov_b32 m0, %[m0s]" \
+                 : "+{v[64:79]}"(A0), "+{v[80:95]}"(A1), "+{v[96:111]}"(A2), "+{v[112:127]}"(A3), [m0s] "=&s"(m0_keep) \
                  : [i0] "s"(I[0]), [i1] "s"(I[1]), [i2] "s"(I[2]), [i3] "s"(I[3]), [i4] "s"(I[4]), [i5] "s"(I[5]), [i6] "s"(I[6]), [i7] "s"(I[7]), [v0] "s"(V[0]), [v1] "s"(V[1]), [v2] "s"(V[2]), [v3] "s"(V[3]), [v4] "s"(V[4]), [v5] "s"(V[5]), [v6] "s"(V[6]), [v7] "s"(V[7]), [b0] "v"(Bv[0]), [b1] "v"(Bv[1]), [b2] "v"(Bv[2]), [b3] "v"(Bv[3]), [b4] "v"(Bv[4]), [b5] "v"(Bv[5]), [b6] "v"(Bv[6]), [b7] "v"(Bv[7]))
 
 // The first M (<= 64) entries of a chunk held one per lane in CI (entry words) / CV (values): batches of eight at
@@ -287,6 +291,7 @@ typedef double hr_d8 __attribute__((ext_vector_type(8)));
                     v_[u_] = mine_ ? v_[u_] : 0.0;                                                                     \
                 }                                                                                                      \
             }                                                                                                          \
+            uint32_t m0_keep;                                                                                          \
             HR_FMA8(ix_, v_, b_);                                                                                      \
         }                                                                                                              \
     } while (0)

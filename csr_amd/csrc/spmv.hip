@@ -1181,7 +1181,7 @@ __global__ void spmv_vector_fixup_kernel(const int64_t *__restrict__ seg_off, in
 }
 
 // ---- scalar: one lane per row ----------------------------------------------------------------
-template <class P, int VT>
+template <class P, int VT, bool R32 = false>
 __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                                          const void *__restrict__ vs, const double *__restrict__ x,
                                                          double *__restrict__ y, int32_t nrows)
@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
     if (r >= nrows) return;
     int64_t s = rp[r], e = rp[r + 1];
     double acc = 0.0;
-    for (int64_t k = s; k < e; k++) acc += x[ci[k]] * ValLoad<VT>::at(vs, k);
+    for (int64_t k = s; k < e; k++) acc += spmv_prod<R32>(ValLoad<VT>::at(vs, k), x[ci[k]]);
     y[r] = acc;
 }
 
@@ -1531,7 +1531,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     }
     case CSRK_SPMV_SCALAR: {
         KernelTimer kt(p, s);
-        spmv_scalar_kernel<P, VT><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->d_colinds, m->d_values, d_x,
+        // (R32: a float32 matrix of fewer than two entries under the merge algorithm lands here with its float32 products)
+        spmv_scalar_kernel<P, VT, R32><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->d_colinds, m->d_values, d_x,
                                                                                   d_y, m->nrows);
         kt.stop();
         CSRK_LAUNCH_CHECK();

@@ -819,6 +819,40 @@ def test_mult_ab_dense_route_declines(monkeypatch):
     assert run(A, full) == 'general'
 
 
+@pytest.mark.parametrize('route', ['dense-panel', 'general'])
+def test_mult_ab_overflow_is_an_error_before_any_numeric_pass(route, monkeypatch):
+    """
+    A product of more than 2^31 - 1 entries cannot have the reference's int32 row pointers (multiply.py:28): CSRK_ERR_OVERFLOW
+    with the reason, from the count alone -- no numeric pass runs, nothing of that size is allocated -- on both routes
+    (600 000 rows of one entry each times a fully populated 1 x 4096 B: 2.46e9 entries), and the handles stay usable.
+    """
+    from csr_amd import CSR
+    from csr_amd._lib import CsrkError
+    from csr_amd.kernels import hip as K
+    if route == 'general':
+        monkeypatch.setenv('CSRK_SPGEMM_DENSE', '0')
+    n, k = 600_000, 4096
+    A = CSR(n, 1, n, np.arange(n + 1, dtype=np.int32), np.zeros(n, dtype=np.int32), np.ones(n), _cast=False)
+    B = _panel_csr(np.arange(k, dtype=np.float64).reshape(1, k))
+    ah, bh = K.to_handle(A), K.to_handle(B)
+    try:
+        with pytest.raises(CsrkError, match='int32 row pointers'):
+            K.mult_ab(ah, bh)
+        assert K.spgemm_last_route() == 'general'         # (nothing was taken: the call failed)
+        assert np.array_equal(K.mult_vec(ah, np.array([2.0])), np.full(n, 2.0))
+        small = K.to_handle(CSR(2, 1, 2, np.array([0, 1, 2], dtype=np.int32), np.zeros(2, dtype=np.int32), np.array([1.0, 3.0]), _cast=False))
+        try:
+            ch = K.mult_ab(small, bh)
+            C = K.from_handle(ch)
+            K.release_handle(ch)
+        finally:
+            K.release_handle(small)
+        assert C.nnz == 2 * k and np.array_equal(C.values[k:], 3.0 * np.arange(k - 1, -1, -1.0))
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
+
+
 @pytest.mark.parametrize('k', [64, 7, 130])
 def test_spmm_dense(k):
     from oracle import oracle as O

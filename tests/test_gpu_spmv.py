@@ -557,6 +557,28 @@ def test_spmv_float32_vector(vals):
         assert np.max(np.abs(ref64 - ref)) > 1e-10
 
 
+@pytest.mark.parametrize('algo', ['auto', 'merge', 'scalar'])
+def test_spmv_float32_product_of_a_one_entry_matrix(algo):
+    """
+    float32 values times a float32 x on matrices of ONE entry and of none: under the merge algorithm these fall through to
+    the one-lane-per-row kernel (the tile kernel's pair loads need two entries), which must round the product to float32
+    like every other path (csr/kernels/numba/__init__.py:55-67 as Numba types it).  The entry is chosen so that
+    the float32 and the float64 product differ.
+    """
+    from csr_amd import CSR
+    from oracle import oracle as O
+    a, b = np.float32(1.0000001), np.float32(3.0000002)
+    assert np.float64(a) * np.float64(b) != np.float64(np.float32(a * b))
+    one = CSR(3, 4, 1, np.array([0, 0, 1, 1], dtype=np.int32), np.array([2], dtype=np.int32), np.array([a], dtype=np.float32), _cast=False)
+    x = np.array([0, 0, b, 0], dtype=np.float32)
+    for _ in range(3):                                   # (first call, plan call, planned call)
+        y = _mult_vec(one, x, algo)
+        ref = O.mult_vec(3, 4, one.rowptrs, one.colinds, one.values, x)
+        assert np.array_equal(y, ref) and y[1] == np.float64(np.float32(a * b))
+    none = CSR(3, 4, 0, np.zeros(4, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), _cast=False)
+    assert np.array_equal(_mult_vec(none, x, algo), np.zeros(3))
+
+
 def test_float32_matrix_keeps_float32_streams(split_mode):
     """
     A float32 matrix's plan stores float32 values in the tier-0 and light streams (6 and 8 bytes per entry instead of 10 and
