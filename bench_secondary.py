@@ -489,7 +489,7 @@ def spmv_f32(dev, rp=None, ci=None, vs=None, nrows=None, ncols=None, reps=20, cp
     check(lib.csrk_free(h))
     alg = nnz * 8 + (nrows + 1) * rp.element_size() + ncols * 4 + nrows * 8
     return {'config': f'mult_vec {nrows}x{ncols} nnz {nnz}, float32 values x float32 vector, y float64', 'entry': 'csrk_spmv_f32x_device',
-            'ms': round(ms, 4), 'timing': f'device events, {reps} products (the float32 vector is widened on the device inside the call)',
+            'ms': round(ms, 4), 'timing': f'device events, {reps} products (the kernels widen the float32 vector as they load it)',
             'gflops': round(2.0 * nnz / (ms * 1e-3) / 1e9, 1), 'bound': 'hbm', **_roof(alg, ms),
             'parity': {'sample_max_err_over_sum_abs_terms': err, 'tolerance': 1e-6,
                        'float32_products_differ_from_float64_by': float(np.max(np.abs(ref64 - ref) / (bound + 1e-300))),

@@ -67,7 +67,7 @@ void spmv_plan_bytes_by_part(const SpmvPlan *p, int64_t out[5])
     add(2, {&l->vals, &l->idx, &l->rowids, &l->tile_base, &l->carry_row, &l->carry_val});
     add(3, {&l->xg, &l->a_col, &l->a_dst, &l->blk_start, &l->round_start, &l->round_tile0, &l->wg_round0, &p->hot_slot, &p->hot_cols, &p->xh});
     add(4, {&p->tile_row, &p->carry_row, &p->carry_val, &p->rp_light, &p->cut_pos, &p->cut_cum, &p->tile_cut, &p->heavy_row, &p->seg_off,
-            &p->seg_row, &p->seg_part});
+            &p->seg_row, &p->seg_part, &p->xwide});
 }
 
 int64_t spmv_plan_bytes(const SpmvPlan *p)
@@ -325,11 +325,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void spmv_merge_kernel(
     }
 }
 
-__global__ void hot_pack_kernel(const double *__restrict__ x, const int32_t *__restrict__ hot_cols, int32_t n_hot,
+// XT: the type of the caller's x -- double, or float for csrk_spmv_f32x[_device]: the kernels that read x itself (the copy
+// pass, the accumulator kernel's windows, the pair kernel's gathers, this pack) widen it as they load it, exactly; the
+// light stream reads what the copy pass left (float64).
+template <class XT>
+__global__ void hot_pack_kernel(const XT *__restrict__ x, const int32_t *__restrict__ hot_cols, int32_t n_hot,
                                 double *__restrict__ xh)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_hot) xh[i] = x[hot_cols[i]];
+    if (i < n_hot) xh[i] = (double)x[hot_cols[i]];
 }
 
 // Tier 0's reduce as extra workgroups of the pair kernel's launch.  The accumulator kernel has finished when the pair kernel
@@ -343,10 +347,10 @@ struct PanelRider {
     int32_t H, n_wg;
 };
 
-template <class PP, int PT, bool R32 = false>
+template <class PP, int PT, bool R32 = false, class XT = double>
 __global__ __launch_bounds__(PT) void spmv_panel_kernel(
     const PP *__restrict__ prp, const int32_t *__restrict__ pci, const double *__restrict__ pvs,
-    const double *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
+    const XT *__restrict__ x, int32_t ncols, double *__restrict__ yp, const PanelTile *__restrict__ tiles,
     const PanelGroup *__restrict__ groups, int64_t n_prows, int32_t *__restrict__ carry_row,
     double *__restrict__ carry_val, int64_t pnnz, int32_t cb, PanelRider rider)
 {
@@ -419,12 +423,12 @@ __global__ __launch_bounds__(PT) void spmv_panel_kernel(
         if (more) nx = tiles[t + 1];
 
         __syncthreads();      // previous tile's LDS reads finished
-        const double *xw = x + (int64_t)pt.blk * cb;
+        const XT *xw = x + (int64_t)pt.blk * cb;
 #pragma unroll
         for (int u = 0; u < PPAIRS; u++) {
             const int k = 2 * (tid + u * PT);
-            const double t0 = spmv_prod<R32>(p0[u], xw[(uint32_t)c0[u] >> PANEL_POS_BITS]);
-            const double t1 = spmv_prod<R32>(p1[u], xw[(uint32_t)c1[u] >> PANEL_POS_BITS]);
+            const double t0 = spmv_prod<R32>(p0[u], (double)xw[(uint32_t)c0[u] >> PANEL_POS_BITS]);
+            const double t1 = spmv_prod<R32>(p1[u], (double)xw[(uint32_t)c1[u] >> PANEL_POS_BITS]);
             p0[u] = k < nn ? t0 : 0.0;       // masked after the multiply: 0 * inf would be NaN
             p1[u] = k + 1 < nn ? t1 : 0.0;
         }
@@ -542,10 +546,10 @@ template <> struct AccVals<float> {
     }
 };
 
-template <int CB, int PT, bool R32 = false, class SV = double>
+template <int CB, int PT, bool R32 = false, class SV = double, class XT = double>
 __global__ __launch_bounds__(PT) void spmv_acc_kernel(const SV *__restrict__ pvals, const uint16_t *__restrict__ pidx,
                                                      const int32_t *__restrict__ tile_row0,
-                                                     const double *__restrict__ x, int32_t ncols,
+                                                     const XT *__restrict__ x, int32_t ncols,
                                                      const AccSeg *__restrict__ segs, const int32_t *__restrict__ wg_seg,
                                                      int32_t H, double *__restrict__ partial)
 {
@@ -576,11 +580,19 @@ __global__ __launch_bounds__(PT) void spmv_acc_kernel(const SV *__restrict__ pva
                 constexpr int WL = CB / 2 / PT;
                 f64x2_t v[WL];
 #pragma unroll
-                for (int u = 0; u < WL; u++) v[u] = *((const F64x2 *)(x + w0) + tid + u * PT);
+                for (int u = 0; u < WL; u++) {
+                    if (sizeof(XT) == 8) {
+                        v[u] = *((const F64x2 *)(x + w0) + tid + u * PT);
+                    } else {
+                        const f32x2_t t = *((const F32x2 *)(x + w0) + tid + u * PT);
+                        v[u].x = (double)t.x;
+                        v[u].y = (double)t.y;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < WL; u++) ((f64x2_t *)s_x)[tid + u * PT] = v[u];
             } else {
-                for (int k = tid; k < wlen; k += PT) s_x[k] = x[w0 + k];
+                for (int k = tid; k < wlen; k += PT) s_x[k] = (double)x[w0 + k];
             }
         }
         __syncthreads();      // A: window stored; heads of the previous segment folded in; accumulators zeroed
@@ -1199,7 +1211,8 @@ __global__ __launch_bounds__(256) void spmv_scalar_kernel(const P *__restrict__ 
 // 128-B line in, wherever the line comes from: as L2 gathers this pass took 78 us for 9 * 10^6 entries).
 // Workgroup i takes block (i % 8) * (blocks / 8) + i / 8: the workgroups of one XCD (i % 8) walk consecutive blocks,
 // so the short runs that neighbouring blocks write into one line of xg meet in one L2 before they are written back.
-__global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double *__restrict__ x, int32_t ncols, int32_t W,
+template <class XT>
+__global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const XT *__restrict__ x, int32_t ncols, int32_t W,
                                                                    const uint16_t *__restrict__ a_col,
                                                                    const int32_t *__restrict__ a_dst,
                                                                    const int32_t *__restrict__ blk_start, int32_t nblk,
@@ -1220,7 +1233,7 @@ __global__ __launch_bounds__(LS_STAGE_THREADS) void ls_stage_kernel(const double
         c[q] = k < k1 ? (int32_t)__builtin_nontemporal_load(a_col + k) : -1;
         d[q] = k < k1 ? __builtin_nontemporal_load(a_dst + k) : 0;
     }
-    for (int i = threadIdx.x; i < W; i += LS_STAGE_THREADS) s_x[i] = c0 + i < ncols ? x[c0 + i] : 0.0;
+    for (int i = threadIdx.x; i < W; i += LS_STAGE_THREADS) s_x[i] = c0 + i < ncols ? (double)x[c0 + i] : 0.0;
     __syncthreads();
     for (int32_t kb = k0; kb < k1; kb += LS_STAGE_THREADS * LS_STAGE_IPT) {
         int32_t cn[LS_STAGE_IPT], dn[LS_STAGE_IPT];
@@ -1256,9 +1269,14 @@ int spmv_kernel_attributes()
                           (const void *)spmv_lstream_kernel<LS_PLAIN, false, false, float>, (const void *)spmv_lstream_kernel<LS_RND, false, false, float>,
                           (const void *)spmv_lstream_kernel<LS_PLAIN, true, false, float>, (const void *)spmv_lstream_kernel<LS_RND, true, false, float>,
                           (const void *)spmv_lstream_kernel<LS_PLAIN, false, true, float>, (const void *)spmv_lstream_kernel<LS_RND, false, true, float>,
-                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true, float>, (const void *)spmv_lstream_kernel<LS_RND, true, true, float>})
+                          (const void *)spmv_lstream_kernel<LS_PLAIN, true, true, float>, (const void *)spmv_lstream_kernel<LS_RND, true, true, float>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, false, double, float>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true, double, float>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, false, float, float>,
+                          (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true, float, float>})
         CSRK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-    CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
+    CSRK_HIP(hipFuncSetAttribute((const void *)ls_stage_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_STAGE_WMAX * 8)));
     return CSRK_OK;
 }
 
@@ -1311,9 +1329,11 @@ static int get_plan(Matrix *m, hipStream_t s, SpmvPlan **out)
     return get_plan_locked(m, s, out, false);
 }
 
-template <class P, int VT, bool R32 = false>
-static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, hipStream_t s, int part)
+// XT = float: the caller's x is float32 and the plan serves every row without the raw-array kernels (spmv_dispatch checks)
+template <class P, int VT, bool R32 = false, class XT = double>
+static int launch_spmv(Matrix *m, SpmvPlan *p, const XT *d_x, double *d_y, hipStream_t s, int part)
 {
+    constexpr bool X64 = sizeof(XT) == 8;
     const P *rp = (const P *)m->d_rowptrs;
     if (m->nrows == 0) return CSRK_OK;
     int algo = p->algo;
@@ -1373,14 +1393,14 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         if (do_light && p->ls.on && p->ls.n_cold) {
             KernelTimer ks(p, s, 3);
             const unsigned gs = (unsigned)(ceil_div(p->ls.n_stage_blk, 8) * 8);
-            ls_stage_kernel<<<gs, LS_STAGE_THREADS, (size_t)p->ls.stage_w * 8, s>>>(
+            ls_stage_kernel<XT><<<gs, LS_STAGE_THREADS, (size_t)p->ls.stage_w * 8, s>>>(
                 d_x, m->ncols, p->ls.stage_w, p->ls.a_col.as<uint16_t>(), p->ls.a_dst.as<int32_t>(),
                 p->ls.blk_start.as<int32_t>(), p->ls.n_stage_blk, p->ls.xg.as<double>());
             ks.stop();
             CSRK_LAUNCH_CHECK();
         }
         if (do_light && p->n_hot && !(p->ls.on && p->ls.n_cold)) {      // (with cold staging the pack is filled by ls_stage_kernel)
-            hot_pack_kernel<<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
+            hot_pack_kernel<XT><<<(unsigned)ceil_div(p->n_hot, 256), 256, 0, s>>>(d_x, p->hot_cols.as<int32_t>(), p->n_hot,
                                                                             p->xh.as<double>());
             CSRK_LAUNCH_CHECK();
         }
@@ -1389,11 +1409,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             KernelTimer kh(p, s, 1);
             for (AccPanel *ap : p->acc) {
                 if (ap->f32)
-                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32, float><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
+                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32, float, XT><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
                         ap->vals.as<float>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols,
                         ap->segs.as<AccSeg>(), ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
                 else
-                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
+                    spmv_acc_kernel<ACC_CB, ACC_THREADS, R32, double, XT><<<(unsigned)ap->n_wg, ACC_THREADS, ap->lds, s>>>(
                         ap->vals.as<double>(), ap->idx.as<uint16_t>(), ap->tile_row0.as<int32_t>(), d_x, m->ncols,
                         ap->segs.as<AccSeg>(), ap->wg_seg.as<int32_t>(), ap->nrow, ap->partial.as<double>());
                 CSRK_LAUNCH_CHECK();
@@ -1417,8 +1437,8 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 t0_rides = true;
             }
             const unsigned grid = (unsigned)(pn->groups + (t0_rides ? ceil_div(rider.H, WAVE) : 0));
-            if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
-            else spmv_panel_kernel<int32_t, PANEL_T1, R32><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
+            if (pn->p64) spmv_panel_kernel<int64_t, PANEL_T1, R32, XT><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int64_t));
+            else spmv_panel_kernel<int32_t, PANEL_T1, R32, XT><<<grid, PANEL_T1, 0, s>>>(PANEL_ARGS(int32_t));
 #undef PANEL_ARGS
             kh.stop();
             CSRK_LAUNCH_CHECK();
@@ -1436,7 +1456,7 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
             if (p->ls.on) {
                 KernelTimer kl(p, s);
                 constexpr size_t ls_lds = ((size_t)LS_HOT_LDS + (size_t)(LS_THREADS / WAVE) * (ACC_TILE + 2)) * 8;
-                const double *x_cold = d_x, *x_pack = p->xh.as<double>();
+                const double *x_cold = X64 ? (const double *)(const void *)d_x : nullptr, *x_pack = p->xh.as<double>();      // (float x: cold staging is on, spmv_dispatch checks)
                 if (p->ls.n_cold) {      // cold staging: the unpacked columns' x values, in the stream's order
                     x_cold = p->ls.xg.as<double>();
                     x_pack = x_cold + p->ls.n_cold;
@@ -1474,14 +1494,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                         p->ls.carry_row.as<int32_t>(), p->ls.carry_val.as<double>(), p->ls.n_tiles, d_y);
                     CSRK_LAUNCH_CHECK();
                 }
-            } else {
+            } else if constexpr (X64) {
             KernelTimer kt(p, s);
             if (p->n_heavy)
                 spmv_merge_kernel<P, VT, true, R32><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_LIGHT(m->d_colinds));
             else
                 spmv_merge_kernel<P, VT, false, R32><<<grid, MERGE_THREADS, 0, s>>>(MERGE_ARGS_FULL(m->d_colinds));
-#undef MERGE_ARGS_LIGHT
-#undef MERGE_ARGS_FULL
             kt.stop();
             CSRK_LAUNCH_CHECK();
             if (p->n_heavy)
@@ -1491,7 +1509,12 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
                 spmv_merge_fixup_kernel<<<(unsigned)ceil_div(p->n_tiles * WAVE, 256), 256, 0, s>>>(
                     p->carry_row.as<int32_t>(), p->carry_val.as<double>(), p->n_tiles, d_y);
             CSRK_LAUNCH_CHECK();
+            } else {
+                set_error("internal: a float32 vector reached the raw-array kernels");
+                return CSRK_ERR_INVALID;
             }
+#undef MERGE_ARGS_LIGHT
+#undef MERGE_ARGS_FULL
         }
         if (do_heavy && p->n_heavy && !p->acc.empty() && t0_rides) {
             AccPanel *ap = p->acc[0];
@@ -1516,6 +1539,10 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         break;
     }
     case CSRK_SPMV_VECTOR: {
+        if constexpr (!X64) {
+            set_error("internal: a float32 vector reached the raw-array kernels");
+            return CSRK_ERR_INVALID;
+        } else
         if (p->n_segs > 0) {
             KernelTimer kt(p, s);
             spmv_vector_kernel<P, VT><<<(unsigned)ceil_div(p->n_segs * WAVE, 256), 256, 0, s>>>(
@@ -1530,12 +1557,17 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
         break;
     }
     case CSRK_SPMV_SCALAR: {
+        if constexpr (!X64) {
+            set_error("internal: a float32 vector reached the raw-array kernels");
+            return CSRK_ERR_INVALID;
+        } else {
         KernelTimer kt(p, s);
         // (R32: a float32 matrix of fewer than two entries under the merge algorithm lands here with its float32 products)
         spmv_scalar_kernel<P, VT, R32><<<(unsigned)ceil_div(m->nrows, 256), 256, 0, s>>>(rp, m->d_colinds, m->d_values, d_x,
                                                                                   d_y, m->nrows);
         kt.stop();
         CSRK_LAUNCH_CHECK();
+        }
         break;
     }
     default:
@@ -1545,8 +1577,18 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const double *d_x, double *d_y, h
     return CSRK_OK;
 }
 
+__global__ void widen_f32_kernel(const float *__restrict__ in, double *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
 // r32: float32 values times a (widened) float32 vector -- products rounded to float32 (spmv_prod); merge algorithm only
-static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s, int part = 3, bool r32 = false)
+// d_x32: the caller's x is float32 (csrk_spmv_f32x[_device]).  When the plan serves every row from its own streams (tiers,
+// light stream, cold staging: everything but a handle's first product) the kernels that read x widen it as they load it;
+// otherwise it is widened into a buffer the plan keeps (no allocation and no synchronisation per call either way).
+static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t s, int part = 3, bool r32 = false,
+                         const float *d_x32 = nullptr)
 {
     // One SpMV = several kernels that share the plan's carry / partial arrays.  The per-handle lock keeps
     // the launch group together so that concurrent callers (the reference's kernels are nogil) are
@@ -1559,6 +1601,32 @@ static int spmv_dispatch(Matrix *m, const double *d_x, double *d_y, hipStream_t 
     // every n-th PRODUCT is timed: a product issued in two parts (part 1, then part 2) is one step, so part 2 keeps
     // the decision taken for its part 1 instead of counting as a call of its own
     if (part != 2) p->prof_this = p->profiling && (p->prof_calls++ % (p->prof_every > 0 ? p->prof_every : 1)) == 0;
+    if (d_x32) {
+        const bool streams_only = p->algo == CSRK_SPMV_MERGE && m->nnz >= 2 && p->ls.on && p->ls.n_cold > 0 && p->ls.round_start.p;
+        if (streams_only) {
+#define GOF(P, VT, R) return launch_spmv<P, VT, R, float>(m, p, d_x32, d_y, s, part)
+            if (r32) {
+                if (m->ptr64) GOF(int64_t, CSRK_VAL_F32, true);
+                GOF(int32_t, CSRK_VAL_F32, true);
+            }
+            if (m->ptr64) {
+                if (m->val_type == CSRK_VAL_F64) GOF(int64_t, CSRK_VAL_F64, false);
+                if (m->val_type == CSRK_VAL_F32) GOF(int64_t, CSRK_VAL_F32, false);
+                GOF(int64_t, CSRK_VAL_NONE, false);
+            } else {
+                if (m->val_type == CSRK_VAL_F64) GOF(int32_t, CSRK_VAL_F64, false);
+                if (m->val_type == CSRK_VAL_F32) GOF(int32_t, CSRK_VAL_F32, false);
+                GOF(int32_t, CSRK_VAL_NONE, false);
+            }
+#undef GOF
+        }
+        CSRK_TRY(p->xwide.ensure((size_t)m->ncols * 8 + 8));
+        if (m->ncols) {
+            widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256, 0, s>>>(d_x32, p->xwide.as<double>(), m->ncols);
+            CSRK_LAUNCH_CHECK();
+        }
+        d_x = p->xwide.as<double>();
+    }
 #define GO(P, VT) return launch_spmv<P, VT>(m, p, d_x, d_y, s, part)
     if (r32) {
         CSRK_REQUIRE(m->val_type == CSRK_VAL_F32 && p->algo == CSRK_SPMV_MERGE, "float32 products need float32 values and the merge algorithm");
@@ -1599,12 +1667,6 @@ __global__ __launch_bounds__(256) void spmv_f32x_kernel(const P *__restrict__ rp
     for (int64_t k = (int64_t)rp[i] + lane, e = (int64_t)rp[i + 1]; k < e; k += WAVE) acc += (double)__fmul_rn(x[ci[k]], vs[k]);
     for (int off = WAVE / 2; off; off >>= 1) acc += __shfl_down(acc, off, WAVE);
     if (lane == 0) y[i] = acc;
-}
-
-__global__ void widen_f32_kernel(const float *__restrict__ in, double *__restrict__ out, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
 }
 
 }  // namespace csrk
@@ -1669,7 +1731,7 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
     if (!m) return CSRK_ERR_INVALID;
     CSRK_REQUIRE((x || m->ncols == 0) && (y || m->nrows == 0), "x or y is NULL");
     if (m->nrows == 0) return CSRK_OK;
-    DevBuf dx32, dx, dy;
+    DevBuf dx32, dy;
     CSRK_TRY(dx32.alloc((size_t)m->ncols * 4 + 4));
     CSRK_TRY(dy.alloc((size_t)m->nrows * 8));
     if (m->ncols) CSRK_HIP(hipMemcpy(dx32.p, x, (size_t)m->ncols * 4, hipMemcpyHostToDevice));
@@ -1690,14 +1752,9 @@ int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y)
         CSRK_LAUNCH_CHECK();
         CSRK_HIP(hipDeviceSynchronize());
     } else {
-        // the usual kernels on the widened vector: float64 (or absent) values multiply in float64, as Numba types that
-        // loop; float32 values round every product to float32 first (spmv_prod)
-        CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
-        if (m->ncols) {
-            widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256>>>(dx32.as<float>(), dx.as<double>(), m->ncols);
-            CSRK_LAUNCH_CHECK();
-        }
-        CSRK_TRY(spmv_dispatch(m, dx.as<double>(), dy.as<double>(), nullptr, 3, f32_values));
+        // the usual kernels: float64 (or absent) values multiply in float64, as Numba types that loop; float32 values round
+        // every product to float32 first (spmv_prod); x is widened as it is loaded, or once into the plan's buffer
+        CSRK_TRY(spmv_dispatch(m, nullptr, dy.as<double>(), nullptr, 3, f32_values, dx32.as<float>()));
     }
     CSRK_HIP(hipMemcpy(y, dy.p, (size_t)m->nrows * 8, hipMemcpyDeviceToHost));
     return CSRK_OK;
@@ -1709,16 +1766,8 @@ int csrk_spmv_f32x_device(csrk_handle_t h, const float *d_x, double *d_y, void *
     if (!m) return CSRK_ERR_INVALID;
     CSRK_REQUIRE((d_x || m->ncols == 0) && (d_y || m->nrows == 0), "x or y is NULL");
     if (m->nrows == 0) return CSRK_OK;
-    hipStream_t s = (hipStream_t)stream;
-    DevBuf dx;      // (pooled: recycled in default-stream order; a caller's stream is drained before it goes back)
-    CSRK_TRY(dx.alloc((size_t)m->ncols * 8 + 8));
-    if (m->ncols) {
-        widen_f32_kernel<<<(unsigned)ceil_div(m->ncols, 256), 256, 0, s>>>(d_x, dx.as<double>(), m->ncols);
-        CSRK_LAUNCH_CHECK();
-    }
-    const int rc = spmv_dispatch(m, dx.as<double>(), d_y, s, 3, m->val_type == CSRK_VAL_F32);
-    if (s) CSRK_HIP(hipStreamSynchronize(s));      // the widened vector is released on return
-    return rc;
+    // (stream-ordered like csrk_spmv_device: nothing is allocated per call and nothing waited for)
+    return spmv_dispatch(m, nullptr, d_y, (hipStream_t)stream, 3, m->val_type == CSRK_VAL_F32, d_x);
 }
 
 int csrk_set_spmv_algo(csrk_handle_t h, int algo)

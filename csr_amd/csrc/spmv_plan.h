@@ -148,6 +148,7 @@ struct SpmvPlan {
     DevBuf seg_off;     // P-agnostic: int64[nrows + 1] segment offsets per row
     DevBuf seg_row;     // int32[n_segs]
     DevBuf seg_part;    // double[n_segs]
+    DevBuf xwide;       // double[ncols]: a float32 x widened for the kernels that read the raw arrays (csrk_spmv_f32x*)
     // kernel timing (csrk_spmv_profile_begin/end)
     std::vector<hipEvent_t> ev;   // start/stop pairs
     std::vector<int> ev_chan;     // channel of each pair: 0 = tile/segment/row kernel, 1/2 = panel tier 0/1

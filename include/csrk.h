@@ -119,8 +119,10 @@ CSRK_API int csrk_spmv(csrk_handle_t h, const double *x, double *y);
  * (csr/kernels/numba/__init__.py:55-67): float32 values times float32 x is a float32 product -- one rounding -- added to the
  * float64 accumulator; with float64 or absent values x is widened and the product is float64 (= csrk_spmv). */
 CSRK_API int csrk_spmv_f32x(csrk_handle_t h, const float *x, double *y);
-/* ... and with x (float32) and y (float64) already on the device; `stream` as for csrk_spmv_device.  Merge algorithm
- * only (CSRK_ERR_INVALID under `vector` / `scalar` with float32 values). */
+/* ... and with x (float32) and y (float64) already on the device; `stream` as for csrk_spmv_device: stream-ordered, nothing
+ * allocated or waited for per call.  From a handle's second product on, the planned kernels widen x as they load it (the
+ * copy pass, tier 0's windows, tier 1's gathers); a first product and the plan-less forms widen it once into a buffer
+ * the plan keeps.  Merge algorithm only (CSRK_ERR_INVALID under `vector` / `scalar` with float32 values). */
 CSRK_API int csrk_spmv_f32x_device(csrk_handle_t h, const float *d_x, double *d_y, void *stream);
 CSRK_API int csrk_spmv_device(csrk_handle_t h, const double *d_x, double *d_y, void *stream);
 /* The same product in two parts, for callers that ship y elsewhere while it is being completed (csr_amd/dist.py:
