@@ -50,8 +50,18 @@ out = {'workload': bench['config']['workload'], 'hbm_bytes_per_launch': traffic,
                  'FETCH_SIZE x 1024 (the correction of MI355X_MICROARCH.md, HBM section); writes = WRITE_SIZE x 1024.'}
 json.dump(out, open(f'profiles/{tag}_spmv_pmc_traffic.json', 'w'), indent=1)
 # the bench line of the same collection run, with the traffic these passes measured for its dominant kernel
-if bench['roofline'].get('traffic') is None and bench['roofline']['kernel'] in traffic:
+if bench['roofline']['kernel'] in traffic:      # (the line was printed before this summary existed: it cites the round before)
     bench['roofline']['traffic'] = traffic[bench['roofline']['kernel']]
+    bench['roofline']['traffic_source'] = f'profiles/{tag}_spmv_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same collection run)'
+    for k in bench['roofline'].get('all_kernels', []):
+        if k.get('kernel') in traffic:
+            k['traffic'] = traffic[k['kernel']]
+            k['traffic_gbs'] = round(k['traffic'] / (k['ms'] * 1e-3) / 1e9, 1) if k.get('ms') else None
+            if k.get('algorithmic_bytes'):
+                k['traffic_over_algorithmic'] = round(k['traffic'] / k['algorithmic_bytes'], 3)
+    if 'whole_spmv' in bench['roofline']:
+        bench['roofline']['whole_spmv']['traffic_bytes_all_kernels'] = sum(
+            v for k, v in traffic.items() if k in ('ls_stage_kernel', 'spmv_acc_kernel', 'spmv_panel_kernel<tier1>', 'spmv_lstream_kernel', 'spmv_epilogue_kernel'))
 open(f'profiles/{tag}_bench.json', 'w').write(json.dumps(bench) + '\n')
 print(json.dumps(out['hbm_bytes_per_launch']))
 print({k: v for k, v in bench['roofline'].items() if k != 'all_kernels'})
