@@ -52,6 +52,7 @@ SIGNATURES = {
     'csrk_device_count': (_int, [C.POINTER(_int)]),
     'csrk_set_device': (_int, [_int]),
     'csrk_synchronize': (_int, [_vp]),
+    'csrk_partition_rows': (_int, [C.c_int32, _vp, _int, C.c_int32, C.POINTER(C.c_int32)]),
     'csrk_trim_cache': (_int, []),
     'csrk_create': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),
     'csrk_create_device': (_int, [_i32, _i32, _i64, _vp, _int, _vp, _vp, _int, C.POINTER(handle_t)]),

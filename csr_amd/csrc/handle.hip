@@ -350,6 +350,26 @@ int csrk_trim_cache(void)
     return CSRK_OK;
 }
 
+int csrk_partition_rows(int32_t nrows, const void *rowptrs, int ptr_is_64, int32_t parts, int32_t *bounds)
+{
+    CSRK_REQUIRE(nrows >= 0 && parts >= 1 && bounds && (rowptrs || nrows == 0), "bad arguments");
+    auto rp = [&](int64_t i) -> int64_t { return ptr_is_64 ? ((const int64_t *)rowptrs)[i] : (int64_t)((const int32_t *)rowptrs)[i]; };
+    const int64_t nnz = nrows ? rp(nrows) : 0;
+    bounds[0] = 0;
+    for (int32_t g = 1; g < parts; g++) {
+        const int64_t target = nnz * g / parts;      // (nnz < 2^63 / parts for every matrix that fits a node)
+        int64_t lo = 0, hi = nrows;                   // first i in [0, nrows] with rowptrs[i] >= target
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (rp(mid) < target) lo = mid + 1;
+            else hi = mid;
+        }
+        bounds[g] = (int32_t)(lo > bounds[g - 1] ? lo : bounds[g - 1]);
+    }
+    bounds[parts] = nrows > bounds[parts - 1] ? nrows : bounds[parts - 1];
+    return CSRK_OK;
+}
+
 int csrk_synchronize(void *stream)
 {
     CSRK_HIP(hipStreamSynchronize((hipStream_t)stream));

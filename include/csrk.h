@@ -69,6 +69,15 @@ CSRK_API int csrk_device_count(int *count);
  * GPU normally passes LOCAL_RANK). */
 CSRK_API int csrk_set_device(int device);
 CSRK_API int csrk_synchronize(void *stream);
+/* Several GPUs from one compiled host (the reference's sequential analogue is _shard_rows,
+ * csr/csr.py:599-621): cut the rows into `parts` contiguous ranges balanced by entries -- bounds[g] = the first row whose
+ * row pointer is >= g * nnz / parts (searchsorted(rowptrs, g * nnz / parts), the primitive of csr/csr.py:609), bounds[0] = 0,
+ * bounds[parts] = nrows, never descending -- from HOST row pointers; no device is touched.  Range g then becomes a handle
+ * of its own on device g (csrk_set_device(g); csrk_create with rowptrs + bounds[g] rebased by the caller, or
+ * csrk_create_device on a slice already there), x is replicated, every device runs csrk_spmv_device on its range and the
+ * caller's collective (RCCL all-gather of the disjoint slices, or the all-reduce north_star names) completes y: what
+ * csr_amd/dist.py does with one process per GPU. */
+CSRK_API int csrk_partition_rows(int32_t nrows, const void *rowptrs, int ptr_is_64, int32_t parts, int32_t *bounds);
 /* Return the library's cached (free) device memory to the driver.  libcsrk keeps freed temporaries
  * and released handles' arrays in a size-bucketed pool (at most 16 GiB) to avoid hipMalloc/hipFree. */
 CSRK_API int csrk_trim_cache(void);

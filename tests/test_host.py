@@ -203,3 +203,29 @@ def test_scipy_round_trip_and_row_accessors():
     assert np.array_equal(s.row_vs(9), np.ones(hi - lo)) and np.array_equal(s.to_scipy().toarray(), (dense != 0) * 1.0)
     e = CSR.empty(3, 4)
     assert np.array_equal(e.row(1), np.zeros(4)) and e.rowinds().size == 0
+
+
+def test_partition_rows_c_abi_matches_the_python_partition():
+    """
+    csrk_partition_rows (host only: no device is touched) = the nnz-balanced contiguous row cut of csr_amd.synth.
+    balanced_row_ranges / csr_amd/dist.py -- searchsorted(rowptrs, g * nnz / parts), the primitive of the reference's
+    _shard_rows (csr/csr.py:609) -- for int32 and int64 row pointers, empty matrices, rows without entries, more parts than rows.
+    """
+    import ctypes as C
+    import torch
+    from csr_amd import synth
+    from csr_amd._lib import lib, check
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        n = int(rng.integers(0, 300))
+        lens = rng.integers(0, 9, n) * (rng.random(n) < 0.6)
+        for dt in (np.int32, np.int64):
+            rp = np.concatenate([[0], np.cumsum(lens)]).astype(dt)
+            for parts in (1, 2, 3, 8, 64):
+                b = (C.c_int32 * (parts + 1))()
+                check(lib.csrk_partition_rows(n, rp.ctypes.data_as(C.c_void_p), int(dt == np.int64), parts, b))
+                got = list(b)
+                assert got == synth.balanced_row_ranges(torch.from_numpy(rp), parts)
+                assert got[0] == 0 and got[-1] == n and all(x <= y for x, y in zip(got, got[1:]))
+    with pytest.raises(Exception):
+        check(lib.csrk_partition_rows(3, None, 0, 2, (C.c_int32 * 3)()))
