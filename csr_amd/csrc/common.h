@@ -123,6 +123,8 @@ struct Matrix {
     int spmv_algo = CSRK_SPMV_AUTO;
     int spmv_calls = 0;            // SpMV launches on this handle (the long-row split is built on the 2nd)
     SpmmPlan *spmm_plan = nullptr;
+    int dense_panel = -1;          // as the right operand of mult_ab: 1 = fully populated, rows 0 .. ncols - 1 ascending (its values ARE a row-major
+                                   // panel), 0 = not, -1 = not looked at yet (spgemm_dense_b; reset with the plans by the in-place operations)
     // A launch was issued on a caller's stream: the caching allocator recycles blocks in default-stream order only,
     // and a non-blocking stream is not ordered with the default one, so the handle's memory (arrays, plans, scratch)
     // goes back to the pool only after the device has drained (csrk_free, plan invalidation, scratch growth).

@@ -258,6 +258,7 @@ void drain_user_streams(Matrix *m)
 
 void invalidate_plans(Matrix *m)
 {
+    m->dense_panel = -1;      // (order_columns may have made the rows ascending, or not)
     if (!m->spmv_plan && !m->spmm_plan) return;
     (void)hipDeviceSynchronize();
     if (m->spmm_plan) {                 // may hold a view into the SpMV plan: goes first

@@ -815,6 +815,32 @@ def test_mult_ab_dense_route_declines(monkeypatch):
     A32 = CSR(A.nrows, A.ncols, A.nnz, A.rowptrs, A.colinds, A.values.astype(np.float32), _cast=False)
     B32 = CSR(200, 8, full.nnz, full.rowptrs, full.colinds, full.values.astype(np.float32), _cast=False)
     assert run(A32, B32) == 'general'
+    # the look at B is remembered by its handle -- and forgotten when an in-place operation changes it: a B whose rows are
+    # complete but shuffled takes the general product; after order_columns on the same handle it IS a row-major panel
+    rngp = np.random.default_rng(78)
+    cols_s, vals_s = full.colinds.copy(), full.values.copy()
+    for j in range(200):
+        o = rngp.permutation(8)
+        cols_s[8 * j:8 * j + 8] = o
+        vals_s[8 * j:8 * j + 8] = B[j, o]
+    shuf = CSR(200, 8, full.nnz, full.rowptrs, cols_s, vals_s, _cast=False)
+    ah, bh = K.to_handle(A), K.to_handle(shuf)
+    try:
+        routes = []
+        for step in range(4):
+            if step == 2:
+                K.order_columns(bh)
+            ch = K.mult_ab(ah, bh)
+            routes.append(K.spgemm_last_route())
+            c = K.from_handle(ch)
+            K.release_handle(ch)
+            bb = shuf if step < 2 else full
+            _, _, rp, ci, vs = O.mult_ab((A.nrows, A.ncols, A.rowptrs, A.colinds, A.values), (200, 8, bb.rowptrs, bb.colinds, bb.values))
+            assert np.array_equal(c.rowptrs, rp) and np.array_equal(c.colinds, ci) and np.array_equal(c.values, vs), step
+        assert routes == ['general', 'general', 'dense-panel', 'dense-panel']
+    finally:
+        K.release_handle(ah)
+        K.release_handle(bh)
     monkeypatch.setenv('CSRK_SPGEMM_DENSE', '0')
     assert run(A, full) == 'general'
 

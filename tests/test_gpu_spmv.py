@@ -579,6 +579,42 @@ def test_spmv_float32_product_of_a_one_entry_matrix(algo):
     assert np.array_equal(_mult_vec(none, x, algo), np.zeros(3))
 
 
+@pytest.mark.parametrize('vals', ['f4', 'f8'])
+def test_spmv_float32_vector_on_the_device_and_a_stream(vals):
+    """
+    csrk_spmv_f32x_device: x (float32) and y already on the card, launched on a caller's non-blocking stream -- stream-ordered,
+    nothing allocated or waited for per call.  The first product widens x into the plan's buffer (plan-less kernel), the
+    later ones read the float32 x directly in the copy pass, tier 0's windows and tier 1's gathers; every one of them equals
+    the host entry's result bit for bit, with and without float32 products.
+    """
+    import ctypes as C
+    import torch
+    from csr_amd import CSR
+    from csr_amd._lib import lib, check
+    from csr_amd.kernels import hip as K
+    rng = np.random.default_rng(21)
+    lens = np.minimum((rng.pareto(0.8, 30000) * 4).astype(np.int64), 20000)
+    m = _random_csr(rng, 30000, 600000, lens, dtype=np.float32 if vals == 'f4' else np.float64, sort=True)
+    A = CSR(m.nrows, m.ncols, m.nnz, m.rowptrs, m.colinds, m.values, _cast=False)
+    x = rng.uniform(-1, 1, size=m.ncols).astype(np.float32)
+    h = K.to_handle(A)
+    try:
+        want = K.mult_vec(h, x)                      # host entry (csrk_spmv_f32x): first product on the handle
+        want2 = K.mult_vec(h, x)                     # ... and a planned one
+        assert np.array_equal(want, want2) or np.allclose(want, want2, rtol=0, atol=1e-12 * np.abs(want).max())
+        dev = torch.device('cuda', 0)
+        dx = torch.from_numpy(x).to(dev)
+        dy = torch.full((m.nrows,), float('nan'), dtype=torch.float64, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            check(lib.csrk_spmv_f32x_device(K._live(h), dx.data_ptr(), dy.data_ptr(), C.c_void_p(st.cuda_stream)))
+        st.synchronize()
+        assert np.array_equal(dy.cpu().numpy(), want2)
+    finally:
+        K.release_handle(h)
+
+
 def test_float32_matrix_keeps_float32_streams(split_mode):
     """
     A float32 matrix's plan stores float32 values in the tier-0 and light streams (6 and 8 bytes per entry instead of 10 and
