@@ -11,11 +11,13 @@
 //          row in storage order, rows cut by a tile boundary leave a carry that a tiny kernel adds in tile
 //          order.  From the SECOND call on, a plan built once per handle (see "plan" below and DESIGN.md
 //          section 4) splits the rows three ways, each with a private, pre-decoded stream:
-//            tier 0  the (up to 15360) longest rows: column-block-major, x window AND one accumulator per
+//            tier 0  the (up to 15936) longest rows: column-block-major, x window AND one accumulator per
 //                    row in LDS, 10 B per entry: f64 value + 16-bit (column, row step) word
 //                    (spmv_acc_kernel, "long rows, accumulator form");
-//            tier 1  rows of 128 .. tier-0 threshold: (column block, row) pairs over 1 MiB x windows kept in
-//                    one XCD's L2 (spmv_panel_kernel, "long rows, panel form");
+//            tier 1  rows of 128 .. tier-0 threshold: (column block, row) pairs over 2 MiB x windows kept in
+//                    one XCD's L2, a tile's entries stored in column order and the products put back in row
+//                    order through LDS (spmv_panel_kernel, "mid rows, pair form"); tier 0's ordered reduce
+//                    rides in this kernel's launch (PanelRider);
 //            light   everything else: one wavefront per 512-entry tile, hot columns from LDS / a packed,
 //                    L2-resident copy of x, the x values of the unpacked columns copied beforehand into the
 //                    order the stream reads them (ls_stage_kernel, "cold staging"), short rows bit-identical

@@ -259,7 +259,7 @@ struct PanelGroup {
 //     the heads are folded in, in tile order, by one wavefront after the segment's barrier.  So every
 //     accumulator sees its addends in a fixed order whichever wavefront took which tile: results are
 //     bitwise reproducible, although ds_add_f64 is used for the adds.
-//   * At the end the workgroup stores its accumulators (H * 8 B) and acc_reduce_multi_kernel sums the
+//   * At the end the workgroup stores its accumulators (H * 8 B) and the ordered reduce (spmv_epilogue_kernel, or the rider of tier 1's launch: PanelRider) sums the
 //     workgroups' partials in workgroup order into y.
 // HBM traffic: 12 B per entry + one 32 KiB window per segment + n_wg * H * 8 B of partials (14 MB on the
 // headline matrix) -- against 12 B + 20 B per pair + windows for the pair form.
