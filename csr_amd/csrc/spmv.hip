@@ -837,7 +837,10 @@ __global__ __launch_bounds__(EPI_THREADS) void spmv_epilogue_kernel(EpiJobs jobs
 // bucket: 0.049 ms against 0.065 at 8 tiles) without the stream side paying for it in L1 lines (0.257 ms at 64 tiles when
 // the round's range is read by gathers).  Two workgroup barriers per round.
 // DENSE: run k is row k (LightStream::dense): row ids are not loaded and there are no gaps between runs to clear.
-constexpr int LS_PLAIN = 0, LS_RND = 2;
+// LS_RND24 = LS_RND with the index words stored in 3 bytes (LightStream::idx24): per tile a 16-bit plane (a lane's eight
+// low halves: one 16-B load) and an 8-bit plane (its eight high bytes: one 8-B load) -- 11 B per entry instead of 12; the
+// kernel's time follows its bytes (2 B per entry less, ablated: 161 -> 151 us).
+constexpr int LS_PLAIN = 0, LS_RND = 2, LS_RND24 = 3;
 template <int MODE, bool DENSE = false, bool R32 = false, class SV = double>
 __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const SV *__restrict__ svals, const uint32_t *__restrict__ sidx, const int32_t *__restrict__ rowids,
@@ -851,7 +854,10 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     // -ffp-contract=fast and fuse after inlining -- measured: 2041 instead of 75 rows of BASELINE configs[0]
     // differed in the last bits; the pragma governs the operators written in this body.)
 #pragma clang fp contract(off)
-    constexpr bool RND = MODE == LS_RND;
+    constexpr bool RND = MODE == LS_RND || MODE == LS_RND24;
+    constexpr bool I24 = MODE == LS_RND24;
+    constexpr uint32_t HOT_BIT = I24 ? LS24_HOT_BIT : LS_HOT_BIT, COL_MASK = I24 ? LS24_COL_MASK : LS_COL_MASK, PAD = COL_MASK;
+    constexpr int START_SHIFT = I24 ? LS24_START_SHIFT : 30;
     extern __shared__ __align__(16) unsigned char ls_smem[];
     double *s_hot = (double *)ls_smem;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -877,6 +883,20 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     const int64_t wave0 = R_begin < R_end ? round_t0(R_begin) + wv : n_tiles;
     AccVals<SV> v, vn;
     u32x4_t ix[2], ixn[2];
+    // a lane's index words of tile t_: two 16-B loads, or (I24) the 16-B load of its low halves and the 8-B load of its high bytes
+    auto idx_request = [&](u32x4_t (&w)[2], int64_t t_) {
+        if constexpr (I24) {
+            const unsigned char *tp = (const unsigned char *)sidx + t_ * LS24_TILE_BYTES;
+            w[0] = __builtin_nontemporal_load((const u32x4_t *)tp + lane);
+            const u32x2_t hi = __builtin_nontemporal_load((const u32x2_t *)(tp + ACC_TILE * 2) + lane);
+            w[1].x = hi.x;
+            w[1].y = hi.y;
+        } else {
+            const u32x4_t *ip = (const u32x4_t *)(sidx + t_ * ACC_TILE);
+#pragma unroll
+            for (int q = 0; q < 2; q++) w[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        }
+    };
     int32_t tb = 0, tbn = 0;
     constexpr int RQ = LS_RND_CAP / 2 / LS_THREADS;      // RND: 16-B loads per thread that cover a round's staged values
     f64x2_t rv[RND ? RQ : 1];
@@ -894,10 +914,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
     if (RND && R_begin < R_end) round_request(R_begin);
     int64_t t = wave0;
     if (R_begin < R_end && t < round_t1(R_begin)) {
-        const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
         v.load(svals + t * ACC_TILE, lane);
-#pragma unroll
-        for (int q = 0; q < 2; q++) ix[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+        idx_request(ix, t);
         tb = __builtin_amdgcn_readfirstlane(tile_base[t]);
     }
     for (int64_t R = R_begin; R < R_end; R += R_step) {
@@ -920,7 +938,19 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
                 if (tf < round_t1(R + R_step)) t_next = tf;
             }
         }
-        const uint32_t e[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
+        uint32_t e[ACC_K];
+        if constexpr (I24) {
+            // word j = {0, byte j of the high plane, half j of the low plane}: one v_perm_b32 each
+            const uint32_t lo[4] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w}, hi[2] = {ix[1].x, ix[1].y};
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++)
+                e[j] = __builtin_amdgcn_perm(hi[j >> 2], lo[j >> 1],
+                                             0x0c000000u | ((4u + (j & 3)) << 16) | ((2u * (j & 1) + 1u) << 8) | (2u * (j & 1)));
+        } else {
+            const uint32_t w[ACC_K] = {ix[0].x, ix[0].y, ix[0].z, ix[0].w, ix[1].x, ix[1].y, ix[1].z, ix[1].w};
+#pragma unroll
+            for (int j = 0; j < ACC_K; j++) e[j] = w[j];
+        }
         double a[ACC_K];
         v.get(a);
         // Issue order matters: vmcnt retires loads in issue order, so whatever is requested BEFORE the loads this tile
@@ -934,9 +964,9 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             // packed columns beyond the LDS slots: gathered from the pack; everything else is in LDS
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) {
-                const uint32_t c = e[j] & LS_COL_MASK;
-                const bool hot = (e[j] & LS_HOT_BIT) != 0;
-                inl[j] = c != LS_PAD && (!hot || (int32_t)c < n_lds);      // (a padding slot multiplies 0 * 0)
+                const uint32_t c = e[j] & COL_MASK;
+                const bool hot = (e[j] & HOT_BIT) != 0;
+                inl[j] = c != PAD && (!hot || (int32_t)c < n_lds);      // (a padding slot multiplies 0 * 0)
                 gv[j] = 0.0;
                 if (hot && (int32_t)c >= n_lds) gv[j] = xh[c];
             }
@@ -967,10 +997,8 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
             // last tile re-requests itself): behind an `if (more)` the compiler cannot count the loads in flight at the
             // join and waits for all of them (s_waitcnt vmcnt(0)) before this tile's first multiply.
             const int64_t tn = t_next;
-            const u32x4_t *ip = (const u32x4_t *)(sidx + tn * ACC_TILE);
             // (index words first: the next tile's gathers need them at its very top, the values only at its multiplies)
-#pragma unroll
-            for (int q = 0; q < 2; q++) ixn[q] = __builtin_nontemporal_load(ip + q * WAVE + lane);
+            idx_request(ixn, tn);
             vn.load(svals + tn * ACC_TILE, lane);
             tbn = tile_base[tn];
         }
@@ -978,15 +1006,15 @@ __global__ __launch_bounds__(LS_THREADS) void spmv_lstream_kernel(
         // row starts: bit j of st = entry j opens a row (index words only: this runs while the tile's x values arrive)
         uint32_t st = 0;
 #pragma unroll
-        for (int j = 0; j < ACC_K; j++) st |= ((e[j] >> 30) & 1u) << j;
+        for (int j = 0; j < ACC_K; j++) st |= ((e[j] >> START_SHIFT) & 1u) << j;
         const int cnt = __popc(st);
         const int S = wave_exscan_i32(cnt, lane);          // row starts in the lanes below
         const int total = wave_last_i32(S + cnt);            // row starts in the tile
         if (RND) {
 #pragma unroll
             for (int j = 0; j < ACC_K; j++) {
-                const uint32_t c = e[j] & LS_COL_MASK;
-                const bool cold = !(e[j] & LS_HOT_BIT) && c != LS_PAD;
+                const uint32_t c = e[j] & COL_MASK;
+                const bool cold = !(e[j] & HOT_BIT) && c != PAD;
                 const double *src = cold ? s_rnd + c : s_hot + (inl[j] ? c : 0);
                 lv[j] = *src;
             }
@@ -1272,6 +1300,10 @@ int spmv_kernel_attributes()
                           (const void *)spmv_lstream_kernel<LS_PLAIN, true, false, float>, (const void *)spmv_lstream_kernel<LS_RND, true, false, float>,
                           (const void *)spmv_lstream_kernel<LS_PLAIN, false, true, float>, (const void *)spmv_lstream_kernel<LS_RND, false, true, float>,
                           (const void *)spmv_lstream_kernel<LS_PLAIN, true, true, float>, (const void *)spmv_lstream_kernel<LS_RND, true, true, float>,
+                          (const void *)spmv_lstream_kernel<LS_RND24>, (const void *)spmv_lstream_kernel<LS_RND24, true>,
+                          (const void *)spmv_lstream_kernel<LS_RND24, false, true>, (const void *)spmv_lstream_kernel<LS_RND24, true, true>,
+                          (const void *)spmv_lstream_kernel<LS_RND24, false, false, float>, (const void *)spmv_lstream_kernel<LS_RND24, true, false, float>,
+                          (const void *)spmv_lstream_kernel<LS_RND24, false, true, float>, (const void *)spmv_lstream_kernel<LS_RND24, true, true, float>,
                           (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, false, double, float>,
                           (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, true, double, float>,
                           (const void *)spmv_acc_kernel<ACC_CB, ACC_THREADS, false, float, float>,
@@ -1471,7 +1503,11 @@ static int launch_spmv(Matrix *m, SpmvPlan *p, const XT *d_x, double *d_y, hipSt
                 const int32_t *nil = nullptr;
 #define LS_GO(D, SV)                                                                                                   \
     do {                                                                                                               \
-        if (p->ls.n_cold && p->ls.round_start.p)                                                                       \
+        if (p->ls.n_cold && p->ls.round_start.p && p->ls.idx24)                                                        \
+            spmv_lstream_kernel<LS_RND24, D, R32, SV><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                         \
+                LS_ARGS(SV), p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(),                         \
+                p->ls.wg_round0.as<int32_t>());                                                                        \
+        else if (p->ls.n_cold && p->ls.round_start.p)                                                                  \
             spmv_lstream_kernel<LS_RND, D, R32, SV><<<p->ls.grid, LS_THREADS, rnd_lds, s>>>(                           \
                 LS_ARGS(SV), p->ls.round_start.as<int32_t>(), p->ls.round_tile0.as<int32_t>(),                         \
                 p->ls.wg_round0.as<int32_t>());                                                                        \

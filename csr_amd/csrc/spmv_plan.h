@@ -90,6 +90,7 @@ struct LightStream {
     int32_t n_runs = 0, n_out = 0;      // non-empty runs; length of the output vector (rows, or pairs)
     unsigned grid = 0;
     DevBuf vals, idx, rowids, tile_base, carry_row, carry_val;
+    bool idx24 = false;    // idx holds 3-byte words in two planes per tile (LS24_*: build_cold_stage), not uint32
     bool f32 = false;      // vals holds float32 (a float32 matrix: 8 B per entry instead of 12)
     // dense rows (build_light_stream): EVERY row of the view has a run -- a row without entries holds one padding entry --
     // so run k is row k: no row-id table (`rowids` stays empty), no gaps to clear
@@ -280,6 +281,7 @@ constexpr uint32_t ACC_COL_MASK = (1u << ACC_ROW_SHIFT) - 1;
 constexpr int ACC_MAXSTEP = 7;
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // physical slot of logical entry e (0..511) of a tile: lane = e / 8, j = e % 8
 __host__ __device__ __forceinline__ int acc_val_slot(int e)
@@ -345,6 +347,14 @@ constexpr int LS_RID = 4;        // batches of 64 run-slot row ids fetched ahead
 constexpr int LS_SEQ = CSRK_LS_SEQ;        // rounds of in-order carry hand-over (runs over <= LS_SEQ + 1 lanes are exact)
 constexpr uint32_t LS_HOT_BIT = 1u << 31, LS_START_BIT = 1u << 30, LS_COL_MASK = (1u << 30) - 1;
 constexpr uint32_t LS_PAD = LS_COL_MASK;      // a padding slot: value 0.0, "column" 2^30 - 1 (never a real one), no flags
+// the same word in 3 bytes (LightStream::idx24, cold staging on: every column field is a pack slot or a round offset):
+// hot bit 23, start bit 22, 22 bits of column; a tile = 512 low halves (a lane's eight: 16 B), then 512 high bytes (8 B)
+#ifndef CSRK_LS_IDX24
+#define CSRK_LS_IDX24 1
+#endif
+constexpr uint32_t LS24_HOT_BIT = 1u << 23, LS24_COL_MASK = (1u << 22) - 1;
+constexpr int LS24_START_SHIFT = 22;
+constexpr int64_t LS24_TILE_BYTES = 512 * 3;
 
 constexpr int VEC_SEG = 4096;
 

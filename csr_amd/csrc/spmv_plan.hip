@@ -1305,6 +1305,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     ls->f32 = VT == CSRK_VAL_F32;      // a float32 matrix keeps float32 values in the stream (widened in the kernel, exactly)
     CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * (ls->f32 ? 4 : 8)));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
+    ls->idx24 = false;
     if (ls->f32)
         ls_fill_kernel<P, VT, float><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
             src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<float>(), ls->idx.as<uint32_t>(), rp_len);
@@ -1438,8 +1439,39 @@ __global__ void ls_round_total_kernel(const int64_t *__restrict__ tot, int32_t n
     if (r <= nround_ls) out[r] = tot[(int64_t)r * nblk];
 }
 
+// One thread per (tile, lane): the lane's eight uint32 index words -> their 3-byte form (LS24_*: spmv_plan.h).
+__global__ __launch_bounds__(256) void ls_idx24_kernel(const uint32_t *__restrict__ sidx, int64_t n_tiles, unsigned char *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = g / WAVE;
+    const int lane = (int)(g % WAVE);
+    if (t >= n_tiles) return;
+    const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
+    const u32x4_t a = ip[lane], b = ip[WAVE + lane];
+    const uint32_t w[ACC_K] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t n[ACC_K];
+#pragma unroll
+    for (int j = 0; j < ACC_K; j++) {
+        const uint32_t c = w[j] & LS_COL_MASK;
+        n[j] = (w[j] & LS_HOT_BIT ? LS24_HOT_BIT : 0u) | (w[j] & LS_START_BIT ? 1u << LS24_START_SHIFT : 0u) |
+               (c == LS_PAD ? LS24_COL_MASK : c);
+    }
+    u32x4_t lo;
+    lo.x = (n[0] & 0xffffu) | (n[1] << 16);
+    lo.y = (n[2] & 0xffffu) | (n[3] << 16);
+    lo.z = (n[4] & 0xffffu) | (n[5] << 16);
+    lo.w = (n[6] & 0xffffu) | (n[7] << 16);
+    u32x2_t hi;
+    hi.x = (n[0] >> 16) | ((n[1] >> 16) << 8) | ((n[2] >> 16) << 16) | ((n[3] >> 16) << 24);
+    hi.y = (n[4] >> 16) | ((n[5] >> 16) << 8) | ((n[6] >> 16) << 16) | ((n[7] >> 16) << 24);
+    unsigned char *tp = out + t * LS24_TILE_BYTES;
+    ((u32x4_t *)tp)[lane] = lo;
+    ((u32x2_t *)(tp + ACC_TILE * 2))[lane] = hi;
+}
+
 static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols, int32_t n_hot, hipStream_t s)
 {
+    ls->idx24 = false;
     ls->n_cold = 0;
     ls->stage_tiles = 0;
     const char *env = getenv("CSRK_LS_STAGE");
@@ -1577,7 +1609,22 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     ls->n_stage_blk = (int32_t)nblk;
     ls->stage_w = (int32_t)W;
     CSRK_TRY(spmv_kernel_attributes());
+    // every column field is now a pack slot (< n_hot) or an offset into a round's staged values (< LS_RND_CAP): 3-byte words
+    DevBuf idx24;
+    const bool narrow = CSRK_LS_IDX24 && (int64_t)n_hot < (int64_t)LS24_COL_MASK && (int64_t)LS_RND_CAP < (int64_t)LS24_COL_MASK;
+    if (narrow) {
+        CSRK_TRY(idx24.alloc((size_t)ls->n_tiles * LS24_TILE_BYTES));
+        ls_idx24_kernel<<<(unsigned)ceil_div(ls->n_tiles * WAVE, 256), 256, 0, s>>>(ls->idx.as<uint32_t>(), ls->n_tiles,
+                                                                                   idx24.as<unsigned char>());
+        CSRK_LAUNCH_CHECK();
+    }
     CSRK_HIP(hipStreamSynchronize(s));      // the temporaries are freed on return
+    if (narrow) {
+        ls->idx.release();
+        ls->idx.p = idx24.take();
+        ls->idx.bytes = (size_t)ls->n_tiles * LS24_TILE_BYTES;
+        ls->idx24 = true;
+    }
     ls->n_cold = n_cold;
     ls->stage_tiles = stage_tiles;
     return CSRK_OK;
