@@ -12,6 +12,33 @@ namespace csrk {
 // tile_row[t] = number of row ends consumed before merge-path diagonal d = min(t*ITEMS, nrows+nnz).
 // Row end r (= rp[r+1]) is consumed once all its nnz are: it lies before diagonal d iff
 // rp[r+1] + r + 1 <= d.
+// CSRK_PLAN_TRACE: laps of the plan builders on stderr (each lap waits for the device)
+struct PlanTrace {
+    bool on;
+    double t0;
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    }
+    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
+    {
+        if (on) {
+            (void)hipDeviceSynchronize();
+            t0 = now();
+        }
+    }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
+        t0 = t;
+    }
+};
+
 template <class P>
 __global__ void merge_plan_kernel(const P *__restrict__ rp, int32_t nrows, int64_t nnz, int items,
                                   int64_t n_tiles, int32_t *__restrict__ tile_row)
@@ -178,6 +205,57 @@ __global__ void hot_list_kernel(const int32_t *__restrict__ cnt, const int32_t *
     if (c < ncols && cnt[c] >= thr) {
         hot_cols[pos[c]] = (int32_t)c;
         hot_cnt[pos[c]] = cnt[c];
+    }
+}
+
+// The packed columns in order of popularity: a stable LSD radix sort of (count, column) by count DESCENDING (digits of the
+// complemented count), 8 bits a pass, one wavefront per chunk of 1024 -- digit counts per chunk, one scan over
+// (digit, chunk), then the chunk places its elements in order (rank among the lanes of the same digit by ballots).  (On the
+// host -- two 16-bit passes plus the copies both ways -- this was 1.5 ms of the headline matrix's plan.)
+constexpr int HS_CHUNK = 1024;
+__global__ __launch_bounds__(WAVE) void hot_sort_count_kernel(const uint32_t *__restrict__ key, int32_t n, int shift, int32_t nchunk,
+                                                             int32_t *__restrict__ cnt)
+{
+    __shared__ int32_t h[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += WAVE) h[d] = 0;
+    __syncthreads();
+    for (int r = 0; r < HS_CHUNK / WAVE; r++) {
+        const int64_t i = (int64_t)blockIdx.x * HS_CHUNK + r * WAVE + lane;
+        if (i < n) atomicAdd(&h[(~key[i] >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    for (int d = lane; d < 256; d += WAVE) cnt[(int64_t)d * nchunk + blockIdx.x] = h[d];
+}
+__global__ __launch_bounds__(WAVE) void hot_sort_place_kernel(const uint32_t *__restrict__ key, const int32_t *__restrict__ val, int32_t n,
+                                                             int shift, int32_t nchunk, const int32_t *__restrict__ base,
+                                                             uint32_t *__restrict__ key_out, int32_t *__restrict__ val_out)
+{
+    __shared__ int32_t b[256];
+    const int lane = threadIdx.x;
+    const unsigned long long below = lane ? (~0ull >> (WAVE - lane)) : 0ull;
+    for (int d = lane; d < 256; d += WAVE) b[d] = base[(int64_t)d * nchunk + blockIdx.x];
+    __syncthreads();
+    for (int r = 0; r < HS_CHUNK / WAVE; r++) {
+        const int64_t i = (int64_t)blockIdx.x * HS_CHUNK + r * WAVE + lane;
+        const bool ok = i < n;
+        const uint32_t k = ok ? key[i] : 0u;
+        const uint32_t d = (~k >> shift) & 255u;
+        unsigned long long same = __ballot(ok);      // the lanes that hold the same digit
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const unsigned long long bb = __ballot((d >> bit) & 1u);
+            same &= ((d >> bit) & 1u) ? bb : ~bb;
+        }
+        const int rank = __popcll(same & below), group = __popcll(same);
+        if (ok) {
+            const int32_t pos = b[d] + rank;
+            key_out[pos] = k;
+            val_out[pos] = val[i];
+        }
+        __syncthreads();
+        if (ok && rank == group - 1) b[d] += group;
+        __syncthreads();
     }
 }
 
@@ -704,6 +782,7 @@ template <class P, int VT>
 static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, int64_t nnz_rows, int32_t cb,
                        int tpw, bool xcd_streams, hipStream_t s)
 {
+    PlanTrace tr;
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t n = (int32_t)rows.size();
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, cb);
@@ -740,6 +819,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div((int64_t)n + be[b + 1] - be[b], MERGE_ITEMS);
     const int64_t n_tiles = t0[nb];
     CSRK_TRY(stage_h2d(bends.p, t0.data(), (size_t)(nb + 1) * 8, s));
+    tr.lap("  tier 1: count, scan, fill");
     CSRK_TRY(pn->tile.alloc((size_t)n_tiles * sizeof(PanelTile)));
     if (pn->p64)
         panel_plan_kernel<int64_t><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
@@ -753,6 +833,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
         panel_colsort_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(pn->tile.as<PanelTile>(), cb, pn->ci.as<int32_t>(), pn->vs.as<double>());
         CSRK_LAUNCH_CHECK();
     }
+    tr.lap("  tier 1: tiles, column order");
 
     // workgroup list: `tpw` consecutive tiles of one block per workgroup
     std::vector<PanelGroup> groups;
@@ -829,6 +910,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     }
     pn->ncs = ncs;
     CSRK_HIP(hipStreamSynchronize(s));     // `groups`, `t0` are host temporaries of async copies
+    tr.lap("  tier 1: groups, carries (host)");
     pn->on = true;
     pn->cb = cb;
     pn->nb = nb;
@@ -847,6 +929,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
 {
     const P *rp = (const P *)m->d_rowptrs;
     const int32_t nb = (int32_t)ceil_div(m->ncols > 0 ? m->ncols : 1, ACC_CB);
+    PlanTrace tr;
     const int64_t pairs = (int64_t)n * nb;
     CSRK_TRY(ap->row_list.alloc((size_t)n * 4));
     CSRK_TRY(stage_h2d(ap->row_list.p, rows, (size_t)n * 4, s));
@@ -869,6 +952,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
         rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, d_trow.as<int32_t>(), d_tpiece.as<int32_t>(), n_tasks,
         pstart.as<int32_t>());
     CSRK_LAUNCH_CHECK();
+    tr.lap("  tier 0: pair starts");
     acc_paircount_kernel<<<(unsigned)ceil_div(pairs, 256), 256, 0, s>>>(pstart.as<int32_t>(), pairs, n, off.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     DevBuf gap;
@@ -886,6 +970,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     for (int32_t b = 0; b < nb; b++) t0[b + 1] = t0[b] + ceil_div(be[b + 1] - be[b], ACC_TILE);
     const int64_t n_tiles = t0[nb];
     CSRK_TRY(stage_h2d(bends.p, t0.data(), (size_t)(nb + 1) * 8, s));
+    tr.lap("  tier 0: counts, gaps, scan");
     // persistent workgroups: one per CU, equal shares of the tiles (stored interleaved: acc_phys_tile), cut into one-block
     // segments
     int cus = 0;
@@ -921,6 +1006,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     if (ap->f32) ACC_FILL(float);
     else ACC_FILL(double);
 #undef ACC_FILL
+    tr.lap("  tier 0: fill");
     std::vector<AccSeg> segs;
     std::vector<int32_t> wg_seg((size_t)n_wg + 1);
     int32_t b = 0;
@@ -957,35 +1043,11 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     ap->tiles = n_tiles;
     ap->nnz = nnz_rows;
     ap->n_segs = (int64_t)segs.size();
+    tr.lap("  tier 0: segments");
     return CSRK_OK;
 }
 
 // Cut the long rows out of the merge path and build their panel tiers.
-struct PlanTrace {
-    bool on;
-    double t0;
-    static double now()
-    {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-    }
-    PlanTrace() : on(getenv("CSRK_PLAN_TRACE") != nullptr), t0(0.0)
-    {
-        if (on) {
-            (void)hipDeviceSynchronize();
-            t0 = now();
-        }
-    }
-    void lap(const char *what)
-    {
-        if (!on) return;
-        (void)hipDeviceSynchronize();
-        const double t = now();
-        fprintf(stderr, "[csrk plan] %-28s %8.3f ms\n", what, t - t0);
-        t0 = t;
-    }
-};
 
 template <class P>
 static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_tier1 = true)
@@ -1138,6 +1200,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     if (env && env[0] == '0') return CSRK_OK;
     const bool force = env && env[0] == '1';
     if (m->nnz < 2 || m->ncols < 1) return CSRK_OK;
+    PlanTrace tr;
     int64_t HOT_SLOTS = 524288;   // 4 MiB of packed x, most popular first (light stream, LDS for the first 8192: 64k 0.340,
                                   // 256k 0.308, 512k 0.302, 1M 0.297, 2M 0.297 ms, but the per-call pack costs more than that gains past 512k)
                                   // earlier sweep, tile kernel, 512 KiB of packed x (measured on the headline matrix: 16k 0.431, 64k 0.422,
@@ -1162,6 +1225,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     CSRK_TRY(stage_d2h(&n_samples_u, census.p, 8, s));
     CSRK_HIP(hipStreamSynchronize(s));
     const int64_t n_samples = (int64_t)n_samples_u;
+    tr.lap("  hot: column counts");
     if (n_samples == 0) return CSRK_OK;
     // smallest threshold (>= 2 references in the sample) that leaves at most HOT_SLOTS columns
     auto census_at = [&](int32_t thr, unsigned long long out[2]) -> int {
@@ -1219,6 +1283,7 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
     }
     const int32_t thr = (int32_t)(lo > INT32_MAX ? INT32_MAX : lo);
     const int32_t n_hot = (int32_t)c[0];
+    tr.lap("  hot: threshold");
     p->hot_cover = n_samples ? (double)c[1] / (double)n_samples : 0.0;
     if (n_hot == 0 || (!force && p->hot_cover < 0.2)) return CSRK_OK;
 
@@ -1236,32 +1301,26 @@ static int build_hot_cache(Matrix *m, SpmvPlan *p, hipStream_t s)
                                       hcnt.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     {
-        std::vector<int32_t> hc((size_t)n_hot), hn((size_t)n_hot), ord((size_t)n_hot), sorted((size_t)n_hot);
-        CSRK_TRY(stage_d2h(hc.data(), p->hot_cols.p, (size_t)n_hot * 4, s));
-        CSRK_TRY(stage_d2h(hn.data(), hcnt.p, (size_t)n_hot * 4, s));
-        CSRK_HIP(hipStreamSynchronize(s));
-        // stable, count descending: two 16-bit LSD radix passes over the complemented count (a comparison sort of
-        // 4 * 10^5 indices through a lambda took tens of ms of the plan)
-        {
-            std::vector<int32_t> tmp((size_t)n_hot);
-            std::vector<uint32_t> bucket(65537);
-            for (int32_t i = 0; i < n_hot; i++) ord[(size_t)i] = i;
-            for (int pass = 0; pass < 2; pass++) {
-                const int sh = 16 * pass;
-                std::fill(bucket.begin(), bucket.end(), 0u);
-                for (int32_t i = 0; i < n_hot; i++) bucket[((~(uint32_t)hn[(size_t)i] >> sh) & 0xffffu) + 1]++;
-                for (size_t b = 0; b < 65536; b++) bucket[b + 1] += bucket[b];
-                for (int32_t i = 0; i < n_hot; i++) {
-                    const int32_t o = ord[(size_t)i];
-                    tmp[bucket[(~(uint32_t)hn[(size_t)o] >> sh) & 0xffffu]++] = o;
-                }
-                ord.swap(tmp);
-            }
+        // stable, count descending (hot_sort_*_kernel): four 8-bit passes, ping-pong between (hcnt, hot_cols) and (k2, v2)
+        const int32_t nchunk = (int32_t)ceil_div(n_hot, HS_CHUNK);
+        DevBuf k2, v2, dc;
+        CSRK_TRY(k2.alloc((size_t)n_hot * 4));
+        CSRK_TRY(v2.alloc((size_t)n_hot * 4));
+        CSRK_TRY(dc.alloc((size_t)(256 * (int64_t)nchunk + 1) * 4));
+        uint32_t *ka = hcnt.as<uint32_t>(), *kb = k2.as<uint32_t>();
+        int32_t *va = p->hot_cols.as<int32_t>(), *vb = v2.as<int32_t>();
+        for (int pass = 0; pass < 4; pass++) {
+            hot_sort_count_kernel<<<(unsigned)nchunk, WAVE, 0, s>>>(ka, n_hot, 8 * pass, nchunk, dc.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            CSRK_TRY(exclusive_scan_i32(dc.as<int32_t>(), dc.as<int32_t>(), 256 * (int64_t)nchunk, s));
+            hot_sort_place_kernel<<<(unsigned)nchunk, WAVE, 0, s>>>(ka, va, n_hot, 8 * pass, nchunk, dc.as<int32_t>(), kb, vb);
+            CSRK_LAUNCH_CHECK();
+            std::swap(ka, kb);
+            std::swap(va, vb);
         }
-        for (int32_t i = 0; i < n_hot; i++) sorted[(size_t)i] = hc[(size_t)ord[(size_t)i]];
-        CSRK_TRY(stage_h2d(p->hot_cols.p, sorted.data(), (size_t)n_hot * 4, s));
-        CSRK_HIP(hipStreamSynchronize(s));      // `sorted` is a host temporary
+        CSRK_HIP(hipStreamSynchronize(s));      // k2, v2, dc are freed here (the sorted columns are back in hot_cols)
     }
+    tr.lap("  hot: list, order by count");
     // column -> slot map (-1: not packed); the light stream's fill reads it, as does the renumbered colinds copy
     // the tile kernel needs when no stream is built
     CSRK_TRY(p->hot_slot.alloc((size_t)nc * 4));
@@ -1287,6 +1346,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     // entry.  Run k is then row k, and no row-id table is built.
     ls->on = false;
     ls->dense = rp_len != nullptr;
+    PlanTrace tr;
     DevBuf ridx;
     CSRK_TRY(ridx.alloc((size_t)(nrows_view + 2) * 4));
     const unsigned gr = (unsigned)ceil_div((int64_t)nrows_view + 1, 256);
@@ -1329,6 +1389,7 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     ls->n_runs = n_runs;
     ls->n_out = n_out;
     CSRK_HIP(hipStreamSynchronize(s));      // ridx, dphys are freed on return; *phys is a host temporary
+    tr.lap("  light: runs, fill");
     ls->on = true;
     return CSRK_OK;
 }
@@ -1439,6 +1500,22 @@ __global__ void ls_round_total_kernel(const int64_t *__restrict__ tot, int32_t n
     if (r <= nround_ls) out[r] = tot[(int64_t)r * nblk];
 }
 
+// tile_cold[t] = cold entries of tile t (one wavefront per tile): with their prefix sums the host finds the largest round
+// size whose rounds all fit the LDS round buffer without counting buckets once per candidate size
+__global__ __launch_bounds__(256) void ls_tile_cold_kernel(const uint32_t *__restrict__ sidx, int64_t n_tiles, int32_t *__restrict__ tile_cold)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = g / WAVE;
+    const int lane = (int)(g % WAVE);
+    if (t >= n_tiles) return;
+    const u32x4_t *ip = (const u32x4_t *)(sidx + t * ACC_TILE);
+    const u32x4_t a = ip[lane], b = ip[WAVE + lane];
+    int c = (int)ls_is_cold(a.x) + (int)ls_is_cold(a.y) + (int)ls_is_cold(a.z) + (int)ls_is_cold(a.w) + (int)ls_is_cold(b.x) +
+            (int)ls_is_cold(b.y) + (int)ls_is_cold(b.z) + (int)ls_is_cold(b.w);
+    c = wave_exscan_i32(c, lane) + c;
+    if (lane == WAVE - 1) tile_cold[t] = c;
+}
+
 // One thread per (tile, lane): the lane's eight uint32 index words -> their 3-byte form (LS24_*: spmv_plan.h).
 __global__ __launch_bounds__(256) void ls_idx24_kernel(const uint32_t *__restrict__ sidx, int64_t n_tiles, unsigned char *__restrict__ out)
 {
@@ -1492,6 +1569,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     CSRK_HIP(hipMemGetInfo(&mfree, &mtotal));
     if ((size_t)n_words * 20 + (size_t)nb_max * 16 + (64u << 20) > mfree) return CSRK_OK;
     if (ls->n_tiles >= INT32_MAX) return CSRK_OK;
+    PlanTrace tr;
     DevBuf cnt, cntT, off, offp, tot, tile_round, d_rt0;
     CSRK_TRY(tile_round.alloc((size_t)ls->n_tiles * 4));
     CSRK_TRY(d_rt0.alloc((size_t)(ls->n_tiles + 2) * 4));
@@ -1508,8 +1586,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     // into equal rounds (whole tiles per wavefront).
     std::vector<int32_t> h_rt0, h_wr0;
     constexpr int NW_ = LS_THREADS / WAVE;
-    auto count_pass = [&](int nt, int64_t *max_round) -> int {
-        stage_tiles = nt;
+    auto make_rounds = [&](int nt) {
         h_rt0.clear();
         h_wr0.clear();
         const int64_t G = ls->grid;
@@ -1525,6 +1602,10 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         h_wr0.push_back((int32_t)h_rt0.size());
         nround_ls = (int64_t)h_rt0.size();
         h_rt0.push_back((int32_t)ls->n_tiles);
+    };
+    auto count_pass = [&](int nt, int64_t *max_round) -> int {
+        stage_tiles = nt;
+        make_rounds(nt);
         nround = nround_ls + 1;      // + the virtual round of the packed columns
         nb = nround * nblk;
         if (nb > nb_max) return CSRK_ERR_INVALID;      // (cannot happen: a round holds at least LS_STAGE_TILES or NW tiles)
@@ -1557,7 +1638,28 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         constexpr int NW = LS_THREADS / WAVE;      // a round is a whole number of tiles per wavefront
         static_assert(NW * ACC_TILE <= LS_RND_CAP, "the smallest round must fit the LDS round buffer");
         bool fits = false;
-        for (int nt = LS_RND_MAXTILES / NW * NW; nt >= NW;) {
+        // where to start: the largest size that fits by the tiles' own cold counts (then one count pass confirms it)
+        int nt_first = LS_RND_MAXTILES / NW * NW;
+        {
+            DevBuf tcold, tpre;
+            CSRK_TRY(tcold.alloc((size_t)(ls->n_tiles + 1) * 4));
+            CSRK_TRY(tpre.alloc((size_t)(ls->n_tiles + 2) * 8));
+            ls_tile_cold_kernel<<<(unsigned)ceil_div(ls->n_tiles * WAVE, 256), 256, 0, s>>>(ls->idx.as<uint32_t>(), ls->n_tiles,
+                                                                                          tcold.as<int32_t>());
+            CSRK_LAUNCH_CHECK();
+            CSRK_TRY(exclusive_scan_i32_to_i64(tcold.as<int32_t>(), tpre.as<int64_t>(), ls->n_tiles, s));
+            std::vector<int64_t> pre((size_t)ls->n_tiles + 1);
+            CSRK_TRY(stage_d2h(pre.data(), tpre.p, pre.size() * 8, s));
+            CSRK_HIP(hipStreamSynchronize(s));
+            for (; nt_first > NW; nt_first -= NW) {
+                make_rounds(nt_first);
+                int64_t mx = 0;
+                for (int64_t r = 0; r < nround_ls; r++)
+                    mx = std::max(mx, pre[(size_t)h_rt0[(size_t)r + 1]] - pre[(size_t)h_rt0[(size_t)r]]);
+                if (mx <= LS_RND_CAP) break;
+            }
+        }
+        for (int nt = nt_first; nt >= NW;) {
             CSRK_TRY(count_pass(nt, &max_round));
             if (max_round <= LS_RND_CAP) {
                 fits = true;
@@ -1569,6 +1671,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
         }
         if (!fits) return CSRK_OK;
     }
+    tr.lap("  cold: round size (count passes)");
     if (nround > INT32_MAX) return CSRK_OK;
     CSRK_HIP(hipMemsetAsync(cnt.as<int32_t>() + nround_ls * nblk, 0, (size_t)(nblk + 1) * 4, s));
     ls_pack_count_kernel<<<(unsigned)ceil_div(n_hot, 256), 256, 0, s>>>(hot_cols, n_hot, (int32_t)W,
@@ -1627,6 +1730,7 @@ static int build_cold_stage(Matrix *m, LightStream *ls, const int32_t *hot_cols,
     }
     ls->n_cold = n_cold;
     ls->stage_tiles = stage_tiles;
+    tr.lap("  cold: place, 3-byte words");
     return CSRK_OK;
 }
 
