@@ -310,7 +310,8 @@ __global__ void heavy_sorted_kernel(const P *__restrict__ rp, const int32_t *__r
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
     // (a 10^6-entry row is one workgroup's: 1024 threads with four comparisons in flight each; 256 threads one at a time
-    // made this check 1.8 ms of the headline matrix's plan)
+    // made this check 1.8 ms of the headline matrix's plan; the rows cut into pieces over a second grid dimension: 2.8 ms
+    // -- a million workgroups that mostly have nothing to do)
     bool b = false;
     const int64_t step = (int64_t)blockDim.x * 4;
     for (int64_t k0 = s + threadIdx.x; k0 + 1 < e; k0 += step) {
@@ -360,14 +361,31 @@ __global__ void heavy_tilecut_kernel(const int32_t *__restrict__ tile_row, int64
     tile_cut[t] = lo;
 }
 
+// XCD-aware walk over (column block, row chunk): workgroup g of a grid of xcd_block_chunk_grid() works on block b and
+// chunk q, and the workgroups one XCD receives (g % 8) are ITS chunks (q % 8 == g % 8), block after block.  A row's entries
+// in consecutive column blocks are neighbours in memory (a few entries each): walked this way the lines that hold them are
+// fetched into one L2 once instead of once per block by whichever XCD the flat index fell on (tier 1's count + fill: 1.8 ->
+// 1.1 ms of the headline matrix's plan; tier 0's acc_fill_kernel, a wavefront per 64 pairs, did not gain: 2.6 -> 3.0 ms).
+__device__ __forceinline__ bool xcd_block_chunk(int64_t g, int32_t chunks, int32_t n_blocks, int32_t &b, int32_t &q)
+{
+    const int32_t per = (chunks + 7) / 8;
+    const int64_t idx = g / 8;
+    b = (int32_t)(idx / per);
+    q = (int32_t)(g % 8) + 8 * (int32_t)(idx % per);
+    return b < n_blocks && q < chunks;
+}
+static inline int64_t xcd_block_chunk_grid(int64_t chunks, int64_t n_blocks) { return 8 * ceil_div(chunks, 8) * n_blocks; }
+
 template <class P>
 __global__ void panel_count_kernel(const P *__restrict__ rp, const int32_t *__restrict__ ci,
                                    const int32_t *__restrict__ heavy_row, int32_t n_heavy, int32_t n_blocks,
                                    int32_t cb, int64_t *__restrict__ cnt)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_heavy * n_blocks) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);      // index = b * H + c
+    int32_t b, q;
+    if (!xcd_block_chunk(blockIdx.x, (n_heavy + (int)blockDim.x - 1) / (int)blockDim.x, n_blocks, b, q)) return;
+    const int32_t c = q * (int)blockDim.x + (int)threadIdx.x;
+    if (c >= n_heavy) return;
+    const int64_t i = (int64_t)b * n_heavy + c;      // index = b * H + c
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
@@ -381,12 +399,13 @@ __global__ void panel_fill_kernel(const P *__restrict__ rp, const int32_t *__res
                                   int32_t cb, const int64_t *__restrict__ off, PP *__restrict__ prp,
                                   int32_t *__restrict__ pci, double *__restrict__ pvs)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t pairs = (int64_t)n_heavy * n_blocks;
-    if (i > pairs) return;
+    int32_t b, q;
+    if (!xcd_block_chunk(blockIdx.x, (n_heavy + (int)blockDim.x - 1) / (int)blockDim.x, n_blocks, b, q)) return;
+    const int32_t c = q * (int)blockDim.x + (int)threadIdx.x;
+    if (c >= n_heavy) return;
+    const int64_t i = (int64_t)b * n_heavy + c, pairs = (int64_t)n_heavy * n_blocks;
     prp[i] = (PP)off[i];
-    if (i == pairs) return;
-    const int32_t b = (int32_t)(i / n_heavy), c = (int32_t)(i % n_heavy);
+    if (i == pairs - 1) prp[pairs] = (PP)off[pairs];
     const int32_t r = heavy_row[c];
     const int64_t s = rp[r], e = rp[r + 1];
     const int64_t lo = lower_bound_col(ci, s, e, (int64_t)b * cb);
@@ -511,7 +530,9 @@ __global__ __launch_bounds__(256) void acc_pairstart_kernel(const P *__restrict_
                                                            const int32_t *__restrict__ task_piece, int64_t n_tasks,
                                                            int32_t *__restrict__ pstart)
 {
-    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    // (an XCD, blockIdx % 8, takes a contiguous range of the tasks: neighbouring rows share the lines of pstart they write)
+    const int64_t wpg = blockDim.x / WAVE, per = ((int64_t)gridDim.x + 7) / 8;
+    const int64_t q = (((int64_t)blockIdx.x % 8) * per + (int64_t)blockIdx.x / 8) * wpg + threadIdx.x / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
     if (q >= n_tasks) return;
     const int32_t c = task_row[q];
@@ -567,15 +588,15 @@ __global__ __launch_bounds__(256) void acc_gap_kernel(int64_t *__restrict__ cnt,
 // shard at 580 tiles per workgroup, 0.218 -> 0.224 on the headline matrix; any other workgroup count restored the rate.)
 __device__ __forceinline__ int64_t acc_phys_tile(int64_t t, const int64_t *__restrict__ wg_t0, int32_t n_wg)
 {
-    int32_t lo = 0, hi = n_wg - 1;      // the workgroup with wg_t0[w] <= t < wg_t0[w + 1]
-    while (lo < hi) {
-        const int32_t mid = lo + ((hi - lo + 1) >> 1);
-        if (wg_t0[mid] <= t)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    return (t - wg_t0[lo]) * n_wg + lo;
+    // the workgroup with wg_t0[w] <= t < wg_t0[w + 1], wg_t0[w] = floor(n_tiles w / n_wg) (build_acc_panel): w is
+    // floor(t n_wg / n_tiles) or a neighbour -- an estimate and two looks at the table instead of a bisection per entry
+    // (eight dependent loads each, for every entry of tier 0)
+    const int64_t n_tiles = wg_t0[n_wg];
+    int64_t w = (int64_t)((double)t * (double)n_wg / (double)(n_tiles > 0 ? n_tiles : 1));      // (an estimate: the table decides)
+    w = w > n_wg - 1 ? n_wg - 1 : (w < 0 ? 0 : w);
+    while (w > 0 && wg_t0[w] > t) w--;
+    while (w + 1 < n_wg && wg_t0[w + 1] <= t) w++;
+    return (t - wg_t0[w]) * n_wg + w;
 }
 
 // One wavefront per 64 consecutive (block, heavy row) pairs of ONE block: their slots are one contiguous range of the
@@ -685,6 +706,18 @@ __device__ __forceinline__ int32_t ls_row_of(const P *__restrict__ rpv, int32_t 
     return lo;
 }
 
+// tile_row[t] = the row that holds a tile's first entry, tile_row[n_tiles] = the last row: the fill kernel then looks for an
+// entry's row between its tile's bounds (9 steps over neighbouring pointers instead of 23 over the whole array: 1.07 ms of
+// the headline matrix's plan)
+template <class P>
+__global__ void ls_tilerow_kernel(const P *__restrict__ rpv, int32_t nrows, int64_t n_ent, int64_t n_tiles, int32_t *__restrict__ tile_row)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const int64_t e0 = t * ACC_TILE;
+    tile_row[t] = t < n_tiles && e0 < n_ent ? ls_row_of(rpv, nrows, e0) : nrows - 1;
+}
+
 template <class P>
 __global__ void ls_rowflag_kernel(const P *__restrict__ rpv, int32_t nrows, int32_t *__restrict__ flag)
 {
@@ -715,7 +748,8 @@ template <class P, int VT, class SV>
 __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src, const P *__restrict__ rpv, int32_t nrows,
                                                      const int32_t *__restrict__ ci, const void *__restrict__ vs,
                                                      int64_t n_ent, int64_t n_slots, const int32_t *__restrict__ slot_map, SV *__restrict__ svals,
-                                                     uint32_t *__restrict__ sidx, const P *__restrict__ rp_len)
+                                                     uint32_t *__restrict__ sidx, const P *__restrict__ rp_len,
+                                                     const int32_t *__restrict__ tile_row)
 {
     // rp_len (dense rows): the view's own row pointers; rpv then gives every row at least one slot, and a row that is
     // empty in rp_len becomes one padding entry that opens (and is) its run
@@ -727,7 +761,15 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
     double v = 0.0;
     uint32_t ix = LS_PAD;
     if (L < n_ent) {
-        const int32_t r = ls_row_of(rpv, nrows, L);
+        int32_t lo = tile_row[t], hi = tile_row[t + 1];      // ls_row_of between the tile's bounds
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)rpv[mid + 1] > L)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const int32_t r = lo;
         const int64_t first = (int64_t)rpv[r];
         if (rp_len && rp_len[r + 1] == rp_len[r]) {
             ix = LS_PAD | LS_START_BIT;
@@ -747,12 +789,12 @@ __global__ __launch_bounds__(256) void ls_fill_kernel(const P *__restrict__ src,
 // per tile: run numbering base
 template <class P>
 __global__ void ls_tilebase_kernel(const P *__restrict__ rpv, int32_t nrows, const int32_t *__restrict__ ridx, int64_t n_tiles,
-                                   int32_t *__restrict__ tile_base)
+                                   const int32_t *__restrict__ tile_row, int32_t *__restrict__ tile_base)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const int64_t e0 = t * ACC_TILE;      // (< the entry count: the stream has no empty tile)
-    const int32_t r = ls_row_of(rpv, nrows, e0);
+    const int32_t r = tile_row[t];
     tile_base[t] = ridx[r] + ((int64_t)rpv[r] == e0 ? 0 : 1);
 }
 
@@ -791,7 +833,7 @@ static int build_panel(Matrix *m, Panel *pn, const std::vector<int32_t> &rows, i
     CSRK_TRY(stage_h2d(pn->row_list.p, rows.data(), (size_t)n * 4, s));
     DevBuf off, bends;
     CSRK_TRY(off.alloc((size_t)(pairs + 1) * 8));
-    const unsigned g = (unsigned)ceil_div(pairs + 1, 256);
+    const unsigned g = (unsigned)xcd_block_chunk_grid(ceil_div(n, 256), nb);
     panel_count_kernel<P><<<g, 256, 0, s>>>(rp, m->d_colinds, pn->row_list.as<int32_t>(), n, nb, cb, off.as<int64_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(exclusive_scan_i64(off.as<int64_t>(), off.as<int64_t>(), pairs, s));
@@ -948,7 +990,7 @@ static int build_acc_panel(Matrix *m, AccPanel *ap, const int32_t *rows, const i
     CSRK_TRY(d_tpiece.alloc((size_t)(n_tasks ? n_tasks : 1) * 4));
     CSRK_TRY(stage_h2d(d_trow.p, trow.data(), (size_t)n_tasks * 4, s));
     CSRK_TRY(stage_h2d(d_tpiece.p, tpiece.data(), (size_t)n_tasks * 4, s));
-    acc_pairstart_kernel<P><<<(unsigned)ceil_div(n_tasks * WAVE, 256), 256, 0, s>>>(
+    acc_pairstart_kernel<P><<<(unsigned)(ceil_div(ceil_div(n_tasks * WAVE, 256), 8) * 8), 256, 0, s>>>(
         rp, m->d_colinds, ap->row_list.as<int32_t>(), n, nb, ACC_CB, d_trow.as<int32_t>(), d_tpiece.as<int32_t>(), n_tasks,
         pstart.as<int32_t>());
     CSRK_LAUNCH_CHECK();
@@ -1119,10 +1161,29 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
         int64_t n_min = 0;
         for (int32_t c = 0; c < n_cut; c++) n_min += lens[c] >= HEAVY_MIN;
         if (n_min < ACC_MAXROWS && n_cut > n_min) {
-            std::vector<int64_t> sl(lens);
             const size_t kth = (size_t)(n_cut < ACC_MAXROWS ? n_cut : ACC_MAXROWS) - 1;
-            std::nth_element(sl.begin(), sl.begin() + kth, sl.end(), [](int64_t a, int64_t b) { return a > b; });
-            int64_t thr = sl[kth];
+            // the kth longest row's length: a histogram of the lengths below 2^16 decides it (nth_element over 10^5 rows was
+            // 0.4 ms of the plan), unless the kth row is longer than that
+            int64_t thr = -1;
+            {
+                constexpr int64_t HB = 1 << 16;
+                std::vector<int32_t> hist((size_t)HB + 1, 0);
+                for (int32_t c = 0; c < n_cut; c++) hist[(size_t)(lens[c] < HB ? lens[c] : HB)]++;
+                int64_t seen = hist[(size_t)HB];
+                if (seen <= (int64_t)kth)
+                    for (int64_t v = HB - 1; v >= 0; v--) {
+                        seen += hist[(size_t)v];
+                        if (seen > (int64_t)kth) {
+                            thr = v;
+                            break;
+                        }
+                    }
+            }
+            if (thr < 0) {
+                std::vector<int64_t> sl(lens);
+                std::nth_element(sl.begin(), sl.begin() + kth, sl.end(), [](int64_t a, int64_t b) { return a > b; });
+                thr = sl[kth];
+            }
             // rows tied with the kth must not push the group over its capacity
             int64_t n_ge = 0;
             for (int32_t c = 0; c < n_cut; c++) n_ge += lens[c] >= thr;
@@ -1136,6 +1197,9 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
     std::vector<int32_t> r0, r1;     // tier 0: >= HEAVY_MIN entries; tier 1: the rest of the cut rows
     std::vector<int64_t> len0;
     int64_t nnz1 = 0;
+    r0.reserve((size_t)n_cut);
+    r1.reserve((size_t)n_cut);
+    len0.reserve((size_t)n_cut);
     for (int32_t c = 0; c < n_cut; c++) {
         if (lens[c] >= HEAVY_MIN) {
             r0.push_back(rows[c]);
@@ -1151,9 +1215,9 @@ static int build_heavy_split(Matrix *m, SpmvPlan *p, hipStream_t s, bool allow_t
 
     p->n_heavy = n_cut;
     p->nnz_light = m->nnz - nnz_cut;
-    p->t0_rows = r0;
-    p->t0_lens = len0;
-    p->t1_rows = r1;
+    p->t0_rows = std::move(r0);
+    p->t0_lens = std::move(len0);
+    p->t1_rows = std::move(r1);
     p->t1_nnz = nnz1;
     tr.lap("  split: host lists");
     return CSRK_OK;
@@ -1366,16 +1430,22 @@ static int build_stream(Matrix *m, LightStream *ls, const P *src, const P *rpv, 
     CSRK_TRY(ls->vals.alloc((size_t)n_tiles * ACC_TILE * (ls->f32 ? 4 : 8)));
     CSRK_TRY(ls->idx.alloc((size_t)n_tiles * ACC_TILE * 4));
     ls->idx24 = false;
+    DevBuf tile_row;
+    CSRK_TRY(tile_row.alloc((size_t)(n_tiles + 1) * 4));
+    ls_tilerow_kernel<P><<<(unsigned)ceil_div(n_tiles + 1, 256), 256, 0, s>>>(rpv, nrows_view, n_ent, n_tiles, tile_row.as<int32_t>());
+    CSRK_LAUNCH_CHECK();
     if (ls->f32)
         ls_fill_kernel<P, VT, float><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<float>(), ls->idx.as<uint32_t>(), rp_len);
+            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<float>(), ls->idx.as<uint32_t>(), rp_len,
+            tile_row.as<int32_t>());
     else
         ls_fill_kernel<P, VT, double><<<(unsigned)ceil_div(n_tiles * ACC_TILE, 256), 256, 0, s>>>(
-            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len);
+            src, rpv, nrows_view, ci, vs, n_ent, n_tiles * ACC_TILE, slot_map, ls->vals.as<double>(), ls->idx.as<uint32_t>(), rp_len,
+            tile_row.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->tile_base.alloc((size_t)n_tiles * 4));
     ls_tilebase_kernel<P><<<(unsigned)ceil_div(n_tiles, 256), 256, 0, s>>>(
-        rpv, nrows_view, ridx.as<int32_t>(), n_tiles, ls->tile_base.as<int32_t>());
+        rpv, nrows_view, ridx.as<int32_t>(), n_tiles, tile_row.as<int32_t>(), ls->tile_base.as<int32_t>());
     CSRK_LAUNCH_CHECK();
     CSRK_TRY(ls->carry_row.alloc((size_t)n_tiles * 4));
     CSRK_TRY(ls->carry_val.alloc((size_t)n_tiles * 8));
