@@ -599,6 +599,10 @@ def main():
             print(json.dumps(out))
             sys.exit('PARITY FAILURE: GPU result differs from the oracle')
 
+    # (the timed handles go first: their plans' buffers return to the library's pool, which the second handle below draws on)
+    for hc in op_handles:
+        check(lib.csrk_free(hc))
+    check(lib.csrk_free(h))
     if world == 1 and not distd:
         # What a caller WITHOUT a kept handle gets (the reference makes one per product, csr/csr.py:580-583): the first
         # product on a fresh handle runs the plan-less merge-path kernel over the CSR arrays as they are.  Timed here on a
@@ -614,6 +618,13 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         pl_ms = e0.elapsed_time(e1)
+        # ... and its second product builds the plan again, this time out of the library's pool: what the builders themselves
+        # cost (the figure above, taken in a fresh process, also holds the runtime's first allocations -- a hipMalloc of tier
+        # 0's 1 GB array has been seen to take 30-40 ms in some processes and 0.03 in others: DESIGN.md section 4)
+        t_w = time.perf_counter()
+        check(lib.csrk_spmv_device(h2.value, x.data_ptr(), y2.data_ptr(), None))
+        torch.cuda.synchronize()
+        plan2_ms = (time.perf_counter() - t_w) * 1e3
         check(lib.csrk_free(h2))
         del y2
         roofline['without_a_plan'] = {
@@ -621,10 +632,10 @@ def main():
             'ms': round(pl_ms, 4), 'frac_whole_spmv': round(whole_bytes / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'plan_build_call_ms': None if plan_ms is None else round(plan_ms, 2), 'plan_bytes': int(st[25]),
             'planned_products_to_amortise_the_plan': None if plan_ms is None or pl_ms <= ms_per_step else
-            int(np.ceil(plan_ms / (pl_ms - ms_per_step)))}
-    for hc in op_handles:
-        check(lib.csrk_free(hc))
-    check(lib.csrk_free(h))
+            int(np.ceil(plan_ms / (pl_ms - ms_per_step))),
+            'plan_build_call_ms_from_the_pool': round(plan2_ms, 2),
+            'planned_products_to_amortise_it_from_the_pool': None if pl_ms <= ms_per_step else
+            int(np.ceil(plan2_ms / (pl_ms - ms_per_step)))}
     if world == 1 and not distd and not args.no_secondary and args.scale == 1.0:
         # the other BASELINE configs, AFTER the SpMV has been timed and checked (nothing above depends on this):
         # each entry carries ms, algorithmic bytes, frac of 8 TB/s, a parity flag and the oracle's time on a stated sample
