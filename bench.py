@@ -470,6 +470,9 @@ def main():
         # stream is narrower than the CSR arrays it replaces
         'stream_bytes': dom['stream_bytes'], 'achieved_stream_gbs': dom['stream_gbs'],
         'frac_stream_of_measured_copy_peak_6290': round(dom['stream_gbs'] / 6290.0, 4),
+        # ... and by the counter traffic over this run's kernel time: what the kernel really moves, against the 8 TB/s spec
+        'frac_by_counter_traffic': round(dom['traffic'] / (dom['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                   if dom['traffic'] and dom['ms'] else None,
         # THE number BASELINE.json asks for: the whole 2.60 GB SpMV over the step (wall: small kernels and launch gaps
         # included), as a fraction of the 8 TB/s roofline; target >= 0.60
         'frac_whole_spmv_over_step': frac_step,
